@@ -1,0 +1,112 @@
+/*
+ * ofxcv_hip.h -- C ABI of libofxcv_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * OpenCV calls behind the openfx-opencv render() actions.
+ *
+ * Every entry point replaces one call the reference makes into OpenCV / openfx-supportext;
+ * the reference call site is cited next to each declaration (paths relative to the reference
+ * tree).  Plain pointers and sizes only; `stream` is a hipStream_t passed as void* (NULL = the
+ * context's own compute stream).  All functions return OFXCV_OK (0) or a negative error code
+ * and never throw; ofxcv_last_error() gives the text of the last failure on a context.
+ *
+ * Pointer conventions: parameters named d_* are DEVICE pointers (HBM), h_* are HOST pointers.
+ * Strides (`*_step`, `*_row_bytes`) are in bytes, like cv::Mat::step / kOfxImagePropRowBytes.
+ */
+#ifndef OFXCV_HIP_H
+#define OFXCV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFXCV_OK 0
+#define OFXCV_ERR_INVALID (-1)     /* bad argument (NULL, non-positive size, ...)            */
+#define OFXCV_ERR_HIP (-2)         /* a HIP runtime call failed (text in ofxcv_last_error)   */
+#define OFXCV_ERR_MEMORY (-3)      /* device / pinned-host allocation failed                 */
+#define OFXCV_ERR_UNSUPPORTED (-4) /* parameter combination outside the reference's use      */
+#define OFXCV_ERR_NO_DEVICE (-5)   /* no gfx950 device visible                               */
+
+typedef struct ofxcv_ctx ofxcv_ctx;
+
+/* ---- context ------------------------------------------------------------------------------
+ * One context = one device + its scratch (pyramid / polynomial-expansion planes, LUT, pinned
+ * staging, two streams).  A context serves one call at a time; concurrent render() threads
+ * (VectorGenerator is eRenderFullySafe, VectorGenerator.cpp:108) each take their own. */
+int ofxcv_device_count(void);
+int ofxcv_ctx_create(int device, ofxcv_ctx **out);
+void ofxcv_ctx_destroy(ofxcv_ctx *ctx);
+const char *ofxcv_last_error(const ofxcv_ctx *ctx);
+const char *ofxcv_status_string(int status);
+int ofxcv_ctx_device(const ofxcv_ctx *ctx);
+/* the context's compute stream (hipStream_t), used whenever a `stream` argument is NULL */
+void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
+/* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL) */
+int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
+
+/* ---- F0: f32 linear RGB(A) -> 8-bit sRGB luma ---------------------------------------------
+ * replaces OFX::Color::Lut::to_byte_grayscale_nodither as called by
+ * GenericOpenCVPlugin::fetchCVImage8UGrayscale (OpenCV/GenericOpenCVPlugin.cpp:223-265, :261). */
+int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_row_bytes, int ncomp,
+                            int width, int height, uint8_t *d_dst, ptrdiff_t dst_row_bytes, void *stream);
+
+/* ---- F1-F6: dense Farneback optical flow --------------------------------------------------
+ * replaces cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize,
+ * iterations, poly_n, poly_sigma, flags) at VectorGenerator/VectorGenerator.cpp:403
+ * (the copyMakeBorder calls at :387-388 pad by zero pixels and are the identity).
+ * prev/next: 8-bit single channel, flow: 2-channel interleaved f32 (CV_32FC2), all in HBM.
+ * Only flags == 0 is supported (the reference hard-codes 0). */
+int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step,
+                                      const uint8_t *d_next, size_t next_step, float *d_flow,
+                                      size_t flow_step, int width, int height, double pyr_scale,
+                                      int levels, int winsize, int iterations, int poly_n,
+                                      double poly_sigma, int flags, void *stream);
+
+/* ---- F7: flow -> RGBA write-back ----------------------------------------------------------
+ * replaces the loop at VectorGenerator/VectorGenerator.cpp:494-519.  chan_u_mask/chan_v_mask:
+ * bit c set = RGBA channel c receives flow.x / flow.y (divided by the render scale); channels
+ * in neither mask are left untouched. */
+int ofxcv_flow_to_rgba(ofxcv_ctx *ctx, const float *d_flow, size_t flow_step, int width, int height,
+                       float *d_dst, ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask,
+                       double render_scale_x, double render_scale_y, void *stream);
+
+/* ---- whole VectorGenerator::calcOpticalFlow for host-resident OFX images --------------------
+ * replaces VectorGeneratorPlugin::calcOpticalFlow (VectorGenerator/VectorGenerator.cpp:353-520,
+ * Farneback branch) including the CVImageWrapper marshalling of GenericOpenCVPlugin.cpp:58-165:
+ * both f32 frames are staged through pinned memory on a copy stream while the compute stream
+ * runs the LUT / flow / scatter kernels, and only the mapped RGBA channels of h_dst are written. */
+int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes,
+                              const float *h_other, ptrdiff_t other_row_bytes, int ncomp,
+                              int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
+                              unsigned chan_u_mask, unsigned chan_v_mask, double render_scale_x,
+                              double render_scale_y, int levels, int iterations, int poly_n,
+                              double poly_sigma);
+
+/* ---- stage-level entry points (the internal stages of calcOpticalFlowFarneback) ------------
+ * Exposed so each stage can be parity-checked on its own against the oracle's restatement of
+ * modules/video/src/optflowgf.cpp.  Planes: a 5-channel field is stored as 5 consecutive planes
+ * of `plane_pitch` floats per row (ofxcv_farneback_plane_pitch(width)), plane stride pitch*height. */
+int ofxcv_farneback_plane_pitch(int width);
+int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels);
+int ofxcv_farneback_level_geom(int width, int height, double pyr_scale, int k, int *lw, int *lh,
+                               double *sigma, int *ksize);
+/* convertTo(CV_32F) + GaussianBlur(ksize, sigma) + resize(lw x lh, INTER_LINEAR); d_I is lw*lh f32 packed */
+int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step, int width, int height,
+                              int lw, int lh, double sigma, int ksize, float *d_I, void *stream);
+/* FarnebackPolyExp: d_I w*h packed -> d_R 5 planes */
+int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n,
+                            double poly_sigma, void *stream);
+/* FarnebackUpdateMatrices over all rows; d_flow is 2-ch interleaved with flow_step bytes per row */
+int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow,
+                                    size_t flow_step, int width, int height, float *d_M, void *stream);
+/* FarnebackUpdateFlow_Blur (box window `winsize`): flow = solve(blur(M_in)); if update!=0 also
+ * M_out = UpdateMatrices(R0,R1,flow).  d_flow may be NULL when update!=0 (flow stays on chip). */
+int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_M_in,
+                                     float *d_M_out, float *d_flow, size_t flow_step, int width, int height,
+                                     int winsize, int update, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,242 @@
+"""openfx-opencv on MI355X: Python host-side mirror of the C ABI in include/ofxcv_hip.h.
+
+The product is lib/libofxcv_hip.so (hand-written gfx950 HIP kernels behind a C ABI) plus the OFX
+plugin bundles built from plugin/.  This module is test/bench plumbing around it: it loads the
+library with ctypes and passes torch CUDA(ROCm) tensors' device pointers and the current torch
+stream straight through.  There is NO CPU fallback: if the library is missing or fails to load,
+importing a compute entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libofxcv_hip.so")
+
+OK = 0
+_lib = None
+
+
+class OfxcvError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("ofxcv status %d: %s" % (status, text))
+        self.status = status
+
+
+def build(verbose=False):
+    """Compile libofxcv_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _HERE, "-j4"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library.  import torch first so both share one libamdhip64.so.7."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OfxcvError(-5, "libofxcv_hip.so not built (%s); run __graft_entry__.build()" % LIB_PATH)
+        try:
+            import torch  # noqa: F401  (loads torch's HIP runtime so SONAME libamdhip64.so.7 is shared)
+        except ImportError:
+            pass
+        l = C.CDLL(LIB_PATH)
+        l.ofxcv_last_error.restype = C.c_char_p
+        l.ofxcv_status_string.restype = C.c_char_p
+        l.ofxcv_ctx_stream.restype = C.c_void_p
+        _lib = l
+    return _lib
+
+
+# every symbol include/ofxcv_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
+    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
+    "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
+    "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
+]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class _Ordered:
+    """Runs a C-ABI call on the context's own compute stream, ordered after the work already queued on
+    torch's current stream and before whatever torch queues next (two event waits, skipped when the
+    caller already works inside `with torch.cuda.stream(ctx.stream)`)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        import torch
+        self.cur = torch.cuda.current_stream()
+        self.same = self.cur.cuda_stream == self.ctx.stream.cuda_stream
+        if not self.same:
+            self.ctx.stream.wait_stream(self.cur)
+        return None  # NULL stream argument = the context's compute stream
+
+    def __exit__(self, *exc):
+        if not self.same:
+            self.cur.wait_stream(self.ctx.stream)
+        return False
+
+
+class Context:
+    """One device context (ofxcv_ctx): scratch planes, LUT, staging.  Not thread-safe: one per thread."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().ofxcv_ctx_create(C.c_int(device), C.byref(self._h))
+        if rc != OK:
+            raise OfxcvError(rc, lib().ofxcv_status_string(rc).decode())
+        self.device = device
+        import torch
+        self.stream = torch.cuda.ExternalStream(lib().ofxcv_ctx_stream(self._h), device=device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().ofxcv_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise OfxcvError(rc, lib().ofxcv_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(lib().ofxcv_ctx_synchronize(self._h, None))
+
+    def _call(self, fn, *args):
+        """fn(ctx, *args, stream=NULL) on the context's compute stream, ordered against torch's current stream."""
+        with _Ordered(self):
+            self._check(fn(self._h, *args, None))
+
+    # ---- F0 ----
+    def to_byte_grayscale(self, src, out=None):
+        """src: HxWx{3,4} float32 CUDA tensor (linear RGB[A]) -> HxW uint8 sRGB luma."""
+        import torch
+        assert src.is_cuda and src.dtype == torch.float32 and src.dim() == 3 and src.stride(2) == 1 and src.stride(1) == src.shape[2]
+        h, w, nc = src.shape
+        if out is None:
+            out = torch.empty((h, w), dtype=torch.uint8, device=src.device)
+        self._call(lib().ofxcv_to_byte_grayscale, _ptr(src), C.c_ssize_t(src.stride(0) * 4), C.c_int(nc), C.c_int(w), C.c_int(h),
+                   _ptr(out), C.c_ssize_t(out.stride(0)))
+        return out
+
+    # ---- F1-F6 ----
+    def calc_optical_flow_farneback(self, prev, nxt, flow=None, pyr_scale=0.5, levels=3, winsize=3, iterations=15,
+                                    poly_n=5, poly_sigma=1.1, flags=0):
+        """Mirror of cv::calcOpticalFlowFarneback: prev/nxt HxW uint8 CUDA tensors -> HxWx2 float32 flow."""
+        import torch
+        assert prev.is_cuda and nxt.is_cuda and prev.dtype == torch.uint8 and nxt.dtype == torch.uint8
+        assert prev.shape == nxt.shape and prev.dim() == 2 and prev.stride(1) == 1 and nxt.stride(1) == 1
+        h, w = prev.shape
+        if flow is None:
+            flow = torch.empty((h, w, 2), dtype=torch.float32, device=prev.device)
+        assert flow.shape == (h, w, 2) and flow.dtype == torch.float32 and flow.stride(2) == 1 and flow.stride(1) == 2
+        self._call(lib().ofxcv_calc_optical_flow_farneback, _ptr(prev), C.c_size_t(prev.stride(0)), _ptr(nxt),
+                   C.c_size_t(nxt.stride(0)), _ptr(flow), C.c_size_t(flow.stride(0) * 4), C.c_int(w), C.c_int(h),
+                   C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n),
+                   C.c_double(poly_sigma), C.c_int(flags))
+        return flow
+
+    # ---- F7 ----
+    def flow_to_rgba(self, flow, dst, chan_u_mask, chan_v_mask, rs_x=1.0, rs_y=1.0):
+        import torch
+        h, w, _ = flow.shape
+        assert dst.shape == (h, w, 4) and dst.dtype == torch.float32 and dst.is_cuda
+        self._call(lib().ofxcv_flow_to_rgba, _ptr(flow), C.c_size_t(flow.stride(0) * 4), C.c_int(w), C.c_int(h), _ptr(dst),
+                   C.c_ssize_t(dst.stride(0) * 4), C.c_uint(chan_u_mask), C.c_uint(chan_v_mask), C.c_double(rs_x), C.c_double(rs_y))
+        return dst
+
+    # ---- whole calcOpticalFlow on host images (numpy arrays) ----
+    def vectorgen_flow_host(self, ref, other, dst, chan_u_mask, chan_v_mask, rs_x=1.0, rs_y=1.0, levels=3, iterations=15,
+                            poly_n=5, poly_sigma=1.1):
+        import numpy as np
+        h, w, nc = ref.shape
+        assert ref.dtype == np.float32 and other.dtype == np.float32 and dst.dtype == np.float32 and dst.shape == (h, w, 4)
+        assert ref.strides[1] == nc * 4 and other.strides[1] == nc * 4 and dst.strides[1] == 16
+        self._check(lib().ofxcv_vectorgen_flow_host(
+            self._h, C.c_void_p(ref.ctypes.data), C.c_ssize_t(ref.strides[0]), C.c_void_p(other.ctypes.data),
+            C.c_ssize_t(other.strides[0]), C.c_int(nc), C.c_int(w), C.c_int(h), C.c_void_p(dst.ctypes.data),
+            C.c_ssize_t(dst.strides[0]), C.c_uint(chan_u_mask), C.c_uint(chan_v_mask), C.c_double(rs_x), C.c_double(rs_y),
+            C.c_int(levels), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma)))
+        return dst
+
+    # ---- stage-level (parity tests) ----
+    def farneback_pyr_image(self, img, lw, lh, sigma, ksize):
+        import torch
+        h, w = img.shape
+        I = torch.empty((lh, lw), dtype=torch.float32, device=img.device)
+        self._call(lib().ofxcv_farneback_pyr_image, _ptr(img), C.c_size_t(img.stride(0)), C.c_int(w), C.c_int(h), C.c_int(lw),
+                   C.c_int(lh), C.c_double(sigma), C.c_int(ksize), _ptr(I))
+        return I
+
+    def farneback_polyexp(self, I, poly_n=5, poly_sigma=1.1):
+        """I: HxW float32 -> 5 x H x pitch float32 planes (use planes_to_hwc to compare with the oracle)."""
+        import torch
+        h, w = I.shape
+        I = I.contiguous()
+        R = torch.zeros((5, h, plane_pitch(w)), dtype=torch.float32, device=I.device)
+        self._call(lib().ofxcv_farneback_polyexp, _ptr(I), C.c_int(w), C.c_int(h), _ptr(R), C.c_int(poly_n), C.c_double(poly_sigma))
+        return R
+
+    def farneback_update_matrices(self, R0, R1, flow):
+        import torch
+        h, w, _ = flow.shape
+        M = torch.zeros_like(R0)
+        self._call(lib().ofxcv_farneback_update_matrices, _ptr(R0), _ptr(R1), _ptr(flow), C.c_size_t(flow.stride(0) * 4), C.c_int(w),
+                   C.c_int(h), _ptr(M))
+        return M
+
+    def farneback_update_flow_blur(self, R0, R1, M, w, winsize=3, update=True):
+        """returns (flow HxWx2, M_out planes or None)"""
+        import torch
+        h = M.shape[1]
+        flow = torch.empty((h, w, 2), dtype=torch.float32, device=M.device)
+        Mo = torch.zeros_like(M) if update else None
+        self._call(lib().ofxcv_farneback_update_flow_blur, _ptr(R0), _ptr(R1), _ptr(M), _ptr(Mo) if update else None, _ptr(flow),
+                   C.c_size_t(w * 8), C.c_int(w), C.c_int(h), C.c_int(winsize), C.c_int(1 if update else 0))
+        return flow, Mo
+
+
+def plane_pitch(w):
+    return int(lib().ofxcv_farneback_plane_pitch(C.c_int(w)))
+
+
+def farneback_num_levels(w, h, pyr_scale=0.5, levels=3):
+    return int(lib().ofxcv_farneback_num_levels(C.c_int(w), C.c_int(h), C.c_double(pyr_scale), C.c_int(levels)))
+
+
+def farneback_level_geom(w, h, pyr_scale, k):
+    lw, lh, ks = C.c_int(), C.c_int(), C.c_int()
+    sg = C.c_double()
+    rc = lib().ofxcv_farneback_level_geom(C.c_int(w), C.c_int(h), C.c_double(pyr_scale), C.c_int(k), C.byref(lw), C.byref(lh),
+                                          C.byref(sg), C.byref(ks))
+    if rc != OK:
+        raise OfxcvError(rc, "level_geom")
+    return lw.value, lh.value, sg.value, ks.value
+
+
+def hwc_to_planes(a, pitch=None):
+    """HxWx5 (torch) -> 5xHxpitch planes, zero padded."""
+    import torch
+    h, w, c = a.shape
+    pitch = pitch or plane_pitch(w)
+    p = torch.zeros((c, h, pitch), dtype=a.dtype, device=a.device)
+    p[:, :, :w] = a.permute(2, 0, 1)
+    return p
+
+
+def planes_to_hwc(p, w):
+    return p[:, :, :w].permute(1, 2, 0).contiguous()

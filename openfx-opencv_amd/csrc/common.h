@@ -1,0 +1,68 @@
+// common.h -- internal definitions shared by the HIP translation units of libofxcv_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "ofxcv_hip.h"
+
+// One growable HBM scratch allocation (never shrinks; freed with the context).
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct ofxcv_ctx {
+    int device = 0;
+    hipStream_t compute = nullptr;  // default stream for kernels when the caller passes NULL
+    hipStream_t copy = nullptr;     // H2D / D2H staging stream of the host-buffer entry points
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    hipEvent_t ev_done = nullptr;
+    char err[512] = {0};
+
+    // F0: 65536-entry 8.8 fixed-point sRGB table (openfx-supportext ofxsLut.h semantics)
+    uint16_t *d_srgb_lut = nullptr;
+
+    // Farneback scratch (sized for the largest frame seen so far)
+    DevBuf fb_planes;  // R0, R1, M0, M1: 4 fields x 5 planes
+    DevBuf fb_tmp;     // blurred half-resolution rows (pyramid) + pyramid image I
+    DevBuf fb_flow;    // two ping-pong coarse flow fields
+    DevBuf fb_coef;    // polyexp / blur coefficient tables
+
+    // host-path staging
+    DevBuf d_stage;            // device side: 2 f32 frames, 2 gray frames, flow, rgba
+    void *h_pinned = nullptr;  // pinned host ring
+    size_t h_pinned_bytes = 0;
+};
+
+int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...);
+int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes);
+
+#define OFXCV_HIP_CHECK(ctx, expr)                                                                    \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return ofxcv_fail((ctx), _e == hipErrorOutOfMemory ? OFXCV_ERR_MEMORY : OFXCV_ERR_HIP,    \
+                              "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define OFXCV_LAUNCH_CHECK(ctx, name)                                                                 \
+    do {                                                                                              \
+        hipError_t _e = hipGetLastError();                                                            \
+        if (_e != hipSuccess)                                                                         \
+            return ofxcv_fail((ctx), OFXCV_ERR_HIP, "launch of %s failed: %s", name, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
+    return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->compute;
+}
+
+static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// host-side cvRound (round half to even) / cvFloor, shared by geometry helpers
+int ofxcv_cv_round(double v);

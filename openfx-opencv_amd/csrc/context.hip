@@ -1,0 +1,108 @@
+// context.hip -- device context, scratch management and error reporting of libofxcv_hip.so.
+#include <cmath>
+#include <new>
+
+#include "common.h"
+
+int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.bytes) return OFXCV_OK;
+    if (b.ptr) {
+        OFXCV_HIP_CHECK(ctx, hipDeviceSynchronize());
+        OFXCV_HIP_CHECK(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.bytes = 0;
+    }
+    OFXCV_HIP_CHECK(ctx, hipMalloc(&b.ptr, bytes));
+    b.bytes = bytes;
+    return OFXCV_OK;
+}
+
+int ofxcv_cv_round(double v) { return (int)std::lrint(v); }
+
+extern "C" {
+
+int ofxcv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ofxcv_status_string(int status) {
+    switch (status) {
+        case OFXCV_OK: return "ok";
+        case OFXCV_ERR_INVALID: return "invalid argument";
+        case OFXCV_ERR_HIP: return "HIP runtime error";
+        case OFXCV_ERR_MEMORY: return "out of memory";
+        case OFXCV_ERR_UNSUPPORTED: return "unsupported parameters";
+        case OFXCV_ERR_NO_DEVICE: return "no usable gfx950 device";
+        default: return "unknown status";
+    }
+}
+
+int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
+    if (!out) return OFXCV_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OFXCV_ERR_NO_DEVICE;
+    ofxcv_ctx *ctx = new (std::nothrow) ofxcv_ctx();
+    if (!ctx) return OFXCV_ERR_MEMORY;
+    ctx->device = device;
+    int rc = OFXCV_OK;
+    auto init = [&]() -> int {
+        OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
+        OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
+        OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
+        OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
+        return OFXCV_OK;
+    };
+    rc = init();
+    if (rc != OFXCV_OK) {
+        fprintf(stderr, "ofxcv_ctx_create: %s\n", ctx->err);
+        ofxcv_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return OFXCV_OK;
+}
+
+void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->d_stage};
+    for (DevBuf *b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (int i = 0; i < 2; i++)
+        if (ctx->ev_h2d[i]) (void)hipEventDestroy(ctx->ev_h2d[i]);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+    if (ctx->compute) (void)hipStreamDestroy(ctx->compute);
+    if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
+    delete ctx;
+}
+
+const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int ofxcv_ctx_device(const ofxcv_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute : nullptr; }
+
+int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ofxcv_stream(ctx, stream)));
+    return OFXCV_OK;
+}
+
+}  // extern "C"

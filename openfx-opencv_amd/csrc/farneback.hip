@@ -1,0 +1,632 @@
+// farneback.hip -- dense Farneback optical flow for gfx950 (MI355X).
+//
+// Replaces cv::calcOpticalFlowFarneback as called at VectorGenerator/VectorGenerator.cpp:403
+// (pyr_scale 0.5, winsize 3, flags 0; levels / iterations / poly_n / poly_sigma are plugin
+// parameters, :390-399).  The stages follow OpenCV's modules/video/src/optflowgf.cpp:
+//   pyramid image   convertTo(32F) + GaussianBlur(full res) + resize(INTER_LINEAR)   [F1,F2]
+//   polyexp         FarnebackPolyExp: separable (2n+1)^2 weighted quadratic fit      [F3]
+//   update          FarnebackUpdateMatrices: warped gather of R1 + border scale      [F4]
+//   blur+solve      FarnebackUpdateFlow_Blur: box window of M, 2x2 solve per pixel   [F5]
+//   prolongation    resize(prevFlow, INTER_LINEAR) * 1/pyr_scale                     [F6]
+//
+// Device data layout: every 5-channel field (R0, R1, M) is stored as 5 planes of
+// `pitch` x height floats (pitch = width rounded up to 64 floats = 256 B) so that a wavefront
+// reading 64 consecutive pixels of one plane issues one fully coalesced 256-byte request.
+// The flow field is 2-channel interleaved (float2 per pixel), as OpenCV returns it.
+//
+// Numerics: every stage evaluates the same IEEE operations in the same order as the CPU code it
+// replaces (f32 products and sums where OpenCV uses float, f64 accumulators where it uses
+// double); the file is compiled with -ffp-contract=off so no FMA contraction changes a rounding.
+// The one deliberate difference: OpenCV's box window keeps running sums (and rounds each row
+// difference to f32 before accumulating it); here each pixel sums its own 3x3 window in f64.
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxGaussTaps = 255;
+constexpr int kMaxPolyN = 15;
+
+struct GaussTaps {
+    int ksize;
+    float k[kMaxGaussTaps];
+};
+
+struct PolyCoef {
+    int n;
+    float g[2 * kMaxPolyN + 1], xg[2 * kMaxPolyN + 1], xxg[2 * kMaxPolyN + 1];  // index k + n
+    double ig11, ig03, ig33, ig55;
+};
+
+// ------------------------------------------------------------------ host-side coefficient prep
+
+// smooth.cpp getGaussianKernel(n, sigma, CV_32F)
+void make_gauss_taps(int n, double sigma, GaussTaps &t) {
+    static const float small_tab[4][7] = {{1.f},
+                                          {0.25f, 0.5f, 0.25f},
+                                          {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
+                                          {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+    const float *fixed = (n % 2 == 1 && n <= 7 && sigma <= 0) ? small_tab[n >> 1] : nullptr;
+    double sigmaX = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2X = -0.5 / (sigmaX * sigmaX);
+    double sum = 0;
+    t.ksize = n;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double v = fixed ? (double)fixed[i] : std::exp(scale2X * x * x);
+        t.k[i] = (float)v;
+        sum += t.k[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) t.k[i] = (float)(t.k[i] * sum);
+}
+
+// optflowgf.cpp FarnebackPrepareGaussian: 1-D weights and the four entries of inv(G) that matter.
+// G is block structured; its inverse is obtained with a Cholesky factorisation like G.inv(DECOMP_CHOLESKY).
+void make_poly_coef(int n, double sigma, PolyCoef &pc) {
+    pc.n = n;
+    float *g = pc.g + n, *xg = pc.xg + n, *xxg = pc.xxg + n;
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += g[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        g[x] = (float)(g[x] * s);
+        xg[x] = (float)(x * g[x]);
+        xxg[x] = (float)(x * x * g[x]);
+    }
+    double G[6][6] = {};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0][0] += g[y] * g[x];
+            G[1][1] += g[y] * g[x] * x * x;
+            G[3][3] += g[y] * g[x] * x * x * x * x;
+            G[5][5] += g[y] * g[x] * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double L[6][6] = {}, Li[6][6] = {};
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double a = G[i][j];
+            for (int k = 0; k < j; k++) a -= L[i][k] * L[j][k];
+            L[i][j] = i == j ? std::sqrt(a) : a / L[j][j];
+        }
+    for (int c = 0; c < 6; c++)
+        for (int i = 0; i < 6; i++) {
+            double a = i == c ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) a -= L[i][k] * Li[k][c];
+            Li[i][c] = a / L[i][i];
+        }
+    auto inv = [&](int i, int j) {
+        double a = 0;
+        for (int k = 0; k < 6; k++) a += Li[k][i] * Li[k][j];
+        return a;
+    };
+    pc.ig11 = inv(1, 1);
+    pc.ig03 = inv(0, 3);
+    pc.ig33 = inv(3, 3);
+    pc.ig55 = inv(5, 5);
+}
+
+// ------------------------------------------------------------------ device helpers
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// imgwarp.cpp resize(INTER_LINEAR) coefficient rule for destination index d
+__device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, float &a0, float &a1) {
+    double scale = (double)ssize / dsize;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    a0 = 1.f - f;
+    a1 = f;
+}
+
+// ------------------------------------------------------------------ F1/F2 pyramid image
+//
+// OpenCV blurs at full resolution and then decimates; only the two source columns / rows that
+// each output sample interpolates between are ever used, so the row filter is evaluated only at
+// those columns (T1: `ntap` samples per output column, all source rows) and the column filter
+// only at the needed rows.  Values are identical to blur-then-resize because the column filter
+// never mixes columns.
+
+__global__ __launch_bounds__(256) void pyr_hblur_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H,
+                                                        int lw, int ntap, GaussTaps gk, float *__restrict__ T1) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    int ncol = lw * ntap;
+    if (c >= ncol) return;
+    int sx;
+    if (ntap == 1) {
+        sx = c;
+    } else {
+        float a0, a1;
+        lerp_coef(c >> 1, W, lw, sx, a0, a1);
+        sx = min(sx + (c & 1), W - 1);
+    }
+    const uint8_t *S = img + (size_t)y * step;
+    const int ksize = gk.ksize, r = ksize >> 1;
+    float s;
+    if (ksize == 3) {
+        s = (float)S[sx] * gk.k[1] + ((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)]) * gk.k[2];
+    } else if (ksize == 5) {
+        s = (float)S[sx] * gk.k[2] + ((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)]) * gk.k[3] +
+            ((float)S[reflect101(sx - 2, W)] + (float)S[reflect101(sx + 2, W)]) * gk.k[4];
+    } else {
+        s = gk.k[0] * (float)S[reflect101(sx - r, W)];
+        for (int j = 1; j < ksize; j++) s += (float)S[reflect101(sx - r + j, W)] * gk.k[j];
+    }
+    T1[(size_t)y * ncol + c] = s;
+}
+
+__device__ __forceinline__ float col_filter(const float *__restrict__ T1, int ncol, int c, int y, int H, const GaussTaps &gk) {
+    const int ksize = gk.ksize, r = ksize >> 1;
+    const float *kc = gk.k + r;
+    if (ksize == 3)
+        return (T1[(size_t)reflect101(y - 1, H) * ncol + c] + T1[(size_t)reflect101(y + 1, H) * ncol + c]) * kc[1] +
+               T1[(size_t)y * ncol + c] * kc[0];
+    float s = kc[0] * T1[(size_t)y * ncol + c];
+    for (int k = 1; k <= r; k++)
+        s += kc[k] * (T1[(size_t)reflect101(y + k, H) * ncol + c] + T1[(size_t)reflect101(y - k, H) * ncol + c]);
+    return s;
+}
+
+__global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__restrict__ T1, int W, int H, int lw, int lh,
+                                                               int ntap, GaussTaps gk, float *__restrict__ I) {
+    int dx = blockIdx.x * blockDim.x + threadIdx.x;
+    int dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx >= lw || dy >= lh) return;
+    int ncol = lw * ntap;
+    float out;
+    if (ntap == 1) {
+        out = col_filter(T1, ncol, dx, dy, H, gk);
+    } else {
+        int sx, sy;
+        float ax0, ax1, b0, b1;
+        lerp_coef(dx, W, lw, sx, ax0, ax1);
+        lerp_coef(dy, H, lh, sy, b0, b1);
+        int sy1 = min(sy + 1, H - 1);
+        float t00 = col_filter(T1, ncol, dx * 2, sy, H, gk), t10 = col_filter(T1, ncol, dx * 2, sy1, H, gk);
+        float r0, r1;
+        if (sx + 1 < W) {
+            float t01 = col_filter(T1, ncol, dx * 2 + 1, sy, H, gk), t11 = col_filter(T1, ncol, dx * 2 + 1, sy1, H, gk);
+            r0 = t00 * ax0 + t01 * ax1;
+            r1 = t10 * ax0 + t11 * ax1;
+        } else {
+            r0 = t00 * 1.f;
+            r1 = t10 * 1.f;
+        }
+        out = r0 * b0 + r1 * b1;
+    }
+    I[(size_t)dy * lw + dx] = out;
+}
+
+// ------------------------------------------------------------------ F3 polynomial expansion
+//
+// One 64x16 output tile per 256-thread block.  The tile of I plus an n-pixel halo is staged in
+// LDS (rows and columns clamped = the replicate border of the reference), the vertical pass
+// writes its three f32 sums per (row, column) back to LDS, and the horizontal pass accumulates
+// the six moments in f64 exactly like the reference's inner loop.
+
+constexpr int kPeTW = 64, kPeTH = 16;
+
+__global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
+                                                      int pitch, PolyCoef pc) {
+    extern __shared__ float lds[];
+    const int n = pc.n;
+    const int cw = kPeTW + 2 * n;          // staged columns
+    const int ldw = cw | 1;                // odd row stride: conflict-free column walks
+    const int ih = kPeTH + 2 * n;          // staged rows
+    float *sI = lds;                       // [ih][ldw]
+    float *sV = lds + ih * ldw;            // [3][kPeTH][ldw]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kPeTW, y0 = blockIdx.y * kPeTH;
+
+    for (int i = tid; i < ih * cw; i += 256) {
+        int ry = i / cw, rx = i - ry * cw;
+        int gy = clampi(y0 + ry - n, 0, h - 1), gx = clampi(x0 + rx - n, 0, w - 1);
+        sI[ry * ldw + rx] = I[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+
+    const float *g = pc.g + n, *xg = pc.xg + n, *xxg = pc.xxg + n;
+    // vertical pass (float).  Row clamping must follow the *image* border, not the tile border:
+    // the staged rows were clamped on load, so plain offsets +-k already see replicated rows.
+    for (int i = tid; i < kPeTH * cw; i += 256) {
+        int ty = i / cw, cx = i - ty * cw;
+        const float *col = sI + (ty + n) * ldw + cx;
+        float t0 = col[0] * g[0], t1 = 0.f, t2 = 0.f;
+        for (int k = 1; k <= n; k++) {
+            float s0 = col[-k * ldw], s1 = col[k * ldw];
+            float p = s0 + s1;
+            t0 = t0 + g[k] * p;
+            t1 = t1 + xg[k] * (s1 - s0);
+            t2 = t2 + xxg[k] * p;
+        }
+        sV[(0 * kPeTH + ty) * ldw + cx] = t0;
+        sV[(1 * kPeTH + ty) * ldw + cx] = t1;
+        sV[(2 * kPeTH + ty) * ldw + cx] = t2;
+    }
+    __syncthreads();
+
+    const size_t plane = (size_t)pitch * h;
+    const int lx = tid & 63;
+    for (int ty = tid >> 6; ty < kPeTH; ty += 4) {
+        int x = x0 + lx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const float *r0 = sV + (0 * kPeTH + ty) * ldw + lx + n;
+        const float *r1 = sV + (1 * kPeTH + ty) * ldw + lx + n;
+        const float *r2 = sV + (2 * kPeTH + ty) * ldw + lx + n;
+        float g0 = g[0];
+        double b1 = r0[0] * g0, b2 = 0, b3 = r1[0] * g0, b4 = 0, b5 = r2[0] * g0, b6 = 0;
+        for (int k = 1; k <= n; k++) {
+            double tg = r0[k] + r0[-k];
+            g0 = g[k];
+            b1 += tg * g0;
+            b4 += tg * xxg[k];
+            b2 += (r0[k] - r0[-k]) * xg[k];
+            b3 += (r1[k] + r1[-k]) * g0;
+            b6 += (r1[k] - r1[-k]) * xg[k];
+            b5 += (r2[k] + r2[-k]) * g0;
+        }
+        size_t o = (size_t)y * pitch + x;
+        R[o + 1 * plane] = (float)(b2 * pc.ig11);
+        R[o + 0 * plane] = (float)(b3 * pc.ig11);
+        R[o + 3 * plane] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+        R[o + 2 * plane] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+        R[o + 4 * plane] = (float)(b6 * pc.ig55);
+    }
+}
+
+// ------------------------------------------------------------------ F4 update matrices (per pixel)
+
+struct M5 {
+    float v[5];
+};
+
+__device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1, int x, int y,
+                                                 int w, int h, int pitch, float dx, float dy) {
+    const size_t plane = (size_t)pitch * h;
+    const size_t o = (size_t)y * pitch + x;
+    float fx = x + dx, fy = y + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1;
+    fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float *p = R1 + (size_t)y1 * pitch + x1;
+        r2 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
+        p += plane;
+        r3 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
+        p += plane;
+        r4 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
+        p += plane;
+        r5 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
+        p += plane;
+        r6 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
+        r4 = (R0[o + 2 * plane] + r4) * 0.5f;
+        r5 = (R0[o + 3 * plane] + r5) * 0.5f;
+        r6 = (R0[o + 4 * plane] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[o + 2 * plane];
+        r5 = R0[o + 3 * plane];
+        r6 = R0[o + 4 * plane] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[o + plane] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+
+    constexpr int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                      (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    M5 m;
+    m.v[0] = r4 * r4 + r6 * r6;
+    m.v[1] = (r4 + r5) * r6;
+    m.v[2] = r5 * r5 + r6 * r6;
+    m.v[3] = r4 * r2 + r6 * r3;
+    m.v[4] = r6 * r2 + r5 * r3;
+    return m;
+}
+
+// F6 + first F4 of a level.  MODE 0: zero initial flow (coarsest level); MODE 1: flow prolongated from
+// the coarser level (resize INTER_LINEAR, then * 1/pyr_scale); MODE 2: explicit interleaved flow.
+template <int MODE>
+__global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                              const float *__restrict__ flow, size_t flow_step, int pw, int ph,
+                                                              double inv_pyr_scale, int w, int h, int pitch,
+                                                              float *__restrict__ M) {
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    float dx = 0.f, dy = 0.f;
+    if (MODE == 1) {
+        int sx, sy;
+        float ax0, ax1, b0, b1;
+        lerp_coef(x, pw, w, sx, ax0, ax1);
+        lerp_coef(y, ph, h, sy, b0, b1);
+        int sy1 = min(sy + 1, ph - 1);
+        const float2 *S0 = (const float2 *)((const char *)flow + (size_t)sy * flow_step);
+        const float2 *S1 = (const float2 *)((const char *)flow + (size_t)sy1 * flow_step);
+        float r0x, r0y, r1x, r1y;
+        if (sx + 1 < pw) {
+            float2 a = S0[sx], b = S0[sx + 1], c = S1[sx], d = S1[sx + 1];
+            r0x = a.x * ax0 + b.x * ax1; r0y = a.y * ax0 + b.y * ax1;
+            r1x = c.x * ax0 + d.x * ax1; r1y = c.y * ax0 + d.y * ax1;
+        } else {
+            float2 a = S0[sx], c = S1[sx];
+            r0x = a.x * 1.f; r0y = a.y * 1.f;
+            r1x = c.x * 1.f; r1y = c.y * 1.f;
+        }
+        dx = (float)((double)(r0x * b0 + r1x * b1) * inv_pyr_scale);
+        dy = (float)((double)(r0y * b0 + r1y * b1) * inv_pyr_scale);
+    } else if (MODE == 2) {
+        float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
+        dx = f.x;
+        dy = f.y;
+    }
+    M5 m = update_matrices_px(R0, R1, x, y, w, h, pitch, dx, dy);
+    const size_t plane = (size_t)pitch * h, o = (size_t)y * pitch + x;
+#pragma unroll
+    for (int c = 0; c < 5; c++) M[o + c * plane] = m.v[c];
+}
+
+// ------------------------------------------------------------------ F5 (+F4) one iteration
+//
+// flow = solve(box(M_in)); if UPDATE, M_out = UpdateMatrices(R0, R1, flow) in the same pass so the
+// flow never leaves the registers.  Box sums: horizontal f64 sum of each window row, left to right,
+// then the rows top to bottom (replicated borders = clamped coordinates).
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                                const float *__restrict__ Min, float *__restrict__ Mout,
+                                                                float *__restrict__ flow, size_t flow_step, int w, int h,
+                                                                int pitch, int m, double scale) {
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)pitch * h;
+    double acc[5];
+    for (int i = -m; i <= m; i++) {
+        const float *row = Min + (size_t)clampi(y + i, 0, h - 1) * pitch;
+        double hs[5];
+        for (int j = -m; j <= m; j++) {
+            int xx = clampi(x + j, 0, w - 1);
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double v = (double)row[xx + c * plane];
+                hs[c] = (j == -m) ? v : hs[c] + v;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) acc[c] = (i == -m) ? hs[c] : acc[c] + hs[c];
+    }
+    double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+    double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+    float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+    float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
+    if (UPDATE) {
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        const size_t o = (size_t)y * pitch + x;
+#pragma unroll
+        for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
+    }
+}
+
+// ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
+
+int num_levels(int w, int h, double pyr_scale, int levels) {
+    const int min_size = 32;
+    int k;
+    double scale = 1;
+    for (k = 0; k < levels; k++) {
+        scale *= pyr_scale;
+        if (w * scale < min_size || h * scale < min_size) break;
+    }
+    return k;
+}
+
+void level_geom(int w, int h, double pyr_scale, int k, int &lw, int &lh, double &sigma, int &ksize) {
+    double scale = 1;
+    for (int i = 0; i < k; i++) scale *= pyr_scale;
+    sigma = (1. / scale - 1) * 0.5;
+    ksize = ofxcv_cv_round(sigma * 5) | 1;
+    if (ksize < 3) ksize = 3;
+    lw = ofxcv_cv_round(w * scale);
+    lh = ofxcv_cv_round(h * scale);
+}
+
+inline int plane_pitch(int w) { return (w + 63) & ~63; }
+
+int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t step, int W, int H, int lw, int lh,
+                     double sigma, int ksize, float *d_T1, float *d_I) {
+    if (ksize > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksize, kMaxGaussTaps);
+    GaussTaps gk;
+    make_gauss_taps(ksize, sigma, gk);
+    int ntap = (lw == W && lh == H) ? 1 : 2;
+    int ncol = lw * ntap;
+    hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, d_img, step, W, H, lw, ntap, gk, d_T1);
+    OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
+    hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_T1, W, H,
+                       lw, lh, ntap, gk, d_I);
+    OFXCV_LAUNCH_CHECK(ctx, "pyr_vblur_resize_kernel");
+    return OFXCV_OK;
+}
+
+int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h, float *d_R, int poly_n, double poly_sigma) {
+    if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
+    PolyCoef pc;
+    make_poly_coef(poly_n, poly_sigma, pc);
+    int cw = kPeTW + 2 * poly_n, ldw = cw | 1, ih = kPeTH + 2 * poly_n;
+    size_t lds = sizeof(float) * ((size_t)ih * ldw + 3 * kPeTH * ldw);
+    hipLaunchKernelGGL(polyexp_kernel, dim3(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH)), dim3(256), lds, s, d_I, w, h, d_R,
+                       plane_pitch(w), pc);
+    OFXCV_LAUNCH_CHECK(ctx, "polyexp_kernel");
+    return OFXCV_OK;
+}
+
+int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
+                     size_t flow_step, int w, int h, int winsize, bool update) {
+    int m = winsize / 2;
+    double scale = 1. / (winsize * winsize);
+    dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+    if (update)
+        hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
+    else
+        hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
+    OFXCV_LAUNCH_CHECK(ctx, "blur_solve_update_kernel");
+    return OFXCV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
+
+int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels) {
+    return num_levels(width, height, pyr_scale, levels);
+}
+
+int ofxcv_farneback_level_geom(int width, int height, double pyr_scale, int k, int *lw, int *lh, double *sigma, int *ksize) {
+    if (!lw || !lh || !sigma || !ksize || width <= 0 || height <= 0 || k < 0) return OFXCV_ERR_INVALID;
+    level_geom(width, height, pyr_scale, k, *lw, *lh, *sigma, *ksize);
+    return OFXCV_OK;
+}
+
+int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step, int width, int height, int lw, int lh,
+                              double sigma, int ksize, float *d_I, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_img || !d_I || width <= 0 || height <= 0 || lw <= 0 || lh <= 0 || ksize < 1 || !(ksize & 1) || step < (size_t)width)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_pyr_image: bad argument");
+    int rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(2 * lw + 2) * height));
+    if (rc) return rc;
+    return launch_pyr_image(ctx, ofxcv_stream(ctx, stream), d_img, step, width, height, lw, lh, sigma, ksize, (float *)ctx->fb_tmp.ptr, d_I);
+}
+
+int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n, double poly_sigma,
+                            void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_I || !d_R || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_polyexp: bad argument");
+    return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma);
+}
+
+int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow, size_t flow_step,
+                                    int width, int height, float *d_M, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_R0 || !d_R1 || !d_flow || !d_M || width <= 0 || height <= 0 || (flow_step & 7))
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
+    hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
+                       ofxcv_stream(ctx, stream), d_R0, d_R1, d_flow, flow_step, 0, 0, 1.0, width, height, plane_pitch(width), d_M);
+    OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
+    return OFXCV_OK;
+}
+
+int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_M_in, float *d_M_out,
+                                     float *d_flow, size_t flow_step, int width, int height, int winsize, int update, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_M_in || width <= 0 || height <= 0 || winsize < 1 || !(winsize & 1) || (d_flow && (flow_step & 7)) ||
+        (update && (!d_R0 || !d_R1 || !d_M_out || d_M_out == d_M_in)) || (!update && !d_flow))
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_flow_blur: bad argument");
+    return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, d_flow, flow_step, width, height, winsize, update != 0);
+}
+
+int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step, const uint8_t *d_next,
+                                      size_t next_step, float *d_flow, size_t flow_step, int width, int height, double pyr_scale,
+                                      int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_prev || !d_next || !d_flow || width <= 0 || height <= 0 || prev_step < (size_t)width || next_step < (size_t)width ||
+        flow_step < (size_t)width * 8 || (flow_step & 7) || (((uintptr_t)d_flow) & 7))
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument");
+    if (flags != 0) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: only flags == 0 (box window, no initial flow)");
+    if (!(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || iterations < 1 || winsize < 1 || !(winsize & 1))
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad parameter");
+    hipStream_t s = ofxcv_stream(ctx, stream);
+    const uint8_t *img[2] = {d_prev, d_next};
+    const size_t step[2] = {prev_step, next_step};
+    levels = num_levels(width, height, pyr_scale, levels);
+
+    const size_t field = 5 * (size_t)plane_pitch(width) * height;  // floats per 5-plane field at level 0
+    int rc = ofxcv_reserve(ctx, ctx->fb_planes, sizeof(float) * 4 * field);
+    if (rc) return rc;
+    rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(width + 4) * height + (size_t)width * height));
+    if (rc) return rc;
+    size_t coarse = 0;
+    if (levels > 0) {
+        int lw, lh, ks;
+        double sg;
+        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
+        coarse = (size_t)lw * lh * 2;
+        rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 2 * coarse);
+        if (rc) return rc;
+    }
+    float *R[2] = {(float *)ctx->fb_planes.ptr, (float *)ctx->fb_planes.ptr + field};
+    float *Mbuf[2] = {(float *)ctx->fb_planes.ptr + 2 * field, (float *)ctx->fb_planes.ptr + 3 * field};
+    float *T1 = (float *)ctx->fb_tmp.ptr;
+    float *I = T1 + (size_t)(width + 4) * height;
+    float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + coarse};
+
+    const float *prev_flow = nullptr;
+    size_t prev_flow_step = 0;
+    int pw = 0, ph = 0;
+    for (int k = levels; k >= 0; k--) {
+        int w, h, ksz;
+        double sigma;
+        level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+        for (int i = 0; i < 2; i++) {
+            rc = launch_pyr_image(ctx, s, img[i], step[i], width, height, w, h, sigma, ksz, T1, I);
+            if (rc) return rc;
+            rc = launch_polyexp(ctx, s, I, w, h, R[i], poly_n, poly_sigma);
+            if (rc) return rc;
+        }
+        const int pitch = plane_pitch(w);
+        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+        if (!prev_flow)
+            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[0], R[1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, w, h, pitch, Mbuf[0]);
+        else
+            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[0], R[1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, w, h, pitch, Mbuf[0]);
+        OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
+        float *out_flow = k == 0 ? d_flow : cflow[k & 1];
+        size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
+        int cur = 0;
+        for (int i = 0; i < iterations; i++) {
+            bool update = i < iterations - 1;
+            rc = launch_iteration(ctx, s, R[0], R[1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+        prev_flow = out_flow;
+        prev_flow_step = out_step;
+        pw = w;
+        ph = h;
+    }
+    return OFXCV_OK;
+}
+
+}  // extern "C"

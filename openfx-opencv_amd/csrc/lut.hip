@@ -1,0 +1,152 @@
+// lut.hip -- F0 (f32 linear RGB(A) -> 8-bit sRGB luma) and F7 (flow -> RGBA write-back).
+//
+// F0 replaces OFX::Color::Lut::to_byte_grayscale_nodither (openfx-supportext ofxsLut.h) as called
+// from GenericOpenCVPlugin::fetchCVImage8UGrayscale (OpenCV/GenericOpenCVPlugin.cpp:223-265).
+// The LUT is the supportext one: 65536 entries indexed by the high half of the float bit
+// pattern, each holding the sRGB-encoded value in 8.8 fixed point; byte = (v + 0x80) >> 8.
+// It is built once on the host (powf) and lives in HBM (128 KiB, L2-resident).
+//
+// F7 replaces the write-back loop of VectorGenerator/VectorGenerator.cpp:494-519.
+// Both kernels are pure streaming: one coalesced 16-byte load or store per lane.
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+// Rec.709 luma weights of the supportext grayscale conversion.
+constexpr float kLumaR = 0.2126f, kLumaG = 0.7152f, kLumaB = 0.0722f;
+
+float srgb_encode(float v) {
+    if (v < 0.0031308f) return (v < 0.0f) ? 0.0f : v * 12.92f;
+    return 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+}
+float srgb_decode(float v) {
+    if (v < 0.04045f) return (v < 0.0f) ? 0.0f : v * (1.0f / 12.92f);
+    return std::pow((v + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
+uint16_t high_half(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return (uint16_t)(u >> 16);
+}
+float bucket_midpoint(uint16_t i) {
+    if (i < 0x80 || (i >= 0x8000 && i < 0x8080)) return 0.f;  // zeros, denormals
+    if (i >= 0x7f80 && i < 0x8000) return FLT_MAX;            // +inf / NaN
+    if (i >= 0xff80) return -FLT_MAX;                         // -inf / NaN
+    uint32_t u = ((uint32_t)i << 16) | 0x8000u;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+int to_fixed_8_8(float v) {
+    if (v <= 0) return 0;
+    if (v >= 1.) return 0xff00;
+    return (int)(v * 0xff00 + 0.5);
+}
+
+int ensure_lut(ofxcv_ctx *ctx, hipStream_t s) {
+    if (ctx->d_srgb_lut) return OFXCV_OK;
+    std::vector<uint16_t> lut(0x10000);
+    for (int i = 0; i < 0x10000; ++i) lut[i] = (uint16_t)to_fixed_8_8(srgb_encode(bucket_midpoint((uint16_t)i)));
+    for (int b = 0; b < 256; ++b) lut[high_half(srgb_decode(b / 255.0f))] = (uint16_t)(b << 8);
+    OFXCV_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_srgb_lut, lut.size() * sizeof(uint16_t)));
+    OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_srgb_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `lut` is pageable and dies with this scope
+    return OFXCV_OK;
+}
+
+__device__ __forceinline__ uint8_t lut_byte(const uint16_t *__restrict__ lut, float r, float g, float b) {
+    float l = kLumaR * r + kLumaG * g + kLumaB * b;
+    return (uint8_t)((lut[__float_as_uint(l) >> 16] + 0x80) >> 8);
+}
+
+// 4 pixels per lane: RGBA rows are read as float4 per pixel, the 4 gray bytes leave as one dword.
+template <int NCOMP>
+__global__ __launch_bounds__(256) void gray_lut_kernel(const float *__restrict__ src, ptrdiff_t src_row_bytes,
+                                                       int width, int height, uint8_t *__restrict__ dst,
+                                                       ptrdiff_t dst_row_bytes, const uint16_t *__restrict__ lut) {
+    int y = blockIdx.y;
+    int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x0 >= width) return;
+    const float *s = (const float *)((const char *)src + (ptrdiff_t)y * src_row_bytes) + (size_t)x0 * NCOMP;
+    uint8_t *d = dst + (ptrdiff_t)y * dst_row_bytes + x0;
+    uint8_t out[4];
+    int n = min(4, width - x0);
+    for (int i = 0; i < n; i++) {
+        if (NCOMP == 4 && (((uintptr_t)s) & 15) == 0) {
+            float4 p = *(const float4 *)(s + i * 4);
+            out[i] = lut_byte(lut, p.x, p.y, p.z);
+        } else {
+            out[i] = lut_byte(lut, s[i * NCOMP], s[i * NCOMP + 1], s[i * NCOMP + 2]);
+        }
+    }
+    if (n == 4 && (((uintptr_t)d) & 3) == 0) {
+        *(uint32_t *)d = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+    } else {
+        for (int i = 0; i < n; i++) d[i] = out[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void flow_to_rgba_kernel(const float *__restrict__ flow, size_t flow_step, int width,
+                                                           int height, float *__restrict__ dst, ptrdiff_t dst_row_bytes,
+                                                           unsigned mu, unsigned mv, double rsx, double rsy) {
+    int y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    const float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
+    float u = (float)(f.x / rsx), v = (float)(f.y / rsy);
+    float *d = (float *)((char *)dst + (ptrdiff_t)y * dst_row_bytes) + (size_t)x * 4;
+    if (((mu | mv) & 15u) == 15u && (((uintptr_t)d) & 15) == 0) {
+        float4 o;
+        o.x = (mv & 1u) ? v : u;
+        o.y = (mv & 2u) ? v : u;
+        o.z = (mv & 4u) ? v : u;
+        o.w = (mv & 8u) ? v : u;
+        *(float4 *)d = o;
+    } else {
+        for (int c = 0; c < 4; c++) {
+            if (mv & (1u << c)) d[c] = v;  // coord 1 is written after coord 0 in the reference loop
+            else if (mu & (1u << c)) d[c] = u;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_row_bytes, int ncomp, int width,
+                            int height, uint8_t *d_dst, ptrdiff_t dst_row_bytes, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_src || !d_dst || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "to_byte_grayscale: bad argument");
+    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "to_byte_grayscale: RGB or RGBA only");
+    hipStream_t s = ofxcv_stream(ctx, stream);
+    int rc = ensure_lut(ctx, s);
+    if (rc) return rc;
+    dim3 block(256), grid(ofxcv_div_up(ofxcv_div_up(width, 4), 256), height);
+    if (ncomp == 4)
+        hipLaunchKernelGGL(gray_lut_kernel<4>, grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
+    else
+        hipLaunchKernelGGL(gray_lut_kernel<3>, grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
+    OFXCV_LAUNCH_CHECK(ctx, "gray_lut_kernel");
+    return OFXCV_OK;
+}
+
+int ofxcv_flow_to_rgba(ofxcv_ctx *ctx, const float *d_flow, size_t flow_step, int width, int height, float *d_dst,
+                       ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask, double render_scale_x,
+                       double render_scale_y, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_flow || !d_dst || width <= 0 || height <= 0 || (flow_step & 7) || render_scale_x == 0 || render_scale_y == 0)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "flow_to_rgba: bad argument");
+    hipStream_t s = ofxcv_stream(ctx, stream);
+    dim3 block(256), grid(ofxcv_div_up(width, 256), height);
+    hipLaunchKernelGGL(flow_to_rgba_kernel, grid, block, 0, s, d_flow, flow_step, width, height, d_dst, dst_row_bytes,
+                       chan_u_mask & 15u, chan_v_mask & 15u, render_scale_x, render_scale_y);
+    OFXCV_LAUNCH_CHECK(ctx, "flow_to_rgba_kernel");
+    return OFXCV_OK;
+}
+
+}  // extern "C"

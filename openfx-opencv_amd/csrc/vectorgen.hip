@@ -1,0 +1,110 @@
+// vectorgen.hip -- VectorGeneratorPlugin::calcOpticalFlow (VectorGenerator/VectorGenerator.cpp:353-520,
+// Farneback branch) for host-resident OFX images.
+//
+// The reference marshals each OFX image into a cv::Mat through CVImageWrapper / OFX::ImageMemory
+// (OpenCV/GenericOpenCVPlugin.cpp:58-165, 223-265).  Here the two f32 frames are copied in row
+// blocks into a pinned ring and sent to HBM with hipMemcpyAsync on the context's copy stream; the
+// compute stream waits on a per-frame event, so the sRGB-gray kernel of frame 0 runs while frame
+// 1 is still on the wire.  Only the flow (8 B/px) comes back; the mapped RGBA channels of the
+// host-owned destination are then filled from the pinned copy (unmapped channels stay untouched,
+// :507-516).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ flow, size_t n, double rsx, double rsy) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float2 f = flow[i];
+    f.x = (float)(f.x / rsx);
+    f.y = (float)(f.y / rsy);
+    flow[i] = f;
+}
+
+int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_pinned_bytes) return OFXCV_OK;
+    if (ctx->h_pinned) {
+        OFXCV_HIP_CHECK(ctx, hipHostFree(ctx->h_pinned));
+        ctx->h_pinned = nullptr;
+        ctx->h_pinned_bytes = 0;
+    }
+    OFXCV_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pinned, bytes, hipHostMallocDefault));
+    ctx->h_pinned_bytes = bytes;
+    return OFXCV_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_other,
+                                         ptrdiff_t other_row_bytes, int ncomp, int width, int height, float *h_dst,
+                                         ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask,
+                                         double render_scale_x, double render_scale_y, int levels, int iterations, int poly_n,
+                                         double poly_sigma) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!h_ref || !h_other || !h_dst || width <= 0 || height <= 0 || render_scale_x == 0 || render_scale_y == 0)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "vectorgen_flow_host: bad argument");
+    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "vectorgen_flow_host: RGB or RGBA sources only");
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+
+    const size_t row = (size_t)width * ncomp * sizeof(float);
+    const size_t frame = align_up(row * height, 256);
+    const size_t gray_pitch = align_up((size_t)width, 256);
+    const size_t gray = gray_pitch * height;
+    const size_t flow_bytes = align_up((size_t)width * height * 8, 256);
+    int rc = reserve_pinned(ctx, 2 * frame + flow_bytes);
+    if (rc) return rc;
+    rc = ofxcv_reserve(ctx, ctx->d_stage, 2 * frame + 2 * gray + flow_bytes);
+    if (rc) return rc;
+    char *hp = (char *)ctx->h_pinned;
+    char *dp = (char *)ctx->d_stage.ptr;
+    char *d_frame[2] = {dp, dp + frame};
+    uint8_t *d_gray[2] = {(uint8_t *)(dp + 2 * frame), (uint8_t *)(dp + 2 * frame + gray)};
+    float *d_flow = (float *)(dp + 2 * frame + 2 * gray);
+    char *h_frame[2] = {hp, hp + frame};
+    float *h_flow = (float *)(hp + 2 * frame);
+
+    const float *src[2] = {h_ref, h_other};
+    const ptrdiff_t src_rb[2] = {ref_row_bytes, other_row_bytes};
+    const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ~4 MiB per DMA
+    for (int f = 0; f < 2; f++) {
+        for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+            int y1 = std::min(height, y0 + rows_per_chunk);
+            for (int y = y0; y < y1; y++) std::memcpy(h_frame[f] + (size_t)y * row, (const char *)src[f] + (ptrdiff_t)y * src_rb[f], row);
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f] + (size_t)y0 * row, h_frame[f] + (size_t)y0 * row, (size_t)(y1 - y0) * row,
+                                                hipMemcpyHostToDevice, ctx->copy));
+        }
+        OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
+        OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
+        rc = ofxcv_to_byte_grayscale(ctx, (const float *)d_frame[f], (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
+        if (rc) return rc;
+    }
+    // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+    rc = ofxcv_calc_optical_flow_farneback(ctx, d_gray[0], gray_pitch, d_gray[1], gray_pitch, d_flow, (size_t)width * 8, width, height, 0.5,
+                                           levels, 3, iterations, poly_n, poly_sigma, 0, ctx->compute);
+    if (rc) return rc;
+    if (render_scale_x != 1.0 || render_scale_y != 1.0) {
+        size_t n = (size_t)width * height;
+        hipLaunchKernelGGL(scale_flow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (float2 *)d_flow, n,
+                           render_scale_x, render_scale_y);
+        OFXCV_LAUNCH_CHECK(ctx, "scale_flow_kernel");
+    }
+    OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow, d_flow, (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+
+    const unsigned mu = chan_u_mask & 15u, mv = chan_v_mask & 15u;
+    for (int y = 0; y < height; y++) {
+        float *d = (float *)((char *)h_dst + (ptrdiff_t)y * dst_row_bytes);
+        const float *s = h_flow + (size_t)y * width * 2;
+        for (int x = 0; x < width; x++) {
+            for (int c = 0; c < 4; c++) {
+                if (mv & (1u << c)) d[x * 4 + c] = s[x * 2 + 1];
+                else if (mu & (1u << c)) d[x * 4 + c] = s[x * 2];
+            }
+        }
+    }
+    return OFXCV_OK;
+}

@@ -1,0 +1,173 @@
+"""Parity of the HIP Farneback path (through the C ABI) against the CPU oracle.
+
+Two comparisons per case:
+  * vs the oracle's DIRECT box-window evaluation (same IEEE operation order as the kernels):
+    every stage must agree to the last bit;
+  * vs the oracle's FAITHFUL restatement of OpenCV's running sums: |a-b| <= 1e-4*max(1,|b|)
+    (the north_star tolerance).  OpenCV rounds each vertical row difference to f32 before adding it
+    to its f64 running sum; that rounding noise is the reference's own, is not reproduced on the
+    GPU, and at a few ill-conditioned pixels is amplified past 1e-4 -- the oracle's own two
+    evaluations differ there by the same amount (tests/test_oracle_farneback.py measures it).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4           # north_star: 1e-4 relative float tolerance
+OUTLIER_FRAC = 2e-3      # samples allowed outside REL_TOL vs the FAITHFUL oracle (reference's own f32 noise)
+
+
+def _gray_pair(oracle, w, h, seed=1234):
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(w, h, seed)
+    return oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (100, 75), (333, 257)])
+def test_pyr_image_bit_exact(oracle, ofxcv, gpu_ctx, w, h):
+    ga, _ = _gray_pair(oracle, w, h)
+    levels = ofxcv.farneback_num_levels(w, h, 0.5, 5)
+    for k in range(levels + 1):
+        lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
+        assert (lw, lh, sigma, ks) == oracle.farneback_level_geom(w, h, 0.5, k)
+        ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
+        got = gpu_ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+        assert np.array_equal(ref, got), "level %d max diff %g" % (k, np.abs(ref - got).max())
+
+
+@pytest.mark.parametrize("w,h,n,sigma", [(64, 48, 5, 1.1), (160, 120, 5, 1.1), (97, 61, 7, 1.5), (33, 40, 5, 1.1)])
+def test_polyexp_bit_exact(oracle, ofxcv, gpu_ctx, w, h, n, sigma):
+    rng = np.random.default_rng(7)
+    I = (rng.uniform(0, 255, size=(h, w))).astype(np.float32)
+    ref = oracle.polyexp(I, n, sigma)
+    got = ofxcv.planes_to_hwc(gpu_ctx.farneback_polyexp(_dev(I), n, sigma), w).cpu().numpy()
+    assert np.array_equal(ref, got), "max diff %g" % np.abs(ref - got).max()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (161, 119), (12, 12)])
+def test_update_matrices_bit_exact(oracle, ofxcv, gpu_ctx, w, h):
+    rng = np.random.default_rng(11)
+    R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    flow = rng.normal(0, 3, size=(h, w, 2)).astype(np.float32)
+    flow[0, 0] = (-5.0, -5.0)          # sample falls outside: the else branch
+    flow[h - 1, w - 1] = (4.0, 4.0)
+    ref = oracle.update_matrices(R0, R1, flow)
+    got = gpu_ctx.farneback_update_matrices(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), _dev(flow))
+    got = ofxcv.planes_to_hwc(got, w).cpu().numpy()
+    assert np.array_equal(ref, got), "max diff %g" % np.abs(ref - got).max()
+
+
+@pytest.mark.parametrize("w,h,update", [(64, 48, True), (161, 119, True), (75, 33, False)])
+def test_update_flow_blur_matches_direct_oracle(oracle, ofxcv, gpu_ctx, w, h, update):
+    rng = np.random.default_rng(13)
+    R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    M = oracle.update_matrices(R0, R1, rng.normal(0, 1, size=(h, w, 2)).astype(np.float32))
+    ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 3, update, oracle.BLUR_DIRECT)
+    flow, Mo = gpu_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)),
+                                                  ofxcv.hwc_to_planes(_dev(M)), w, 3, update)
+    assert np.array_equal(ref_flow, flow.cpu().numpy())
+    if update:
+        assert np.array_equal(ref_M, ofxcv.planes_to_hwc(Mo, w).cpu().numpy())
+    # and the faithful (running-sum) evaluation of the same step agrees within tolerance
+    f_flow, _ = oracle.update_flow_blur(R0, R1, M, 3, update, oracle.BLUR_FAITHFUL)
+    err = np.abs(f_flow - flow.cpu().numpy())
+    assert (err <= REL_TOL * np.maximum(1, np.abs(f_flow))).all()
+
+
+def _check_flow(oracle, got, ga, gb, **kw):
+    direct = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT, **kw)
+    faithful = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, **kw)
+    assert np.isfinite(got).all()
+    # same evaluation order -> identical results
+    assert np.array_equal(direct, got), "vs direct oracle: max diff %g" % np.abs(direct - got).max()
+    err = np.abs(faithful - got)
+    bad = err > REL_TOL * np.maximum(1, np.abs(faithful))
+    assert bad.mean() <= OUTLIER_FRAC, "vs faithful oracle: %.3g of samples outside 1e-4 (max err %g)" % (bad.mean(), err.max())
+    return bad.mean(), err.max()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (333, 257), (640, 480)])
+def test_farneback_end_to_end(oracle, ofxcv, gpu_ctx, w, h):
+    ga, gb = _gray_pair(oracle, w, h)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    _check_flow(oracle, got, ga, gb)
+
+
+def test_farneback_other_parameters(oracle, ofxcv, gpu_ctx):
+    ga, gb = _gray_pair(oracle, 200, 150, seed=99)
+    kw = dict(levels=2, iterations=4, poly_n=7, poly_sigma=1.5)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
+    _check_flow(oracle, got, ga, gb, **kw)
+
+
+def test_farneback_identical_frames(oracle, ofxcv, gpu_ctx):
+    """prev == next: the flow is exactly zero except where UpdateMatrices' out-of-range branch fires (the last
+    row / column sample R1 at x1 == w-1 or y1 == h-1, optflowgf.cpp) and what the box window spreads from there."""
+    ga, _ = _gray_pair(oracle, 160, 120)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(ga)).cpu().numpy()
+    assert np.array_equal(got, oracle.calc_optical_flow_farneback(ga, ga, blur_mode=oracle.BLUR_DIRECT))
+    assert np.array_equal(got[:40, :40], np.zeros((40, 40, 2), np.float32))
+
+
+def test_farneback_padded_strides(oracle, ofxcv, gpu_ctx):
+    import torch
+    w, h = 150, 100
+    ga, gb = _gray_pair(oracle, w, h)
+    pa = torch.zeros((h, 256), dtype=torch.uint8, device="cuda")
+    pb = torch.zeros((h, 192), dtype=torch.uint8, device="cuda")
+    pa[:, :w] = _dev(ga)
+    pb[:, :w] = _dev(gb)
+    fl = torch.full((h, w + 10, 2), 7.0, dtype=torch.float32, device="cuda")
+    gpu_ctx.calc_optical_flow_farneback(pa[:, :w], pb[:, :w], fl[:, :w])
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT)
+    assert np.array_equal(ref, fl[:, :w].cpu().numpy())
+    assert (fl[:, w:] == 7.0).all()
+
+
+def test_farneback_1080p_properties(oracle, ofxcv, gpu_ctx):
+    """BASELINE config 3 size: full comparison against the oracle (about 5 s of CPU) + size-independent checks."""
+    import torch
+    from openfx_opencv_amd import synth
+    w, h = 1920, 1080
+    a, b = synth.flow_pair(w, h)
+    ga = gpu_ctx.to_byte_grayscale(_dev(a))
+    gb = gpu_ctx.to_byte_grayscale(_dev(b))
+    assert np.array_equal(ga.cpu().numpy(), oracle.to_byte_grayscale(a))
+    flow = gpu_ctx.calc_optical_flow_farneback(ga, gb)
+    again = gpu_ctx.calc_optical_flow_farneback(ga, gb)
+    assert torch.equal(flow, again)                      # deterministic, scratch reuse is clean
+    got = flow.cpu().numpy()
+    frac, mx = _check_flow(oracle, got, ga.cpu().numpy(), gb.cpu().numpy())
+    u, v = synth.known_flow(w, h)
+    inner = (slice(40, -40), slice(40, -40))
+    assert np.abs(got[..., 0] - u)[inner].mean() < 0.3 and np.abs(got[..., 1] - v)[inner].mean() < 0.3
+    zero = gpu_ctx.calc_optical_flow_farneback(ga, ga)
+    assert float(zero[:500, :900].abs().max()) == 0.0   # identical frames: zero far from the bottom/right border
+
+
+def test_gray_lut_and_scatter(oracle, ofxcv, gpu_ctx):
+    import torch
+    rng = np.random.default_rng(5)
+    img = rng.uniform(-0.2, 1.3, size=(37, 53, 4)).astype(np.float32)
+    img[0, 0] = (np.nan, 0, 0, 1)
+    img[0, 1] = (np.inf, 1, 1, 1)
+    img[0, 2] = (0, 0, 0, 1)
+    assert np.array_equal(gpu_ctx.to_byte_grayscale(_dev(img)).cpu().numpy(), oracle.to_byte_grayscale(img))
+    rgb = np.ascontiguousarray(img[..., :3])
+    rgb[0, 0] = 0.5
+    rgb[0, 1] = 0.25
+    assert np.array_equal(gpu_ctx.to_byte_grayscale(_dev(rgb)).cpu().numpy(), oracle.to_byte_grayscale(rgb))
+    flow = rng.normal(0, 3, size=(37, 53, 2)).astype(np.float32)
+    for mu, mv, rs in [(0b0011, 0b1100, (1.0, 1.0)), (0b0001, 0b0010, (0.5, 0.25)), (0b0101, 0b0100, (1.0, 2.0)), (0, 0, (1.0, 1.0))]:
+        base = rng.normal(size=(37, 53, 4)).astype(np.float32)
+        ref = oracle.flow_to_rgba(flow, base.copy(), [(mu >> c) & 1 for c in range(4)], [(mv >> c) & 1 for c in range(4)], *rs)
+        got = gpu_ctx.flow_to_rgba(_dev(flow), _dev(base), mu, mv, *rs).cpu().numpy()
+        assert np.array_equal(ref, got)
