@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- Farneback dense optical flow throughput at 1920x1080 (BASELINE.json metric).
+
+One step = one pass of the VectorGenerator hot path over one synthetic f32 RGBA frame pair that is
+already resident in HBM: sRGB-gray LUT x2 (F0) -> calcOpticalFlowFarneback (F1-F6) -> flow->RGBA
+write-back (F7), all through the C ABI of libofxcv_hip.so.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank runs its own independent pairs -- the path has no
+exchange step, so there is no data-path collective; only the timing barrier / max-reduce.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the fused blur+solve+update
+iteration at pyramid level 0, timed live with HIP events on its own stream) and `cpu_baseline`
+(the CPU oracle -- a port of the reference's OpenCV algorithm -- timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H = 1920, 1080
+LEVELS, ITERS, POLY_N, POLY_SIGMA, WINSIZE, PYR_SCALE = 3, 15, 5, 1.1, 3, 0.5  # VectorGenerator.cpp:804-834, :391-395
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
+# fused iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
+ITER_BYTES_PER_PX = 80.0
+
+
+def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
+    """per level 1282*n + 2*N0 bytes (coarsest level 1272*n + 2*N0), u8 source."""
+    n0 = w * h
+    total = 0.0
+    for k in range(levels + 1):
+        n = round(w * 0.5 ** k) * round(h * 0.5 ** k)
+        per = 2 * n0 + 2 * 4 * n + 48 * n + (10 * n if k < levels else 0) + 68 * n + (iters - 1) * 80 * n + 28 * n
+        total += per
+    return total
+
+
+def cpu_baseline(ga, gb, budget_s=12.0):
+    """Time the CPU oracle (kind 'port': restatement of OpenCV's single-threaded CPU Farneback) on rank 0."""
+    from oracle import binding as oracle
+    oracle.lib()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        oracle.calc_optical_flow_farneback(ga, gb, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0, oracle.BLUR_FAITHFUL)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 8:
+            break
+    return {"value": n / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d Farneback frame pairs at %dx%d (same synthetic frames, levels=3 iterations=15 poly_n=5), "
+                      "oracle/farneback.c single thread, %.1f s" % (n, W, H, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import openfx_opencv_amd as ofxcv
+    from openfx_opencv_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    ctx = ofxcv.Context(local_rank)
+    a, b = synth.flow_pair(W, H, seed=1234 + rank)
+    with torch.cuda.stream(ctx.stream):
+        d_a = torch.from_numpy(a).cuda()
+        d_b = torch.from_numpy(b).cuda()
+        g_a = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        g_b = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        flow = torch.empty((H, W, 2), dtype=torch.float32, device="cuda")
+        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+
+        def step():
+            ctx.to_byte_grayscale(d_a, g_a)
+            ctx.to_byte_grayscale(d_b, g_b)
+            ctx.calc_optical_flow_farneback(g_a, g_b, flow, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+            ctx.flow_to_rgba(flow, out, 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+
+        # roofline leg: same process, same inputs -- event pairs around every level-0 iteration launch
+        ctx.profile_enable(True)
+        nprof = max(3, min(10, args.steps))
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        kern_ms, kern_n = ctx.profile_read()
+        ctx.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = args.steps * world
+        value = pairs / elapsed
+        avg_s = kern_ms / 1e3 / max(1, kern_n)
+        achieved = ITER_BYTES_PER_PX * W * H / avg_s / 1e9
+        alg = algorithmic_bytes_per_pair(W, H)
+        line = {
+            "metric": "frames/sec at 1920x1080 f32 (Farneback flow)",
+            "value": value,
+            "unit": "frame-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "VectorGenerator Farneback dense optical flow, 1920x1080 f32 RGBA frame pair resident in HBM "
+                                   "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[2])",
+                       "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
+                       "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": 1, "parallelism": "independent frame pairs per GPU, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "blur_solve_update_kernel<true> (level 0, %dx%d)" % (W, H),
+                         "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n},
+            "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
+                           "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            ga = g_a.cpu().numpy()
+            gb = g_b.cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(ga, gb)
+        elif world > 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

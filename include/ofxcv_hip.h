@@ -45,6 +45,14 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
 /* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL) */
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 
+/* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
+ * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of its dominant kernel --
+ * the fused blur+solve+update iteration at pyramid level 0 -- with a hipEvent pair on the stream it
+ * is launched on.  ofxcv_profile_read synchronises, adds up the pairs and returns the total
+ * kernel time and the number of launches since the last reset. */
+int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
+int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);
+
 /* ---- F0: f32 linear RGB(A) -> 8-bit sRGB luma ---------------------------------------------
  * replaces OFX::Color::Lut::to_byte_grayscale_nodither as called by
  * GenericOpenCVPlugin::fetchCVImage8UGrayscale (OpenCV/GenericOpenCVPlugin.cpp:223-265, :261). */

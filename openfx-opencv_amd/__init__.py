@@ -53,7 +53,7 @@ def lib():
 # every symbol include/ofxcv_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -115,6 +115,15 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ofxcv_ctx_synchronize(self._h, None))
+
+    def profile_enable(self, on=True):
+        self._check(lib().ofxcv_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile_read(self, reset=True):
+        """(total_ms, launches) of the dominant kernel (level-0 fused iteration) since the last reset."""
+        ms, n = C.c_double(), C.c_long()
+        self._check(lib().ofxcv_profile_read(self._h, C.byref(ms), C.byref(n), C.c_int(1 if reset else 0)))
+        return ms.value, n.value
 
     def _call(self, fn, *args):
         """fn(ctx, *args, stream=NULL) on the context's compute stream, ordered against torch's current stream."""
@@ -199,12 +208,14 @@ class Context:
                    C.c_int(h), _ptr(M))
         return M
 
-    def farneback_update_flow_blur(self, R0, R1, M, w, winsize=3, update=True):
+    def farneback_update_flow_blur(self, R0, R1, M, w, winsize=3, update=True, flow=None, Mo=None):
         """returns (flow HxWx2, M_out planes or None)"""
         import torch
         h = M.shape[1]
-        flow = torch.empty((h, w, 2), dtype=torch.float32, device=M.device)
-        Mo = torch.zeros_like(M) if update else None
+        if flow is None:
+            flow = torch.empty((h, w, 2), dtype=torch.float32, device=M.device)
+        if update and Mo is None:
+            Mo = torch.zeros_like(M)
         self._call(lib().ofxcv_farneback_update_flow_blur, _ptr(R0), _ptr(R1), _ptr(M), _ptr(Mo) if update else None, _ptr(flow),
                    C.c_size_t(w * 8), C.c_int(w), C.c_int(h), C.c_int(winsize), C.c_int(1 if update else 0))
         return flow, Mo

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "ofxcv_hip.h"
 
@@ -33,6 +34,12 @@ struct ofxcv_ctx {
     DevBuf fb_tmp;     // blurred half-resolution rows (pyramid) + pyramid image I
     DevBuf fb_flow;    // two ping-pong coarse flow fields
     DevBuf fb_coef;    // polyexp / blur coefficient tables
+
+    // measurement hook: event pairs around the dominant kernel (see ofxcv_profile_enable)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;  // start/stop pairs, recorded but not yet read
+    double prof_ms = 0;
+    long prof_launches = 0;
 
     // host-path staging
     DevBuf d_stage;            // device side: 2 f32 frames, 2 gray frames, flow, rgba
@@ -63,6 +70,10 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
 }
 
 static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// measurement hook helpers (context.hip)
+int ofxcv_prof_mark(ofxcv_ctx *ctx, hipStream_t s);  // records one event of a start/stop pair
+int ofxcv_prof_drain(ofxcv_ctx *ctx);
 
 // host-side cvRound (round half to even) / cvFloor, shared by geometry helpers
 int ofxcv_cv_round(double v);

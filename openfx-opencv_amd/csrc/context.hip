@@ -27,6 +27,27 @@ int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     return OFXCV_OK;
 }
 
+int ofxcv_prof_mark(ofxcv_ctx *ctx, hipStream_t s) {
+    hipEvent_t e;
+    OFXCV_HIP_CHECK(ctx, hipEventCreate(&e));
+    ctx->prof_ev.push_back(e);
+    OFXCV_HIP_CHECK(ctx, hipEventRecord(e, s));
+    return OFXCV_OK;
+}
+
+int ofxcv_prof_drain(ofxcv_ctx *ctx) {
+    for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
+        float ms = 0;
+        OFXCV_HIP_CHECK(ctx, hipEventSynchronize(ctx->prof_ev[i + 1]));
+        OFXCV_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        ctx->prof_ms += ms;
+        ctx->prof_launches++;
+    }
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    ctx->prof_ev.clear();
+    return OFXCV_OK;
+}
+
 int ofxcv_cv_round(double v) { return (int)std::lrint(v); }
 
 extern "C" {
@@ -80,6 +101,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->d_stage};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -98,6 +120,25 @@ const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "nu
 int ofxcv_ctx_device(const ofxcv_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute : nullptr; }
+
+int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    ctx->prof_on = enable != 0;
+    return OFXCV_OK;
+}
+
+int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset) {
+    if (!ctx || !total_ms || !launches) return OFXCV_ERR_INVALID;
+    int rc = ofxcv_prof_drain(ctx);
+    if (rc) return rc;
+    *total_ms = ctx->prof_ms;
+    *launches = ctx->prof_launches;
+    if (reset) {
+        ctx->prof_ms = 0;
+        ctx->prof_launches = 0;
+    }
+    return OFXCV_OK;
+}
 
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;

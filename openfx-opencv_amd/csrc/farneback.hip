@@ -304,46 +304,89 @@ struct M5 {
     float v[5];
 };
 
-__device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1, int x, int y,
-                                                 int w, int h, int pitch, float dx, float dy) {
-    const size_t plane = (size_t)pitch * h;
-    const size_t o = (size_t)y * pitch + x;
+// Buffer addressing: the 128-bit descriptor and the row/plane part of every address are wave-uniform
+// (SGPRs: descriptor + soffset), the lane's column is a 32-bit voffset -- no 64-bit vector address math.
+// Out-of-range offsets are bounds-checked by the hardware (loads return 0, stores are dropped).
+struct Buf {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ Buf make_buf(const void *p, size_t bytes) {
+    Buf b;
+    b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ float buf_ld(const Buf &b, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_st(const Buf &b, float v, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, 0);
+}
+// two horizontally adjacent taps of one plane.  Measured on gfx950 (tools/ubench/l1rate.hip): a coalesced
+// dword wave-load costs ~5 clk of the CU's texture-addresser, a dwordx2 one ~18 clk, so the pair is
+// fetched as two dword loads (the second is an L1 hit on the line the first one brought in).
+struct TapPair {
+    float a, b;
+};
+
+// R1 taps of one pixel: the 2x2 bilinear footprint of all five planes.  Pixels whose sample falls
+// outside the image load a dummy in-range address instead of branching; `inb` selects afterwards.
+struct Taps {
+    TapPair t[5], b[5];
+    float fx, fy;
+    bool inb;
+};
+
+__device__ __forceinline__ Taps gather_taps(const float *__restrict__ R1, int x, int y, int w, int h, int pitch, size_t plane,
+                                            float dx, float dy) {
+    Taps tp;
     float fx = x + dx, fy = y + dy;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
-    float r2, r3, r4, r5, r6;
-    fx -= x1;
-    fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float *p = R1 + (size_t)y1 * pitch + x1;
-        r2 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
-        p += plane;
-        r3 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
-        p += plane;
-        r4 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
-        p += plane;
-        r5 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
-        p += plane;
-        r6 = a00 * p[0] + a01 * p[1] + a10 * p[pitch] + a11 * p[pitch + 1];
-        r4 = (R0[o + 2 * plane] + r4) * 0.5f;
-        r5 = (R0[o + 3 * plane] + r5) * 0.5f;
-        r6 = (R0[o + 4 * plane] + r6) * 0.25f;
-    } else {
-        r2 = r3 = 0.f;
-        r4 = R0[o + 2 * plane];
-        r5 = R0[o + 3 * plane];
-        r6 = R0[o + 4 * plane] * 0.5f;
+    tp.fx = fx - x1;
+    tp.fy = fy - y1;
+    tp.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const unsigned o0 = tp.inb ? ((unsigned)y1 * (unsigned)pitch + (unsigned)x1) * 4u : 0u, o1 = o0 + (unsigned)pitch * 4u;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const char *pl = (const char *)(R1 + c * plane);  // wave-uniform plane base + 32-bit lane byte offset
+        tp.t[c].a = *(const float *)(pl + o0);
+        tp.t[c].b = *(const float *)(pl + o0 + 4);
+        tp.b[c].a = *(const float *)(pl + o1);
+        tp.b[c].b = *(const float *)(pl + o1 + 4);
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[o + plane] - r3) * 0.5f;
+    return tp;
+}
+
+__device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const Taps &tp, int x, int y, int w, int h, float dx, float dy) {
+    const float fx = tp.fx, fy = tp.fy;
+    float r2, r3, r4, r5, r6;
+    {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const TapPair *t = tp.t, *b = tp.b;
+        r2 = a00 * t[0].a + a01 * t[0].b + a10 * b[0].a + a11 * b[0].b;
+        r3 = a00 * t[1].a + a01 * t[1].b + a10 * b[1].a + a11 * b[1].b;
+        r4 = a00 * t[2].a + a01 * t[2].b + a10 * b[2].a + a11 * b[2].b;
+        r5 = a00 * t[3].a + a01 * t[3].b + a10 * b[3].a + a11 * b[3].b;
+        r6 = a00 * t[4].a + a01 * t[4].b + a10 * b[4].a + a11 * b[4].b;
+        r4 = (r0v[2] + r4) * 0.5f;
+        r5 = (r0v[3] + r5) * 0.5f;
+        r6 = (r0v[4] + r6) * 0.25f;
+    }
+    if (!tp.inb) {
+        r2 = r3 = 0.f;
+        r4 = r0v[2];
+        r5 = r0v[3];
+        r6 = r0v[4] * 0.5f;
+    }
+    r2 = (r0v[0] - r2) * 0.5f;
+    r3 = (r0v[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
 
     constexpr int BORDER = 5;
     if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
-        const float border[BORDER] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
-        float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
-                      (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}
+        auto bs = [](int d) { return d < 2 ? 0.14f : (d < BORDER ? 0.4472f : 1.f); };
+        float scale = bs(x) * bs(w - x - 1) * bs(y) * bs(h - y - 1);
         r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
     }
     M5 m;
@@ -353,6 +396,22 @@ __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, c
     m.v[3] = r4 * r2 + r6 * r3;
     m.v[4] = r6 * r2 + r5 * r3;
     return m;
+}
+
+__device__ __forceinline__ M5 update_matrices_core(const float r0v[5], const float *__restrict__ R1, int x, int y, int w, int h,
+                                                   int pitch, size_t plane, float dx, float dy) {
+    Taps tp = gather_taps(R1, x, y, w, h, pitch, plane, dx, dy);
+    return update_matrices_finish(r0v, tp, x, y, w, h, dx, dy);
+}
+
+__device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1, int x, int y,
+                                                 int w, int h, int pitch, float dx, float dy) {
+    const size_t plane = (size_t)pitch * h;
+    const size_t o = (size_t)y * pitch + x;
+    float r0v[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) r0v[c] = R0[o + c * plane];
+    return update_matrices_core(r0v, R1, x, y, w, h, pitch, plane, dx, dy);
 }
 
 // F6 + first F4 of a level.  MODE 0: zero initial flow (coarsest level); MODE 1: flow prolongated from
@@ -439,6 +498,190 @@ __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__r
     }
 }
 
+// Specialisation for the 3x3 window the reference uses (winSize = 3, VectorGenerator.cpp:395).
+//
+// Row walker, PX pixels per lane: one wavefront owns 64*PX consecutive columns and walks down `rows`
+// image rows.  The texture-addresser cost of a vector-memory instruction is per instruction, not per
+// byte, so every streaming access is PX floats wide (dwordx4 for PX = 4): per row a lane issues one
+// load per plane of M and of R0 and one store per plane of M-out for its PX pixels.  The left / right
+// window neighbours of a lane's pixel group arrive by DPP wave shifts (the wavefront shuffle of the
+// 3-wide window reduction); only lanes 0 and 63 fetch the wave's halo column.  The f64 horizontal sums
+// of the new window row join the two previous row sums held in registers, so the vertical reuse of
+// the window costs no memory traffic and no LDS.  The next row's M and R0 values are requested before
+// the current row's 2x2 solves and R1 gathers, so a wave always has loads in flight.  Summation order
+// (per window row left to right, rows top to bottom) is that of the oracle's direct evaluation:
+// results are bit-identical to it.
+__device__ __forceinline__ float dpp_from_left(float v, float edge) {  // lane i <- lane i-1, lane 0 <- edge
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane i <- lane i+1, lane 63 <- edge
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <int PX>
+__device__ __forceinline__ void buf_ldv(const Buf &b, unsigned voff, unsigned soff, float out[PX]) {
+    if constexpr (PX == 1) {
+        out[0] = buf_ld(b, voff, soff);
+    } else if constexpr (PX == 2) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        u2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
+        out[0] = __builtin_bit_cast(float, v.x);
+        out[1] = __builtin_bit_cast(float, v.y);
+    } else {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0);
+        out[0] = __builtin_bit_cast(float, v.x);
+        out[1] = __builtin_bit_cast(float, v.y);
+        out[2] = __builtin_bit_cast(float, v.z);
+        out[3] = __builtin_bit_cast(float, v.w);
+    }
+}
+template <int PX>
+__device__ __forceinline__ void buf_stv(const Buf &b, const float in[PX], unsigned voff, unsigned soff) {
+    if constexpr (PX == 1) {
+        buf_st(b, in[0], voff, soff);
+    } else if constexpr (PX == 2) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        u2 v = {__builtin_bit_cast(unsigned, in[0]), __builtin_bit_cast(unsigned, in[1])};
+        __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
+    } else {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        u4 v = {__builtin_bit_cast(unsigned, in[0]), __builtin_bit_cast(unsigned, in[1]), __builtin_bit_cast(unsigned, in[2]),
+                __builtin_bit_cast(unsigned, in[3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
+    }
+}
+
+template <bool UPDATE, int PX>
+__global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                       const float *__restrict__ Min, float *__restrict__ Mout,
+                                                       float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
+                                                       int rows, double scale) {
+    const int lane = threadIdx.x & 63;
+    const int xw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * PX);  // first column of this wave
+    if (xw >= w) return;
+    const int x = xw + lane * PX;  // first column of this lane
+    const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, h);
+    const int nvalid = min(max(w - x, 0), PX);  // pixels of this lane inside the image
+    const bool last_in_row = x + PX >= w;       // holds pixel w-1 (or lies beyond it): right neighbour is replicated
+    // halo column of this wave: lane 0 fetches xw-1, lane 63 fetches xw+64*PX (clamped = replicated border)
+    const bool edge_lane = lane == 0 || lane == 63;
+    const unsigned ve = 4u * (unsigned)(lane == 0 ? max(xw - 1, 0) : min(xw + 64 * PX, w - 1));
+    const unsigned vc = 4u * (unsigned)x;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u;  // plane / row strides in bytes
+    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+
+    // one raw row of M: PX centre values per lane and plane + the halo value in the edge lanes
+    auto load_row = [&](int yy, float mc[5][PX], float me[5]) {
+        const unsigned so = (unsigned)yy * rb;  // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            buf_ldv<PX>(bM, vc, so + c * pb, mc[c]);
+            me[c] = 0.f;
+        }
+        if (edge_lane) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) me[c] = buf_ld(bM, ve, so + c * pb);
+        }
+    };
+    // f64 3-wide horizontal sums of one window row for the lane's PX pixels
+    auto hsum = [&](float mc[5][PX], const float me[5], double hs[PX][5]) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+#pragma unroll
+            for (int i = 1; i < PX; i++) mc[c][i] = i < nvalid ? mc[c][i] : mc[c][i - 1];  // replicate past column w-1
+            float L = dpp_from_left(mc[c][PX - 1], me[c]), R = dpp_from_right(mc[c][0], me[c]);
+            if (last_in_row) R = mc[c][PX - 1];
+            double e[PX + 2];
+            e[0] = (double)L;
+#pragma unroll
+            for (int i = 0; i < PX; i++) e[i + 1] = (double)mc[c][i];
+            e[PX + 1] = (double)R;
+#pragma unroll
+            for (int i = 0; i < PX; i++) hs[i][c] = (e[i] + e[i + 1]) + e[i + 2];
+        }
+    };
+
+    double hsA[PX][5], hsB[PX][5];
+    float mc[5][PX], me[5], r0n[5][PX];
+    load_row(max(y0 - 1, 0), mc, me);
+    hsum(mc, me, hsA);
+    load_row(y0, mc, me);
+    hsum(mc, me, hsB);
+    load_row(min(y0 + 1, h - 1), mc, me);
+    if (UPDATE) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) buf_ldv<PX>(bR0, vc, (unsigned)y0 * rb + c * pb, r0n[c]);
+    }
+    for (int y = y0; y < y1; y++) {
+        double hsC[PX][5];
+        float r0v[5][PX];
+        hsum(mc, me, hsC);
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+#pragma unroll
+            for (int i = 0; i < PX; i++) r0v[c][i] = r0n[c][i];
+        if (y + 1 < y1) {  // request the next row before the dependent solves + gathers of this one
+            load_row(min(y + 2, h - 1), mc, me);
+            if (UPDATE) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) buf_ldv<PX>(bR0, vc, (unsigned)(y + 1) * rb + c * pb, r0n[c]);
+            }
+        }
+        float fxv[PX], fyv[PX];
+#pragma unroll
+        for (int i = 0; i < PX; i++) {
+            double acc[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                acc[c] = (hsA[i][c] + hsB[i][c]) + hsC[i][c];
+                hsA[i][c] = hsB[i][c];
+                hsB[i][c] = hsC[i][c];
+            }
+            double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+            double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+            fxv[i] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+            fyv[i] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        }
+        if (flow) {
+            float2 *frow = (float2 *)((char *)flow + (size_t)y * flow_step) + x;
+#pragma unroll
+            for (int i = 0; i < PX; i++)
+                if (i < nvalid) frow[i] = make_float2(fxv[i], fyv[i]);
+        }
+        if (UPDATE) {
+            float mo[5][PX];
+            // all R1 taps of the lane's pixels are requested before any of them is consumed
+            Taps tp[PX];
+#pragma unroll
+            for (int i = 0; i < PX; i++) tp[i] = gather_taps(R1, min(x + i, w - 1), y, w, h, pitch, plane, fxv[i], fyv[i]);
+#pragma unroll
+            for (int i = 0; i < PX; i++) {
+                float r0p[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) r0p[c] = r0v[c][i];
+                M5 mm = update_matrices_finish(r0p, tp[i], min(x + i, w - 1), y, w, h, fxv[i], fyv[i]);
+#pragma unroll
+                for (int c = 0; c < 5; c++) mo[c][i] = mm.v[c];
+            }
+            const unsigned so = (unsigned)y * rb;
+            if (nvalid == PX) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) buf_stv<PX>(bMo, mo[c], vc, so + c * pb);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; i++)
+                    if (i < nvalid) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) buf_st(bMo, mo[c][i], vc + 4u * i, so + c * pb);
+                    }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -495,6 +738,24 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
                      size_t flow_step, int w, int h, int winsize, bool update) {
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
+    if (winsize == 3) {
+        // One pixel per lane: 2- and 4-pixel lanes (dwordx2/x4 streams) were measured slower on MI355X -- the
+        // kernel is bound by its per-row dependent chain, not by load width, and wide lanes cost occupancy.
+        // Rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels.
+        constexpr int px = 1;
+        const int cols = ofxcv_div_up(w, 64 * px);
+        int rows = 2;
+        while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 2048) rows >>= 1;
+        if (const char *e = getenv("OFXCV_ROWS")) rows = atoi(e);
+        dim3 grid(ofxcv_div_up(w, 256 * px), ofxcv_div_up(h, rows)), block(256);
+        const int pitch = plane_pitch(w);
+        if (update)
+            hipLaunchKernelGGL((iterate3_kernel<true, px>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, rows, scale);
+        else
+            hipLaunchKernelGGL((iterate3_kernel<false, px>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, rows, scale);
+        OFXCV_LAUNCH_CHECK(ctx, "iterate3_kernel");
+        return OFXCV_OK;
+    }
     dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
     if (update)
         hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
@@ -617,8 +878,11 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         int cur = 0;
         for (int i = 0; i < iterations; i++) {
             bool update = i < iterations - 1;
+            const bool prof = ctx->prof_on && k == 0 && update;
+            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             rc = launch_iteration(ctx, s, R[0], R[1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
             if (rc) return rc;
+            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             cur ^= 1;
         }
         prev_flow = out_flow;
