@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,45 +82,57 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    ctx = ofxcv.Context(local_rank)
-    a, b = synth.flow_pair(W, H, seed=1234 + rank)
-    with torch.cuda.stream(ctx.stream):
-        d_a = torch.from_numpy(a).cuda()
-        d_b = torch.from_numpy(b).cuda()
-        g_a = torch.empty((H, W), dtype=torch.uint8, device="cuda")
-        g_b = torch.empty((H, W), dtype=torch.uint8, device="cuda")
-        flow = torch.empty((H, W, 2), dtype=torch.float32, device="cuda")
-        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    # One step = one batch of `pairs` independent frame pairs, each on its own context (own HIP stream and
+    # scratch): frame pairs never exchange data, so they shard across streams exactly as they shard across GPUs.
+    P = max(1, args.pairs)
+    ctxs = [ofxcv.Context(local_rank) for _ in range(P)]
+    bufs = []
+    for i, c in enumerate(ctxs):
+        a, b = synth.flow_pair(W, H, seed=1234 + rank * P + i)
+        with torch.cuda.stream(c.stream):
+            bufs.append(dict(a=torch.from_numpy(a).cuda(), b=torch.from_numpy(b).cuda(),
+                             ga=torch.empty((H, W), dtype=torch.uint8, device="cuda"),
+                             gb=torch.empty((H, W), dtype=torch.uint8, device="cuda"),
+                             flow=torch.empty((H, W, 2), dtype=torch.float32, device="cuda"),
+                             out=torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")))
 
-        def step():
-            ctx.to_byte_grayscale(d_a, g_a)
-            ctx.to_byte_grayscale(d_b, g_b)
-            ctx.calc_optical_flow_farneback(g_a, g_b, flow, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
-            ctx.flow_to_rgba(flow, out, 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
+    def step():
+        for c, t in zip(ctxs, bufs):
+            with torch.cuda.stream(c.stream):
+                c.to_byte_grayscale(t["a"], t["ga"])
+                c.to_byte_grayscale(t["b"], t["gb"])
+                c.calc_optical_flow_farneback(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+                c.flow_to_rgba(t["flow"], t["out"], 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
 
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
 
-        # roofline leg: same process, same inputs -- event pairs around every level-0 iteration launch
-        ctx.profile_enable(True)
-        nprof = max(3, min(10, args.steps))
-        for _ in range(nprof):
-            step()
-        torch.cuda.synchronize()
-        kern_ms, kern_n = ctx.profile_read()
-        ctx.profile_enable(False)
+    # roofline leg: same process, same inputs, same concurrency -- HIP event pairs around every launch of the
+    # dominant kernel (level-0 fused iteration), recorded on the stream the kernel is launched on
+    for c in ctxs:
+        c.profile_enable(True)
+    for _ in range(max(2, min(6, args.steps))):
+        step()
+    torch.cuda.synchronize()
+    kern_ms, kern_n = 0.0, 0
+    for c in ctxs:
+        ms, n = c.profile_read()
+        kern_ms += ms
+        kern_n += n
+        c.profile_enable(False)
+    g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -127,7 +140,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        pairs = args.steps * world
+        pairs = args.steps * world * P
         value = pairs / elapsed
         avg_s = kern_ms / 1e3 / max(1, kern_n)
         achieved = ITER_BYTES_PER_PX * W * H / avg_s / 1e9
@@ -148,9 +161,9 @@ def main():
             "config": {"workload": "VectorGenerator Farneback dense optical flow, 1920x1080 f32 RGBA frame pair resident in HBM "
                                    "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[2])",
                        "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
-                       "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": 1, "parallelism": "independent frame pairs per GPU, no collective"},
+                       "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "blur_solve_update_kernel<true> (level 0, %dx%d)" % (W, H),
+                         "traffic": None, "kernel": "iterate3_kernel<true,1> (fused blur+solve+update, pyramid level 0, %dx%d)" % (W, H),
                          "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n},
             "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
                            "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},
@@ -162,7 +175,8 @@ def main():
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
 

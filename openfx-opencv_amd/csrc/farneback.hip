@@ -336,7 +336,7 @@ struct Taps {
     bool inb;
 };
 
-__device__ __forceinline__ Taps gather_taps(const float *__restrict__ R1, int x, int y, int w, int h, int pitch, size_t plane,
+__device__ __forceinline__ Taps gather_taps(const Buf &R1, int x, int y, int w, int h, int pitch, unsigned plane_bytes,
                                             float dx, float dy) {
     Taps tp;
     float fx = x + dx, fy = y + dy;
@@ -346,12 +346,11 @@ __device__ __forceinline__ Taps gather_taps(const float *__restrict__ R1, int x,
     tp.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
     const unsigned o0 = tp.inb ? ((unsigned)y1 * (unsigned)pitch + (unsigned)x1) * 4u : 0u, o1 = o0 + (unsigned)pitch * 4u;
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const char *pl = (const char *)(R1 + c * plane);  // wave-uniform plane base + 32-bit lane byte offset
-        tp.t[c].a = *(const float *)(pl + o0);
-        tp.t[c].b = *(const float *)(pl + o0 + 4);
-        tp.b[c].a = *(const float *)(pl + o1);
-        tp.b[c].b = *(const float *)(pl + o1 + 4);
+    for (int c = 0; c < 5; c++) {  // wave-uniform plane offset in soffset, 32-bit lane byte offset in voffset
+        tp.t[c].a = buf_ld(R1, o0, c * plane_bytes);
+        tp.t[c].b = buf_ld(R1, o0 + 4u, c * plane_bytes);
+        tp.b[c].a = buf_ld(R1, o1, c * plane_bytes);
+        tp.b[c].b = buf_ld(R1, o1 + 4u, c * plane_bytes);
     }
     return tp;
 }
@@ -400,7 +399,7 @@ __device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const T
 
 __device__ __forceinline__ M5 update_matrices_core(const float r0v[5], const float *__restrict__ R1, int x, int y, int w, int h,
                                                    int pitch, size_t plane, float dx, float dy) {
-    Taps tp = gather_taps(R1, x, y, w, h, pitch, plane, dx, dy);
+    Taps tp = gather_taps(make_buf(R1, 5 * plane * sizeof(float)), x, y, w, h, pitch, (unsigned)(plane * 4), dx, dy);
     return update_matrices_finish(r0v, tp, x, y, w, h, dx, dy);
 }
 
@@ -500,17 +499,21 @@ __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__r
 
 // Specialisation for the 3x3 window the reference uses (winSize = 3, VectorGenerator.cpp:395).
 //
-// Row walker, PX pixels per lane: one wavefront owns 64*PX consecutive columns and walks down `rows`
-// image rows.  The texture-addresser cost of a vector-memory instruction is per instruction, not per
-// byte, so every streaming access is PX floats wide (dwordx4 for PX = 4): per row a lane issues one
-// load per plane of M and of R0 and one store per plane of M-out for its PX pixels.  The left / right
-// window neighbours of a lane's pixel group arrive by DPP wave shifts (the wavefront shuffle of the
-// 3-wide window reduction); only lanes 0 and 63 fetch the wave's halo column.  The f64 horizontal sums
-// of the new window row join the two previous row sums held in registers, so the vertical reuse of
-// the window costs no memory traffic and no LDS.  The next row's M and R0 values are requested before
-// the current row's 2x2 solves and R1 gathers, so a wave always has loads in flight.  Summation order
-// (per window row left to right, rows top to bottom) is that of the oracle's direct evaluation:
-// results are bit-identical to it.
+// Row walker: one wavefront owns 64 consecutive columns and walks down ROWS image rows.  Per row each
+// lane loads ONE new value per plane of M (a single coalesced 256-byte request per plane); its left and
+// right window neighbours arrive by DPP wave shifts (the wavefront shuffle of the 3-wide window
+// reduction) and only lanes 0 and 63 fetch the wave's halo column.  The f64 horizontal sum of the new
+// window row joins the two previous row sums held in registers, so the vertical reuse of the window
+// costs no memory traffic and no LDS.  The next row's M and R0 values are requested before the current
+// row's 2x2 solve and R1 gather, so a wave always has loads in flight.  ROWS is a template parameter:
+// the row loop is fully unrolled, which removes the register rotation of the window (a quarter of the
+// VALU instructions of a rolled loop).  Summation order (per window row left to right, rows top to
+// bottom) is that of the oracle's direct evaluation: results are bit-identical to it.
+//
+// Measured on MI355X (tools/ubench/l1rate.hip, tools/bench_stage.py): a coalesced dword wave-load costs
+// ~5 clk of the CU's texture addresser and a dwordx2/x4 one ~18 clk, and 2- or 4-pixel lanes were
+// slower (VGPR pressure halves the occupancy while the per-row dependent chain stays), hence one pixel
+// per lane and dword accesses throughout.
 __device__ __forceinline__ float dpp_from_left(float v, float edge) {  // lane i <- lane i-1, lane 0 <- edge
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
@@ -518,67 +521,32 @@ __device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 
-template <int PX>
-__device__ __forceinline__ void buf_ldv(const Buf &b, unsigned voff, unsigned soff, float out[PX]) {
-    if constexpr (PX == 1) {
-        out[0] = buf_ld(b, voff, soff);
-    } else if constexpr (PX == 2) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        u2 v = __builtin_amdgcn_raw_buffer_load_b64(b.r, (int)voff, (int)soff, 0);
-        out[0] = __builtin_bit_cast(float, v.x);
-        out[1] = __builtin_bit_cast(float, v.y);
-    } else {
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        u4 v = __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff, (int)soff, 0);
-        out[0] = __builtin_bit_cast(float, v.x);
-        out[1] = __builtin_bit_cast(float, v.y);
-        out[2] = __builtin_bit_cast(float, v.z);
-        out[3] = __builtin_bit_cast(float, v.w);
-    }
-}
-template <int PX>
-__device__ __forceinline__ void buf_stv(const Buf &b, const float in[PX], unsigned voff, unsigned soff) {
-    if constexpr (PX == 1) {
-        buf_st(b, in[0], voff, soff);
-    } else if constexpr (PX == 2) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        u2 v = {__builtin_bit_cast(unsigned, in[0]), __builtin_bit_cast(unsigned, in[1])};
-        __builtin_amdgcn_raw_buffer_store_b64(v, b.r, (int)voff, (int)soff, 0);
-    } else {
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        u4 v = {__builtin_bit_cast(unsigned, in[0]), __builtin_bit_cast(unsigned, in[1]), __builtin_bit_cast(unsigned, in[2]),
-                __builtin_bit_cast(unsigned, in[3])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, b.r, (int)voff, (int)soff, 0);
-    }
-}
-
-template <bool UPDATE, int PX>
+template <bool UPDATE, int ROWS>
 __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                        const float *__restrict__ Min, float *__restrict__ Mout,
                                                        float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
-                                                       int rows, double scale) {
+                                                       double scale) {
     const int lane = threadIdx.x & 63;
-    const int xw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * PX);  // first column of this wave
-    if (xw >= w) return;
-    const int x = xw + lane * PX;  // first column of this lane
-    const int y0 = blockIdx.y * rows, y1 = min(y0 + rows, h);
-    const int nvalid = min(max(w - x, 0), PX);  // pixels of this lane inside the image
-    const bool last_in_row = x + PX >= w;       // holds pixel w-1 (or lies beyond it): right neighbour is replicated
-    // halo column of this wave: lane 0 fetches xw-1, lane 63 fetches xw+64*PX (clamped = replicated border)
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if ((x & ~63) >= w) return;  // whole wave outside
+    const int y0 = blockIdx.y * ROWS;
+    const bool live = x < w;
+    const int xc = min(x, w - 1);
+    // halo column of this wave: lane 0 fetches x-1, lane 63 fetches x+1 (clamped = replicated border)
     const bool edge_lane = lane == 0 || lane == 63;
-    const unsigned ve = 4u * (unsigned)(lane == 0 ? max(xw - 1, 0) : min(xw + 64 * PX, w - 1));
-    const unsigned vc = 4u * (unsigned)x;
+    const unsigned ve = 4u * (unsigned)(lane == 0 ? max(xc - 1, 0) : min(xc + 1, w - 1));
+    const unsigned vc = 4u * (unsigned)xc;
     const size_t plane = (size_t)pitch * h;
     const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u;  // plane / row strides in bytes
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
-              bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
 
-    // one raw row of M: PX centre values per lane and plane + the halo value in the edge lanes
-    auto load_row = [&](int yy, float mc[5][PX], float me[5]) {
+    // one raw row of M: the lane's value per plane + the halo value in the edge lanes
+    auto load_row = [&](int yy, float mc[5], float me[5]) {
         const unsigned so = (unsigned)yy * rb;  // wave-uniform
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            buf_ldv<PX>(bM, vc, so + c * pb, mc[c]);
+            mc[c] = buf_ld(bM, vc, so + c * pb);
             me[c] = 0.f;
         }
         if (edge_lane) {
@@ -586,97 +554,52 @@ __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__
             for (int c = 0; c < 5; c++) me[c] = buf_ld(bM, ve, so + c * pb);
         }
     };
-    // f64 3-wide horizontal sums of one window row for the lane's PX pixels
-    auto hsum = [&](float mc[5][PX], const float me[5], double hs[PX][5]) {
+    auto hsum = [&](const float mc[5], const float me[5], double hs[5]) {
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-#pragma unroll
-            for (int i = 1; i < PX; i++) mc[c][i] = i < nvalid ? mc[c][i] : mc[c][i - 1];  // replicate past column w-1
-            float L = dpp_from_left(mc[c][PX - 1], me[c]), R = dpp_from_right(mc[c][0], me[c]);
-            if (last_in_row) R = mc[c][PX - 1];
-            double e[PX + 2];
-            e[0] = (double)L;
-#pragma unroll
-            for (int i = 0; i < PX; i++) e[i + 1] = (double)mc[c][i];
-            e[PX + 1] = (double)R;
-#pragma unroll
-            for (int i = 0; i < PX; i++) hs[i][c] = (e[i] + e[i + 1]) + e[i + 2];
+            float ml = dpp_from_left(mc[c], me[c]), mr = dpp_from_right(mc[c], me[c]);
+            hs[c] = ((double)ml + (double)mc[c]) + (double)mr;
         }
     };
 
-    double hsA[PX][5], hsB[PX][5];
-    float mc[5][PX], me[5], r0n[5][PX];
-    load_row(max(y0 - 1, 0), mc, me);
-    hsum(mc, me, hsA);
-    load_row(y0, mc, me);
-    hsum(mc, me, hsB);
-    load_row(min(y0 + 1, h - 1), mc, me);
+    // window row sums: hs[r] holds image row y0 - 1 + r
+    double hs[ROWS + 2][5];
+    float mc[ROWS + 2][5], me[ROWS + 2][5], r0v[ROWS][5];
+    load_row(max(y0 - 1, 0), mc[0], me[0]);
+    load_row(y0, mc[1], me[1]);
+    load_row(min(y0 + 1, h - 1), mc[2], me[2]);
     if (UPDATE) {
 #pragma unroll
-        for (int c = 0; c < 5; c++) buf_ldv<PX>(bR0, vc, (unsigned)y0 * rb + c * pb, r0n[c]);
+        for (int c = 0; c < 5; c++) r0v[0][c] = buf_ld(bR0, vc, (unsigned)y0 * rb + c * pb);
     }
-    for (int y = y0; y < y1; y++) {
-        double hsC[PX][5];
-        float r0v[5][PX];
-        hsum(mc, me, hsC);
+    hsum(mc[0], me[0], hs[0]);
+    hsum(mc[1], me[1], hs[1]);
 #pragma unroll
-        for (int c = 0; c < 5; c++)
-#pragma unroll
-            for (int i = 0; i < PX; i++) r0v[c][i] = r0n[c][i];
-        if (y + 1 < y1) {  // request the next row before the dependent solves + gathers of this one
-            load_row(min(y + 2, h - 1), mc, me);
+    for (int r = 0; r < ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= h) break;  // wave-uniform
+        if (r + 1 < ROWS) {  // request the next row before the dependent solve + gather of this one
+            load_row(min(y + 2, h - 1), mc[r + 3 < ROWS + 2 ? r + 3 : 0], me[r + 3 < ROWS + 2 ? r + 3 : 0]);
             if (UPDATE) {
 #pragma unroll
-                for (int c = 0; c < 5; c++) buf_ldv<PX>(bR0, vc, (unsigned)(y + 1) * rb + c * pb, r0n[c]);
+                for (int c = 0; c < 5; c++) r0v[r + 1][c] = buf_ld(bR0, vc, (unsigned)min(y + 1, h - 1) * rb + c * pb);
             }
         }
-        float fxv[PX], fyv[PX];
+        hsum(mc[r + 2], me[r + 2], hs[r + 2]);
+        double acc[5];
 #pragma unroll
-        for (int i = 0; i < PX; i++) {
-            double acc[5];
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                acc[c] = (hsA[i][c] + hsB[i][c]) + hsC[i][c];
-                hsA[i][c] = hsB[i][c];
-                hsB[i][c] = hsC[i][c];
-            }
-            double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-            double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-            fxv[i] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-            fyv[i] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
-        }
-        if (flow) {
-            float2 *frow = (float2 *)((char *)flow + (size_t)y * flow_step) + x;
-#pragma unroll
-            for (int i = 0; i < PX; i++)
-                if (i < nvalid) frow[i] = make_float2(fxv[i], fyv[i]);
-        }
+        for (int c = 0; c < 5; c++) acc[c] = (hs[r][c] + hs[r + 1][c]) + hs[r + 2][c];
+        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        if (flow && live) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
         if (UPDATE) {
-            float mo[5][PX];
-            // all R1 taps of the lane's pixels are requested before any of them is consumed
-            Taps tp[PX];
+            Taps tp = gather_taps(bR1, xc, y, w, h, pitch, pb, fxv, fyv);
+            M5 mm = update_matrices_finish(r0v[r], tp, xc, y, w, h, fxv, fyv);
+            if (live) {
 #pragma unroll
-            for (int i = 0; i < PX; i++) tp[i] = gather_taps(R1, min(x + i, w - 1), y, w, h, pitch, plane, fxv[i], fyv[i]);
-#pragma unroll
-            for (int i = 0; i < PX; i++) {
-                float r0p[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0p[c] = r0v[c][i];
-                M5 mm = update_matrices_finish(r0p, tp[i], min(x + i, w - 1), y, w, h, fxv[i], fyv[i]);
-#pragma unroll
-                for (int c = 0; c < 5; c++) mo[c][i] = mm.v[c];
-            }
-            const unsigned so = (unsigned)y * rb;
-            if (nvalid == PX) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) buf_stv<PX>(bMo, mo[c], vc, so + c * pb);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PX; i++)
-                    if (i < nvalid) {
-#pragma unroll
-                        for (int c = 0; c < 5; c++) buf_st(bMo, mo[c][i], vc + 4u * i, so + c * pb);
-                    }
+                for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], vc, (unsigned)y * rb + c * pb);
             }
         }
     }
@@ -739,20 +662,25 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
     if (winsize == 3) {
-        // One pixel per lane: 2- and 4-pixel lanes (dwordx2/x4 streams) were measured slower on MI355X -- the
-        // kernel is bound by its per-row dependent chain, not by load width, and wide lanes cost occupancy.
-        // Rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels.
-        constexpr int px = 1;
-        const int cols = ofxcv_div_up(w, 64 * px);
-        int rows = 2;
-        while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 2048) rows >>= 1;
+        // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
+        const int cols = ofxcv_div_up(w, 64);
+        int rows = 4;
+        while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
         if (const char *e = getenv("OFXCV_ROWS")) rows = atoi(e);
-        dim3 grid(ofxcv_div_up(w, 256 * px), ofxcv_div_up(h, rows)), block(256);
+        dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
         const int pitch = plane_pitch(w);
-        if (update)
-            hipLaunchKernelGGL((iterate3_kernel<true, px>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, rows, scale);
-        else
-            hipLaunchKernelGGL((iterate3_kernel<false, px>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, rows, scale);
+#define OFXCV_LAUNCH_IT(UPD, RW) \
+    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale)
+        if (update) {
+            if (rows == 4) OFXCV_LAUNCH_IT(true, 4);
+            else if (rows == 2) OFXCV_LAUNCH_IT(true, 2);
+            else OFXCV_LAUNCH_IT(true, 1);
+        } else {
+            if (rows == 4) OFXCV_LAUNCH_IT(false, 4);
+            else if (rows == 2) OFXCV_LAUNCH_IT(false, 2);
+            else OFXCV_LAUNCH_IT(false, 1);
+        }
+#undef OFXCV_LAUNCH_IT
         OFXCV_LAUNCH_CHECK(ctx, "iterate3_kernel");
         return OFXCV_OK;
     }
