@@ -165,3 +165,37 @@ def flow_to_rgba(flow, dst, chan_u, chan_v, rs_x=1.0, rs_y=1.0):
     lib().orc_flow_to_rgba(_p(flow), C.c_int(w), C.c_int(h), _p(dst), C.c_ssize_t(w * 16), cu, cv,
                            C.c_double(rs_x), C.c_double(rs_y))
     return dst
+
+
+# ---- inpaint ----------------------------------------------------------------------------------------------
+def inpaint_mask(rgba, dilate_iters=1):
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w, _ = rgba.shape
+    mask = np.empty((h, w), np.uint8)
+    lib().orc_inpaint_mask(_p(rgba), C.c_ssize_t(w * 4), C.c_int(w), C.c_int(h), C.c_int(dilate_iters), _p(mask))
+    return mask
+
+
+def inpaint_telea(rgb, mask, radius=3.0, maps=False):
+    """cvInpaint(rgb, mask, out, radius, CV_INPAINT_TELEA); maps=True also returns (t, f, order)."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty_like(rgb)
+    t = np.empty((h + 2, w + 2), np.float32)
+    f = np.empty((h + 2, w + 2), np.uint8)
+    order = np.empty((h, w), np.int32)
+    fn = lib().orc_inpaint_telea
+    fn.restype = C.c_int
+    fn(_p(rgb), _p(mask), C.c_int(w), C.c_int(h), C.c_double(radius), _p(out), _p(t), _p(f), _p(order))
+    return (out, t, f, order) if maps else out
+
+
+def inpaint_render(rgba, radius=3.0, dilation=1.0):
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w, _ = rgba.shape
+    dst = np.empty_like(rgba)
+    fn = lib().orc_inpaint_render
+    fn.restype = C.c_int
+    fn(_p(rgba), C.c_ssize_t(w * 4), C.c_int(w), C.c_int(h), C.c_double(radius), C.c_double(dilation), _p(dst), C.c_ssize_t(w * 4))
+    return dst
