@@ -91,6 +91,32 @@ int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_
                               double render_scale_y, int levels, int iterations, int poly_n,
                               double poly_sigma);
 
+/* ---- I0-I2: inpaint hole mask -------------------------------------------------------------
+ * replaces cvCvtColor(imgSrc, mask, CV_RGBA2GRAY) + cvThreshold(mask, mask, 0, 255, CV_THRESH_BINARY_INV)
+ * + cvDilate(mask, mask, NULL, (int)t2) at opencv2fx/inpaint/inpaint.cpp:305-309.
+ * d_rgba: 8-bit RGBA (4-byte aligned rows), d_mask: 8-bit, 255 = hole. */
+int ofxcv_inpaint_mask(ofxcv_ctx *ctx, const uint8_t *d_rgba, ptrdiff_t row_bytes, int width, int height,
+                       int dilate_iters, uint8_t *d_mask, ptrdiff_t mask_step, void *stream);
+
+/* ---- I3-I4: Telea inpainting ---------------------------------------------------------------
+ * replaces cvInpaint(image0, mask, image1, t1, CV_INPAINT_TELEA) at opencv2fx/inpaint/inpaint.cpp:311-318.
+ * d_src/d_dst: 8-bit images with `channels` (3 or 4) bytes per pixel, the first three are inpainted (the
+ * cvCvtColor RGBA2RGB copies of :303-304 become a pixel stride); d_src != d_dst.  Optional outputs for
+ * parity checks (may be NULL): d_t_map (height+2)*(width+2) f32 final distance map of the padded image,
+ * d_order_map width*height int32 fill order (1-based, 0 = not filled).  Synchronises `stream`: the
+ * fast-marching front is advanced on the calling host thread. */
+int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels,
+                        const uint8_t *d_mask, ptrdiff_t mask_step, int width, int height, double radius,
+                        uint8_t *d_dst, ptrdiff_t dst_step, float *d_t_map, int *d_order_map, void *stream);
+
+/* ---- whole inpaint render() body for host-resident OFX images (noise == 0 path) --------------
+ * replaces opencv2fx/inpaint/inpaint.cpp:286-358: RGBA in -> RGBA out, alpha forced to 255.  h_mask_out
+ * (optional, width*height) receives the dilated hole mask so the caller can apply the libc-rand() noise of
+ * :336-347 itself when the noise parameter is non-zero. */
+int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t src_row_bytes, int width, int height,
+                              double radius, double dilation, uint8_t *h_dst, ptrdiff_t dst_row_bytes,
+                              uint8_t *h_mask_out);
+
 /* ---- stage-level entry points (the internal stages of calcOpticalFlowFarneback) ------------
  * Exposed so each stage can be parity-checked on its own against the oracle's restatement of
  * modules/video/src/optflowgf.cpp.  Planes: a 5-channel field is stored as 5 consecutive planes

@@ -57,6 +57,7 @@ EXPORTS = [
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
+    "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint_render_host",
 ]
 
 
@@ -181,6 +182,40 @@ class Context:
             C.c_ssize_t(dst.strides[0]), C.c_uint(chan_u_mask), C.c_uint(chan_v_mask), C.c_double(rs_x), C.c_double(rs_y),
             C.c_int(levels), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma)))
         return dst
+
+    # ---- inpaint ----
+    def inpaint_mask(self, rgba, dilate_iters=1):
+        """rgba: HxWx4 uint8 CUDA tensor -> HxW uint8 hole mask (255 = hole)."""
+        import torch
+        h, w, _ = rgba.shape
+        mask = torch.empty((h, w), dtype=torch.uint8, device=rgba.device)
+        self._call(lib().ofxcv_inpaint_mask, _ptr(rgba), C.c_ssize_t(rgba.stride(0)), C.c_int(w), C.c_int(h), C.c_int(dilate_iters),
+                   _ptr(mask), C.c_ssize_t(w))
+        return mask
+
+    def inpaint_telea(self, src, mask, radius=3.0, maps=False):
+        """Mirror of cvInpaint(src, mask, dst, radius, CV_INPAINT_TELEA); src HxWx{3,4} uint8, mask HxW uint8."""
+        import torch
+        h, w, cn = src.shape
+        dst = torch.empty_like(src)
+        t = torch.empty((h + 2, w + 2), dtype=torch.float32, device=src.device) if maps else None
+        order = torch.empty((h, w), dtype=torch.int32, device=src.device) if maps else None
+        self._call(lib().ofxcv_inpaint_telea, _ptr(src), C.c_ssize_t(src.stride(0)), C.c_int(cn), _ptr(mask), C.c_ssize_t(mask.stride(0)),
+                   C.c_int(w), C.c_int(h), C.c_double(radius), _ptr(dst), C.c_ssize_t(dst.stride(0)),
+                   _ptr(t) if maps else None, _ptr(order) if maps else None)
+        return (dst, t, order) if maps else dst
+
+    def inpaint_render_host(self, rgba, radius=3.0, dilation=1.0, want_mask=False):
+        """Whole inpaint render() body on a host image (numpy HxWx4 uint8)."""
+        import numpy as np
+        h, w, _ = rgba.shape
+        assert rgba.dtype == np.uint8 and rgba.strides[1] == 4 and rgba.strides[2] == 1
+        dst = np.empty((h, w, 4), np.uint8)
+        mask = np.empty((h, w), np.uint8) if want_mask else None
+        self._check(lib().ofxcv_inpaint_render_host(self._h, C.c_void_p(rgba.ctypes.data), C.c_ssize_t(rgba.strides[0]), C.c_int(w),
+                                                    C.c_int(h), C.c_double(radius), C.c_double(dilation), C.c_void_p(dst.ctypes.data),
+                                                    C.c_ssize_t(w * 4), C.c_void_p(mask.ctypes.data) if want_mask else None))
+        return (dst, mask) if want_mask else dst
 
     # ---- stage-level (parity tests) ----
     def farneback_pyr_image(self, img, lw, lh, sigma, ksize):

@@ -35,6 +35,11 @@ struct ofxcv_ctx {
     DevBuf fb_flow;    // two ping-pong coarse flow fields
     DevBuf fb_coef;    // polyexp / blur coefficient tables
 
+    // inpaint scratch
+    DevBuf ip_tmp;   // undilated mask
+    DevBuf ip_maps;  // distance / order maps and the per-level pixel lists of the colour fill
+    DevBuf ip_img;   // device copies of the host images (render_host)
+
     // measurement hook: event pairs around the dominant kernel (see ofxcv_profile_enable)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;  // start/stop pairs, recorded but not yet read

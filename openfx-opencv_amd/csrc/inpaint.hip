@@ -1,0 +1,508 @@
+// inpaint.hip -- the OpenCV calls of the opencv2fx/inpaint render() body (opencv2fx/inpaint/inpaint.cpp:303-318):
+//   I0  cvCvtColor(RGBA2RGB) x2, cvCvtColor(RGBA2GRAY)            :303-305
+//   I1  cvThreshold(mask, mask, 0, 255, CV_THRESH_BINARY_INV)       :307
+//   I2  cvDilate(mask, mask, NULL, (int)t2)                         :309
+//   I3  cvInpaint set-up: band / ring maps on the 1-pixel padded image
+//   I4  cvInpaint(image0, mask, image1, t1, CV_INPAINT_TELEA)       :311-318  (photo/src/inpaint.cpp)
+//
+// Split of the Telea algorithm (see DESIGN.md "inpaint"):
+//   * I0-I2 are exact-integer pixel kernels (one coalesced dword per lane).
+//   * The fast-marching front (distance map T and the order in which hole pixels are filled) depends only
+//     on the hole mask, never on colours, and is a strictly sequential priority-queue recurrence: a pixel
+//     receives its T once, from the state at the moment its first neighbour is accepted.  It touches only
+//     hole pixels (a few % of the frame) and runs on the host thread that owns the context.
+//   * The colour fill (>90 % of the arithmetic: a (2r+1)^2 weighted window per pixel and channel) runs on
+//     the GPU.  A pixel may only be computed after every earlier-filled pixel inside its window; pixels
+//     are grouped into dependency levels and one persistent 1024-thread workgroup walks the levels with a
+//     barrier in between.  Inside a pixel the window taps are evaluated in parallel by a 16-lane group and
+//     then accumulated strictly in the reference's row-major order (float addition is not associative and
+//     the result is rounded twice, so the order matters for bit-exact colours).
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <queue>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+enum : uint8_t { KNOWN = 0, BAND = 1, INSIDE = 2, CHANGE = 3 };
+constexpr int kNeverFilled = INT_MAX;  // hole pixel the march never reaches (image row / column 0)
+
+// ------------------------------------------------------------------ I0-I2 kernels
+
+// RGBA -> hole mask: gray = (R*4899 + G*9617 + B*1868 + 8192) >> 14 (cvCvtColor RGBA2GRAY, channel 0 = R),
+// mask = gray > 0 ? 0 : 255 (THRESH_BINARY_INV at 0)
+__global__ __launch_bounds__(256) void rgba_to_mask_kernel(const uint8_t *__restrict__ src, ptrdiff_t row_bytes, int w, int h,
+                                                           uint8_t *__restrict__ mask, ptrdiff_t mask_step) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint32_t p = *(const uint32_t *)(src + (ptrdiff_t)y * row_bytes + (size_t)x * 4);
+    int r = p & 255, g = (p >> 8) & 255, b = (p >> 16) & 255;
+    int gray = (r * 4899 + g * 9617 + b * 1868 + 8192) >> 14;
+    mask[(ptrdiff_t)y * mask_step + x] = gray > 0 ? 0 : 255;
+}
+
+// `iters` 3x3-rect dilations == one (2*iters+1)^2 max; pixels outside the image never contribute
+__global__ __launch_bounds__(256) void dilate_rect_kernel(const uint8_t *__restrict__ src, ptrdiff_t src_step, int w, int h, int r,
+                                                          uint8_t *__restrict__ dst, ptrdiff_t dst_step) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint8_t m = 0;
+    for (int dy = -r; dy <= r; dy++) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        const uint8_t *row = src + (ptrdiff_t)yy * src_step;
+        for (int dx = -r; dx <= r; dx++) {
+            int xx = x + dx;
+            if (xx >= 0 && xx < w) m = max(m, row[xx]);
+        }
+    }
+    dst[(ptrdiff_t)y * dst_step + x] = m;
+}
+
+// ------------------------------------------------------------------ I3/I4 front march (host)
+
+struct QElem {
+    float T;
+    unsigned seq;
+    int i, j;
+};
+struct QCmp {  // pop order of CvPriorityQueueFloat: smallest T first, equal T in push order
+    bool operator()(const QElem &a, const QElem &b) const { return a.T > b.T || (a.T == b.T && a.seq > b.seq); }
+};
+struct FrontQueue {
+    std::priority_queue<QElem, std::vector<QElem>, QCmp> q;
+    unsigned seq = 0;
+    void push(int i, int j, float T) { q.push(QElem{T, seq++, i, j}); }
+    bool pop(int &i, int &j) {
+        if (q.empty()) return false;
+        i = q.top().i;
+        j = q.top().j;
+        q.pop();
+        return true;
+    }
+};
+
+inline float eikonal(int i1, int j1, int i2, int j2, const uint8_t *f, const float *t, int ec) {
+    double a11 = t[i1 * ec + j1], a22 = t[i2 * ec + j2], m12 = std::min(a11, a22), sol;
+    if (f[i1 * ec + j1] != INSIDE) {
+        if (f[i2 * ec + j2] != INSIDE) {
+            if (std::fabs(a11 - a22) >= 1.0) sol = 1 + m12;
+            else sol = (a11 + a22 + std::sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
+        } else
+            sol = 1 + a11;
+    } else if (f[i2 * ec + j2] != INSIDE)
+        sol = 1 + a22;
+    else
+        sol = 1 + m12;
+    return (float)sol;
+}
+inline float front_value(int i, int j, const uint8_t *f, const float *t, int ec) {
+    float a = eikonal(i - 1, j, i, j - 1, f, t, ec), b = eikonal(i + 1, j, i, j - 1, f, t, ec);
+    float c = eikonal(i - 1, j, i, j + 1, f, t, ec), d = eikonal(i + 1, j, i, j + 1, f, t, ec);
+    return std::min(std::min(a, b), std::min(c, d));
+}
+
+void dilate_host(const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, int rows, int cols, int r, bool cross) {
+    dst.assign(src.size(), 0);
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++) {
+            if (!src[i * cols + j]) continue;
+            for (int di = -r; di <= r; di++)
+                for (int dj = -r; dj <= r; dj++) {
+                    if (cross && di && dj) continue;
+                    int ii = i + di, jj = j + dj;
+                    if (ii < 0 || jj < 0 || ii >= rows || jj >= cols) continue;
+                    dst[ii * cols + jj] = std::max(dst[ii * cols + jj], src[i * cols + j]);
+                }
+        }
+}
+void zero_frame(std::vector<uint8_t> &m, int rows, int cols) {
+    for (int j = 0; j < cols; j++) m[j] = m[(rows - 1) * cols + j] = 0;
+    for (int i = 0; i < rows; i++) m[i * cols] = m[i * cols + cols - 1] = 0;
+}
+
+struct March {
+    int w = 0, h = 0, range = 1;
+    std::vector<float> t;      // (h+2)*(w+2) final distance map (negative outside the hole within `range`)
+    std::vector<int> ord;      // (h+2)*(w+2): 0 = not a hole pixel, k >= 1 = filled k-th, kNeverFilled = hole never reached
+    std::vector<int> pix;      // fill order: padded linear index of the k-th filled pixel
+    std::vector<int> level;    // dependency level (>= 1) of the k-th filled pixel
+    std::vector<int> lvl_pix;  // pixels (padded linear index) sorted by (level, order)
+    std::vector<int> lvl_ord;  // their order numbers
+    std::vector<int> lvl_off;  // CSR offsets per level
+};
+
+// cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
+void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
+    const int ec = w + 2, er = h + 2;
+    const size_t en = (size_t)ec * er;
+    m.w = w;
+    m.h = h;
+    m.range = range;
+    std::vector<uint8_t> mask(en, 0), band, ring;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++)
+            if (mask_in[(size_t)i * w + j]) mask[(i + 1) * ec + j + 1] = INSIDE;
+    m.t.assign(en, 1.0e6f);
+    m.ord.assign(en, 0);
+    m.pix.clear();
+    dilate_host(mask, band, er, ec, 1, true);
+    bool any = false;
+    for (size_t i = 0; i < en; i++) any |= band[i] != 0;
+    if (!any) return;
+    for (size_t i = 0; i < en; i++) band[i] = band[i] > mask[i] ? band[i] - mask[i] : 0;
+    zero_frame(band, er, ec);
+    FrontQueue heap, outq;
+    for (int i = 0; i < er; i++)
+        for (int j = 0; j < ec; j++)
+            if (band[i * ec + j]) {
+                heap.push(i, j, 0);
+                outq.push(i, j, 0);
+                m.t[i * ec + j] = 0;
+            }
+    // outward distances (negated) on the ring = dilate(mask, (2r+1)^2) - mask - band
+    dilate_host(mask, ring, er, ec, range, false);
+    bool any_ring = false;
+    for (size_t i = 0; i < en; i++) {
+        ring[i] = ring[i] > mask[i] ? ring[i] - mask[i] : 0;
+        any_ring |= ring[i] != 0;
+    }
+    if (!any_ring) return;  // Out->Init fails in the reference: cvInpaint returns without filling
+    for (size_t i = 0; i < en; i++) ring[i] = ring[i] > band[i] ? ring[i] - band[i] : 0;
+    zero_frame(ring, er, ec);
+    int ii, jj;
+    float *t = m.t.data();
+    {
+        uint8_t *f = ring.data();
+        while (outq.pop(ii, jj)) {
+            f[ii * ec + jj] = CHANGE;
+            const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
+            for (int q = 0; q < 4; q++) {
+                int i = ni[q], j = nj[q];
+                if (i <= 0 || j <= 0 || i > er || j > ec) continue;
+                if (f[i * ec + j] != INSIDE) continue;
+                float dist = front_value(i, j, f, t, ec);
+                t[i * ec + j] = dist;
+                f[i * ec + j] = BAND;
+                outq.push(i, j, dist);
+            }
+        }
+        for (size_t i = 0; i < en; i++)
+            if (f[i] == CHANGE) t[i] = -t[i];
+    }
+    // inward front over the hole; the reference passes `mask` ({KNOWN, INSIDE}) as the flag map
+    for (size_t i = 0; i < en; i++)
+        if (mask[i]) m.ord[i] = kNeverFilled;
+    uint8_t *f = mask.data();
+    int filled = 0;
+    while (heap.pop(ii, jj)) {
+        f[ii * ec + jj] = KNOWN;
+        const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
+        for (int q = 0; q < 4; q++) {
+            int i = ni[q], j = nj[q];
+            if (i <= 1 || j <= 1 || i > er - 1 || j > ec - 1) continue;
+            if (f[i * ec + j] != INSIDE) continue;
+            float dist = front_value(i, j, f, t, ec);
+            t[i * ec + j] = dist;
+            f[i * ec + j] = BAND;
+            heap.push(i, j, dist);
+            m.ord[i * ec + j] = ++filled;
+            m.pix.push_back(i * ec + j);
+        }
+    }
+}
+
+// level(p) = 1 + max level of the pixels filled before p within Chebyshev distance range+2 (every pixel whose
+// colour p can read: window range, +1 for the image-gradient taps, +1 for the row/column-1 sample quirk)
+void build_levels(March &m) {
+    const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
+    const int n = (int)m.pix.size();
+    m.level.assign(n, 1);
+    std::vector<int> lvl_map((size_t)ec * er, 0);
+    int nlev = 0;
+    const bool windowed = (long)(2 * R + 1) * (2 * R + 1) * n <= 400000000L;
+    for (int k = 0; k < n; k++) {
+        const int p = m.pix[k], i = p / ec, j = p % ec;
+        int lv = 0;
+        if (windowed) {
+            for (int a = std::max(i - R, 1); a <= std::min(i + R, er - 2); a++) {
+                const int *row = lvl_map.data() + (size_t)a * ec;
+                for (int b = std::max(j - R, 1); b <= std::min(j + R, ec - 2); b++) lv = std::max(lv, row[b]);
+            }
+        } else {
+            lv = k;  // very large radius: plain sequential order
+        }
+        m.level[k] = lv + 1;
+        lvl_map[p] = lv + 1;
+        nlev = std::max(nlev, lv + 1);
+    }
+    m.lvl_off.assign(nlev + 1, 0);
+    for (int k = 0; k < n; k++) m.lvl_off[m.level[k]]++;
+    for (int l = 1; l <= nlev; l++) m.lvl_off[l] += m.lvl_off[l - 1];
+    m.lvl_pix.resize(n);
+    m.lvl_ord.resize(n);
+    std::vector<int> cur(m.lvl_off.begin(), m.lvl_off.end() - 1);
+    for (int k = 0; k < n; k++) {
+        int at = cur[m.level[k] - 1]++;
+        m.lvl_pix[at] = m.pix[k];
+        m.lvl_ord[at] = k + 1;
+    }
+}
+
+// ------------------------------------------------------------------ I4 colour fill (device)
+
+constexpr int kGroup = 16;                       // lanes cooperating on one pixel
+constexpr int kFillThreads = 1024;               // one persistent workgroup
+constexpr int kSlots = kFillThreads / kGroup;    // pixels in flight per round
+constexpr int kAcc = 10;                         // Ia[3], Jx[3], Jy[3], s
+constexpr int kChunk = 32;                       // window taps staged per pass (64 slots x 32 taps x 11 floats = 88 KiB of LDS)
+
+struct FillArgs {
+    const float *t;        // padded distance map
+    const int *ord;        // padded order map
+    const uint8_t *src;    // original image, `cn` bytes per pixel
+    uint8_t *out;          // image being filled (initialised to src)
+    ptrdiff_t src_step, out_step;
+    int cn;                // 3 or 4 bytes per pixel
+    int w, h, range;
+    const int *lvl_pix, *lvl_ord, *lvl_off;
+    int nlev;
+};
+
+__global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
+    __shared__ float terms[kSlots][kChunk][kAcc + 1];  // +1: odd stride, no bank conflicts on the column walks
+    __shared__ float accs[kSlots][kAcc];
+    const int ec = a.w + 2, er = a.h + 2, range = a.range;
+    const int side = 2 * range + 1, ntap = side * side;
+    const int slot = threadIdx.x / kGroup, gl = threadIdx.x % kGroup;
+
+    // colour of image pixel (r,c) as the sequential algorithm sees it when pixel number `o` is being filled
+    auto img = [&](int r, int c, int ch, int o) -> float {
+        int q = a.ord[(r + 1) * ec + c + 1];
+        if (q != 0 && q < o)  // filled earlier: read past the L1 (written by another wave of this workgroup)
+            return (float)*(const volatile uint8_t *)(a.out + (ptrdiff_t)r * a.out_step + (size_t)c * a.cn + ch);
+        return (float)a.src[(ptrdiff_t)r * a.src_step + (size_t)c * a.cn + ch];
+    };
+
+    for (int lv = 0; lv < a.nlev; lv++) {
+        const int beg = a.lvl_off[lv], end = a.lvl_off[lv + 1];
+        for (int base = beg; base < end; base += kSlots) {
+            const int id = base + slot;
+            const bool act = id < end;
+            int i = 0, j = 0, o = 0;
+            float Tij = 0, gTx = 0, gTy = 0;
+            if (act) {
+                const int p = a.lvl_pix[id];
+                o = a.lvl_ord[id];
+                i = p / ec;
+                j = p - i * ec;
+                auto inside = [&](int r, int c) { return a.ord[r * ec + c] >= o; };  // INSIDE at the time of `o`
+                auto T = [&](int r, int c) { return a.t[r * ec + c]; };
+                Tij = T(i, j);
+                if (!inside(i, j + 1)) gTx = !inside(i, j - 1) ? (T(i, j + 1) - T(i, j - 1)) * 0.5f : (T(i, j + 1) - Tij);
+                else gTx = !inside(i, j - 1) ? (Tij - T(i, j - 1)) : 0.f;
+                if (!inside(i + 1, j)) gTy = !inside(i - 1, j) ? (T(i + 1, j) - T(i - 1, j)) * 0.5f : (T(i + 1, j) - Tij);
+                else gTy = !inside(i - 1, j) ? (Tij - T(i - 1, j)) : 0.f;
+            }
+            float run = 0.f;  // lanes 0..9 of a group: the sequential accumulator they own
+            if (gl == kAcc - 1) run = 1.0e-20f;
+            for (int t0 = 0; t0 < ntap; t0 += kChunk) {
+                // phase 1: every lane evaluates its taps of this chunk
+                for (int tt = gl; tt < kChunk; tt += kGroup) {
+                    float term[kAcc];
+#pragma unroll
+                    for (int q = 0; q < kAcc; q++) term[q] = 0.f;
+                    const int tap = t0 + tt;
+                    if (act && tap < ntap) {
+                        const int k = i - range + tap / side, l = j - range + tap % side;
+                        if (k > 0 && l > 0 && k < er - 1 && l < ec - 1 && a.ord[k * ec + l] < o &&
+                            (l - j) * (l - j) + (k - i) * (k - i) <= range * range) {
+                            const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
+                            const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
+                            const float ry = (float)(i - k), rx = (float)(j - l);
+                            const float vl = rx * rx + ry * ry;
+                            const float dst = (float)(1. / (vl * sqrt((double)vl)));
+                            const float lev = (float)(1. / (1 + fabsf(a.t[k * ec + l] - Tij)));
+                            float dir = rx * gTx + ry * gTy;
+                            if (fabs(dir) <= 0.01) dir = 0.000001f;
+                            const float wgt = (float)fabs(dst * lev * dir);
+                            const bool r_in = a.ord[k * ec + l + 1] >= o, l_in = a.ord[k * ec + l - 1] >= o;
+                            const bool d_in = a.ord[(k + 1) * ec + l] >= o, u_in = a.ord[(k - 1) * ec + l] >= o;
+#pragma unroll
+                            for (int ch = 0; ch < 3; ch++) {
+                                float gIx, gIy;
+                                if (!r_in) gIx = !l_in ? (img(km, lp + 1, ch, o) - img(km, lm - 1, ch, o)) * 2.0f : (img(km, lp + 1, ch, o) - img(km, lm, ch, o));
+                                else gIx = !l_in ? (img(km, lp, ch, o) - img(km, lm - 1, ch, o)) : 0.f;
+                                if (!d_in) gIy = !u_in ? (img(kp + 1, lm, ch, o) - img(km - 1, lm, ch, o)) * 2.0f : (img(kp + 1, lm, ch, o) - img(km, lm, ch, o));
+                                else gIy = !u_in ? (img(kp, lm, ch, o) - img(km - 1, lm, ch, o)) : 0.f;
+                                term[ch] = wgt * img(km, lm, ch, o);
+                                term[3 + ch] = wgt * (gIx * rx);
+                                term[6 + ch] = wgt * (gIy * ry);
+                            }
+                            term[9] = wgt;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < kAcc; q++) terms[slot][tt][q] = term[q];
+                }
+                __syncthreads();
+                // phase 2: lane q of the group adds the chunk's terms of accumulator q in tap order
+                if (gl < kAcc) {
+                    const bool minus = gl >= 3 && gl < 9;  // Jx, Jy are accumulated with -=
+                    const int lim = min(kChunk, ntap - t0);
+                    for (int tt = 0; tt < lim; tt++) {
+                        float v = terms[slot][tt][gl];
+                        run = minus ? run - v : run + v;
+                    }
+                }
+                __syncthreads();
+            }
+            if (gl < kAcc) accs[slot][gl] = run;
+            __syncthreads();
+            // phase 3: one lane per channel finishes the pixel
+            if (act && gl < 3) {
+                const float Ia = accs[slot][gl], Jx = accs[slot][3 + gl], Jy = accs[slot][6 + gl], s = accs[slot][9];
+                const float sat = (float)((Ia / s + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
+                int iv = (int)rintf(sat);  // cvRound, then saturate
+                iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
+                a.out[(ptrdiff_t)(i - 1) * a.out_step + (size_t)(j - 1) * a.cn + gl] = (uint8_t)iv;
+            }
+        }
+        // all colours of this level are written (and visible: one workgroup, one CU) before the next level reads them
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+int inpaint_mask_device(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_rgba, ptrdiff_t row_bytes, int w, int h, int iters,
+                        uint8_t *d_mask, ptrdiff_t mask_step, uint8_t *d_tmp) {
+    dim3 block(256), grid(ofxcv_div_up(w, 256), h);
+    uint8_t *first = iters > 0 ? d_tmp : d_mask;
+    ptrdiff_t first_step = iters > 0 ? (ptrdiff_t)w : mask_step;
+    hipLaunchKernelGGL(rgba_to_mask_kernel, grid, block, 0, s, d_rgba, row_bytes, w, h, first, first_step);
+    OFXCV_LAUNCH_CHECK(ctx, "rgba_to_mask_kernel");
+    if (iters > 0) {
+        hipLaunchKernelGGL(dilate_rect_kernel, grid, block, 0, s, (const uint8_t *)d_tmp, (ptrdiff_t)w, w, h, iters, d_mask, mask_step);
+        OFXCV_LAUNCH_CHECK(ctx, "dilate_rect_kernel");
+    }
+    return OFXCV_OK;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+extern "C" {
+
+int ofxcv_inpaint_mask(ofxcv_ctx *ctx, const uint8_t *d_rgba, ptrdiff_t row_bytes, int width, int height, int dilate_iters,
+                       uint8_t *d_mask, ptrdiff_t mask_step, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_rgba || !d_mask || width <= 0 || height <= 0 || dilate_iters < 0 || mask_step < width || (((uintptr_t)d_rgba | (uintptr_t)row_bytes) & 3))
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_mask: bad argument");
+    int rc = ofxcv_reserve(ctx, ctx->ip_tmp, (size_t)width * height);
+    if (rc) return rc;
+    return inpaint_mask_device(ctx, ofxcv_stream(ctx, stream), d_rgba, row_bytes, width, height, dilate_iters, d_mask, mask_step,
+                               (uint8_t *)ctx->ip_tmp.ptr);
+}
+
+int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels, const uint8_t *d_mask,
+                        ptrdiff_t mask_step, int width, int height, double radius, uint8_t *d_dst, ptrdiff_t dst_step,
+                        float *d_t_map, int *d_order_map, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!d_src || !d_mask || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || d_src == d_dst)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_telea: bad argument");
+    hipStream_t s = ofxcv_stream(ctx, stream);
+    int range = ofxcv_cv_round(radius);
+    range = std::min(std::max(range, 1), 100);
+    const int w = width, h = height, ec = w + 2, er = h + 2;
+    const size_t en = (size_t)ec * er;
+
+    // dst = src (cvCopy(input_img, output_img)); the mask comes back to the host for the front march
+    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, dst_step, d_src, src_step, (size_t)w * channels, h, hipMemcpyDeviceToDevice, s));
+    std::vector<uint8_t> mask((size_t)w * h);
+    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(mask.data(), w, d_mask, mask_step, w, h, hipMemcpyDeviceToHost, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+
+    March m;
+    march_front(mask.data(), w, h, range, m);
+    build_levels(m);
+    const int n = (int)m.pix.size(), nlev = (int)m.lvl_off.size() - 1;
+
+    if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, m.t.data(), en * sizeof(float), hipMemcpyHostToDevice, s));
+    if (d_order_map) {
+        std::vector<int> order((size_t)w * h);
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int o = m.ord[(i + 1) * ec + j + 1];
+                order[(size_t)i * w + j] = o == kNeverFilled ? 0 : o;
+            }
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_order_map, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `order` is a local
+    }
+    if (n > 0) {
+        const size_t off_t = 0, off_ord = align_up(off_t + en * 4, 256), off_pix = align_up(off_ord + en * 4, 256),
+                     off_po = align_up(off_pix + (size_t)n * 4, 256), off_lo = align_up(off_po + (size_t)n * 4, 256),
+                     total = align_up(off_lo + (size_t)(nlev + 1) * 4, 256);
+        int rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
+        if (rc) return rc;
+        char *dp = (char *)ctx->ip_maps.ptr;
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_t, m.t.data(), en * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_ord, m.ord.data(), en * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.lvl_off.data(), (size_t)(nlev + 1) * 4, hipMemcpyHostToDevice, s));
+        FillArgs fa;
+        fa.t = (const float *)(dp + off_t);
+        fa.ord = (const int *)(dp + off_ord);
+        fa.src = d_src;
+        fa.out = d_dst;
+        fa.src_step = src_step;
+        fa.out_step = dst_step;
+        fa.cn = channels;
+        fa.w = w;
+        fa.h = h;
+        fa.range = range;
+        fa.lvl_pix = (const int *)(dp + off_pix);
+        fa.lvl_ord = (const int *)(dp + off_po);
+        fa.lvl_off = (const int *)(dp + off_lo);
+        fa.nlev = nlev;
+        hipLaunchKernelGGL(telea_fill_kernel, dim3(1), dim3(kFillThreads), 0, s, fa);
+        OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host vectors above must outlive the copies
+    }
+    return OFXCV_OK;
+}
+
+int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t src_row_bytes, int width, int height, double radius,
+                              double dilation, uint8_t *h_dst, ptrdiff_t dst_row_bytes, uint8_t *h_mask_out) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!h_src || !h_dst || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_render_host: bad argument");
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->compute;
+    const int w = width, h = height;
+    const size_t row = (size_t)w * 4, img = align_up(row * h, 256), msk = align_up((size_t)w * h, 256);
+    int rc = ofxcv_reserve(ctx, ctx->ip_img, 2 * img + msk);
+    if (rc) return rc;
+    uint8_t *d_src = (uint8_t *)ctx->ip_img.ptr, *d_dst = d_src + img, *d_mask = d_dst + img;
+    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_src, row, h_src, src_row_bytes, row, h, hipMemcpyHostToDevice, s));
+    rc = ofxcv_inpaint_mask(ctx, d_src, (ptrdiff_t)row, w, h, dilation > 0 ? (int)dilation : 0, d_mask, w, s);
+    if (rc) return rc;
+    rc = ofxcv_inpaint_telea(ctx, d_src, (ptrdiff_t)row, 4, d_mask, w, w, h, radius, d_dst, (ptrdiff_t)row, nullptr, nullptr, s);
+    if (rc) return rc;
+    // write-back of inpaint.cpp:320-358 for noise == 0: RGB copied, alpha forced to 255 (the caller applies the
+    // libc rand() noise of :336-347 itself when the noise parameter is non-zero, using h_mask_out)
+    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, dst_row_bytes, d_dst, row, row, h, hipMemcpyDeviceToHost, s));
+    if (h_mask_out) OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_mask_out, w, d_mask, w, w, h, hipMemcpyDeviceToHost, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int y = 0; y < h; y++) {
+        uint8_t *d = h_dst + (ptrdiff_t)y * dst_row_bytes;
+        for (int x = 0; x < w; x++) d[x * 4 + 3] = 255;
+    }
+    return OFXCV_OK;
+}
+
+}  // extern "C"

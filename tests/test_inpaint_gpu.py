@@ -1,0 +1,93 @@
+"""Parity of the inpaint path (C ABI) against the CPU oracle: masks, distance map and fill-order index map
+bit-exact (north_star), colours bit-exact too (same IEEE operation order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _frame(w, h, seed=1234, holes=12):
+    from openfx_opencv_amd import synth
+    return synth.inpaint_frame(w, h, seed=seed, n_holes=holes)
+
+
+@pytest.mark.parametrize("w,h,iters", [(64, 48, 0), (160, 120, 1), (333, 257, 2), (640, 480, 1)])
+def test_mask_bit_exact(oracle, gpu_ctx, w, h, iters):
+    fr = _frame(w, h)
+    fr[5, 7, :3] = (1, 0, 0)     # integer luma 0 -> hole
+    fr[5, 9, :3] = (0, 1, 0)     # (9617 + 8192) >> 14 = 1 -> not a hole
+    ref = oracle.inpaint_mask(fr, iters)
+    got = gpu_ctx.inpaint_mask(_dev(fr), iters).cpu().numpy()
+    assert np.array_equal(ref, got)
+    if iters == 0:
+        assert got[5, 7] == 255 and got[5, 9] == 0
+
+
+@pytest.mark.parametrize("w,h,radius,cn", [(64, 48, 3, 3), (160, 120, 3, 4), (200, 150, 5, 3), (97, 83, 1, 4)])
+def test_telea_maps_and_colours(oracle, gpu_ctx, w, h, radius, cn):
+    fr = _frame(w, h, holes=6)
+    mask = oracle.inpaint_mask(fr, 1)
+    rgb = np.ascontiguousarray(fr[..., :3])
+    ref, t_ref, f_ref, ord_ref = oracle.inpaint_telea(rgb, mask, radius, maps=True)
+    src = rgb if cn == 3 else fr
+    dst, t, order = gpu_ctx.inpaint_telea(_dev(src), _dev(mask), radius, maps=True)
+    assert np.array_equal(order.cpu().numpy(), ord_ref)                       # fill-order index map
+    assert np.array_equal(t.cpu().numpy(), t_ref)                            # distance map incl. negated ring
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[..., :3], ref), "colours differ at %d pixels" % (got[..., :3] != ref).any(axis=2).sum()
+    if cn == 4:
+        assert np.array_equal(got[..., 3], fr[..., 3])
+    # only hole pixels change
+    assert np.array_equal(got[..., :3][mask == 0], rgb[mask == 0])
+
+
+def test_telea_edge_cases(oracle, gpu_ctx):
+    h, w = 40, 56
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(1, 255, size=(h, w, 3), dtype=np.uint8)
+    # empty mask: identity
+    m0 = np.zeros((h, w), np.uint8)
+    assert np.array_equal(gpu_ctx.inpaint_telea(_dev(rgb), _dev(m0)).cpu().numpy(), rgb)
+    # holes touching every image border, a one-pixel hole, and a symmetric square (FIFO tie order)
+    m = np.zeros((h, w), np.uint8)
+    m[0:6, 0:9] = 255
+    m[h - 5:h, w - 7:w] = 255
+    m[20, 30] = 255
+    m[10:20, 40:50] = 255
+    ref, t_ref, _, ord_ref = oracle.inpaint_telea(rgb, m, 3, maps=True)
+    dst, t, order = gpu_ctx.inpaint_telea(_dev(rgb), _dev(m), 3, maps=True)
+    assert np.array_equal(order.cpu().numpy(), ord_ref) and np.array_equal(t.cpu().numpy(), t_ref)
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    # first image row / column are never marched (padded index <= 1): they keep their input colour
+    assert ord_ref[0, 0:9].max() == 0 and ord_ref[0:6, 0].max() == 0
+    # everything masked: nothing to march from, output == input
+    mall = np.full((h, w), 255, np.uint8)
+    assert np.array_equal(gpu_ctx.inpaint_telea(_dev(rgb), _dev(mall)).cpu().numpy(), oracle.inpaint_telea(rgb, mall))
+
+
+def test_render_host_640x480(oracle, gpu_ctx):
+    """BASELINE config 1/2 generator at 640x480: whole render() body, host image in, host image out."""
+    fr = _frame(640, 480)
+    ref = oracle.inpaint_render(fr, 3.0, 1.0)
+    got, mask = gpu_ctx.inpaint_render_host(fr, 3.0, 1.0, want_mask=True)
+    assert np.array_equal(mask, oracle.inpaint_mask(fr, 1))
+    assert np.array_equal(got, ref)
+    assert (got[..., 3] == 255).all()
+
+
+def test_render_host_1080p_properties(oracle, gpu_ctx):
+    """BASELINE config 2 size: compared with the oracle in full (0.3 s of CPU) + idempotence on a hole-free frame."""
+    fr = _frame(1920, 1080)
+    got = gpu_ctx.inpaint_render_host(fr, 3.0, 1.0)
+    assert np.array_equal(got, oracle.inpaint_render(fr, 3.0, 1.0))
+    clean = fr.copy()
+    clean[..., :3] = np.maximum(clean[..., :3], 1)
+    clean[(clean[..., :3] == 0).all(axis=2)] = (9, 9, 9, 255)
+    again = gpu_ctx.inpaint_render_host(got, 3.0, 1.0)
+    hole_left = oracle.inpaint_mask(got, 1) > 0
+    assert np.array_equal(again[~hole_left], got[~hole_left])
