@@ -13,12 +13,15 @@
 //     hole pixels (a few % of the frame) and runs on the host thread that owns the context.
 //   * The colour fill (>90 % of the arithmetic: a (2r+1)^2 weighted window per pixel and channel) runs on
 //     the GPU.  A pixel may only be computed after every earlier-filled pixel inside its window; pixels
-//     are grouped into dependency levels and one persistent 1024-thread workgroup walks the levels with a
-//     barrier in between.  Inside a pixel the window taps are evaluated in parallel by a 16-lane group and
-//     then accumulated strictly in the reference's row-major order (float addition is not associative and
-//     the result is rounded twice, so the order matters for bit-exact colours).
+//     are grouped into dependency levels, holes that cannot influence each other form independent
+//     components, and one persistent workgroup per component walks its levels with a barrier in between.
+//     One wavefront fills one pixel: it stages the (2r+3)^2 neighbourhood (distance, fill order, colours as
+//     the sequential algorithm would see them at that moment) in LDS, evaluates the window taps one per
+//     lane, and then accumulates them strictly in the reference's row-major order (float addition is not
+//     associative and the result is rounded twice, so the order matters for bit-exact colours).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <queue>
@@ -133,7 +136,8 @@ struct March {
     std::vector<int> level;    // dependency level (>= 1) of the k-th filled pixel
     std::vector<int> lvl_pix;  // pixels (padded linear index) sorted by (level, order)
     std::vector<int> lvl_ord;  // their order numbers
-    std::vector<int> lvl_off;  // CSR offsets per level
+    std::vector<int> lvl_off;  // CSR offsets per (component, level) segment
+    std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
 };
 
 // cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
@@ -217,13 +221,14 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
 }
 
 // level(p) = 1 + max level of the pixels filled before p within Chebyshev distance range+2 (every pixel whose
-// colour p can read: window range, +1 for the image-gradient taps, +1 for the row/column-1 sample quirk)
+// colour p can read: window range, +1 for the image-gradient taps, +1 for the row/column-1 sample quirk).
+// Pixels further apart than 2*(range+2) never influence each other: connected groups of occupied coarse
+// cells are independent components, each walked by its own workgroup.
 void build_levels(March &m) {
     const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
     const int n = (int)m.pix.size();
     m.level.assign(n, 1);
     std::vector<int> lvl_map((size_t)ec * er, 0);
-    int nlev = 0;
     const bool windowed = (long)(2 * R + 1) * (2 * R + 1) * n <= 400000000L;
     for (int k = 0; k < n; k++) {
         const int p = m.pix[k], i = p / ec, j = p % ec;
@@ -238,108 +243,202 @@ void build_levels(March &m) {
         }
         m.level[k] = lv + 1;
         lvl_map[p] = lv + 1;
-        nlev = std::max(nlev, lv + 1);
     }
-    m.lvl_off.assign(nlev + 1, 0);
-    for (int k = 0; k < n; k++) m.lvl_off[m.level[k]]++;
-    for (int l = 1; l <= nlev; l++) m.lvl_off[l] += m.lvl_off[l - 1];
+    // components: cells of 2R+1 pixels; two hole pixels closer than 2R+1 lie in the same or in 8-adjacent cells
+    const int cs = 2 * R + 1, gw = (ec + cs - 1) / cs, gh = (er + cs - 1) / cs;
+    std::vector<int> cell((size_t)gw * gh, -1);
+    for (int k = 0; k < n; k++) cell[(size_t)(m.pix[k] / ec / cs) * gw + (m.pix[k] % ec) / cs] = -2;  // occupied
+    int ncomp = 0;
+    std::vector<int> stack;
+    if (!windowed) {  // sequential order: a single component
+        for (int &c : cell)
+            if (c == -2) c = 0;
+        ncomp = n > 0 ? 1 : 0;
+    } else {
+        for (int c0 = 0; c0 < gw * gh; c0++) {
+            if (cell[c0] != -2) continue;
+            cell[c0] = ncomp;
+            stack.assign(1, c0);
+            while (!stack.empty()) {
+                int c = stack.back();
+                stack.pop_back();
+                int cy = c / gw, cx = c % gw;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        int yy = cy + dy, xx = cx + dx;
+                        if (yy < 0 || xx < 0 || yy >= gh || xx >= gw || cell[yy * gw + xx] != -2) continue;
+                        cell[yy * gw + xx] = ncomp;
+                        stack.push_back(yy * gw + xx);
+                    }
+            }
+            ncomp++;
+        }
+    }
+    // sort pixels by (component, level, order) and build the two-level CSR
+    std::vector<int> comp(n), idx(n);
+    for (int k = 0; k < n; k++) {
+        comp[k] = cell[(size_t)(m.pix[k] / ec / cs) * gw + (m.pix[k] % ec) / cs];
+        idx[k] = k;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return comp[a] != comp[b] ? comp[a] < comp[b] : m.level[a] < m.level[b]; });
     m.lvl_pix.resize(n);
     m.lvl_ord.resize(n);
-    std::vector<int> cur(m.lvl_off.begin(), m.lvl_off.end() - 1);
-    for (int k = 0; k < n; k++) {
-        int at = cur[m.level[k] - 1]++;
-        m.lvl_pix[at] = m.pix[k];
-        m.lvl_ord[at] = k + 1;
+    m.lvl_off.clear();
+    m.comp_off.assign(1, 0);
+    for (int q = 0; q < n; q++) {
+        const int k = idx[q];
+        m.lvl_pix[q] = m.pix[k];
+        m.lvl_ord[q] = k + 1;
+        const bool new_comp = q == 0 || comp[k] != comp[idx[q - 1]];
+        if (new_comp && q > 0) m.comp_off.push_back((int)m.lvl_off.size());
+        if (new_comp || m.level[k] != m.level[idx[q - 1]]) m.lvl_off.push_back(q);
     }
+    m.lvl_off.push_back(n);
+    m.comp_off.push_back((int)m.lvl_off.size() - 1);
+    if (n == 0) m.comp_off.assign(1, 0);
 }
 
 // ------------------------------------------------------------------ I4 colour fill (device)
 
-constexpr int kGroup = 16;                       // lanes cooperating on one pixel
-constexpr int kFillThreads = 1024;               // one persistent workgroup
-constexpr int kSlots = kFillThreads / kGroup;    // pixels in flight per round
-constexpr int kAcc = 10;                         // Ia[3], Jx[3], Jy[3], s
-constexpr int kChunk = 32;                       // window taps staged per pass (64 slots x 32 taps x 11 floats = 88 KiB of LDS)
+constexpr int kFillThreads = 1024;             // 16 wavefronts: 16 pixels of a level in flight per workgroup
+constexpr int kFillWaves = kFillThreads / 64;
+constexpr int kAcc = 10;                       // Ia[3], Jx[3], Jy[3], s
+constexpr int kMaxLdsRange = 5;                // (2r+3)^2 <= 169 neighbourhood entries staged in LDS
+constexpr int kWinMax = (2 * kMaxLdsRange + 3) * (2 * kMaxLdsRange + 3);
 
+// The fill works on 4-byte pixels (R | G<<8 | B<<16 | X<<24), w*h dwords: one aligned load / store per pixel.
 struct FillArgs {
-    const float *t;        // padded distance map
-    const int *ord;        // padded order map
-    const uint8_t *src;    // original image, `cn` bytes per pixel
-    uint8_t *out;          // image being filled (initialised to src)
-    ptrdiff_t src_step, out_step;
-    int cn;                // 3 or 4 bytes per pixel
+    const float *t;         // padded distance map
+    const int *ord;         // padded order map
+    const uint32_t *src;    // original image
+    uint32_t *out;          // image being filled (initialised to src)
     int w, h, range;
-    const int *lvl_pix, *lvl_ord, *lvl_off;
-    int nlev;
+    const int *lvl_pix, *lvl_ord, *lvl_off, *comp_off;
 };
 
-__global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
-    __shared__ float terms[kSlots][kChunk][kAcc + 1];  // +1: odd stride, no bank conflicts on the column walks
-    __shared__ float accs[kSlots][kAcc];
-    const int ec = a.w + 2, er = a.h + 2, range = a.range;
-    const int side = 2 * range + 1, ntap = side * side;
-    const int slot = threadIdx.x / kGroup, gl = threadIdx.x % kGroup;
+__device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between lanes of ONE wavefront
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
-    // colour of image pixel (r,c) as the sequential algorithm sees it when pixel number `o` is being filled
-    auto img = [&](int r, int c, int ch, int o) -> float {
-        int q = a.ord[(r + 1) * ec + c + 1];
-        if (q != 0 && q < o)  // filled earlier: read past the L1 (written by another wave of this workgroup)
-            return (float)*(const volatile uint8_t *)(a.out + (ptrdiff_t)r * a.out_step + (size_t)c * a.cn + ch);
-        return (float)a.src[(ptrdiff_t)r * a.src_step + (size_t)c * a.cn + ch];
+template <int CN>
+__global__ __launch_bounds__(256) void pack_rgbx_kernel(const uint8_t *__restrict__ src, ptrdiff_t step, int w, int h,
+                                                        uint32_t *__restrict__ a, uint32_t *__restrict__ b) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t *p = src + (ptrdiff_t)y * step + (size_t)x * CN;
+    uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (CN == 4 ? (uint32_t)p[3] << 24 : 0u);
+    a[(size_t)y * w + x] = v;
+    b[(size_t)y * w + x] = v;
+}
+template <int CN>
+__global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__restrict__ src, int w, int h, uint8_t *__restrict__ dst,
+                                                          ptrdiff_t step) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    uint32_t v = src[(size_t)y * w + x];
+    uint8_t *p = dst + (ptrdiff_t)y * step + (size_t)x * CN;
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    if (CN == 4) p[3] = (uint8_t)(v >> 24);
+}
+
+// LDSWIN: the (2r+3)^2 neighbourhood of the pixel is staged in LDS (range <= kMaxLdsRange); otherwise every
+// access goes to global memory (any range up to 100).
+template <bool LDSWIN>
+__global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
+    __shared__ float s_terms[kFillWaves][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
+    __shared__ float s_acc[kFillWaves][kAcc];
+    __shared__ int s_word[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
+    __shared__ float s_wt[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
+    __shared__ uint32_t s_wrgb[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
+    const int ec = a.w + 2, er = a.h + 2, range = a.range;
+    const int side = 2 * range + 1, ntap = side * side, ws = side + 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg_beg = a.comp_off[blockIdx.x], seg_end = a.comp_off[blockIdx.x + 1];
+
+    // colour of padded pixel (r,c) as the sequential algorithm sees it while pixel number `o` is filled: the
+    // filled value if it was filled earlier (agent-scope load: written by another wave, must not come from a
+    // stale L1 line), the original otherwise.  Both loads are issued; `q` only selects.
+    auto resolve = [&](int r, int c, int q, int o) -> uint32_t {
+        const size_t at = (size_t)(r - 1) * a.w + (c - 1);
+        const uint32_t orig = a.src[at];
+        const uint32_t cur = __hip_atomic_load(a.out + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (q != 0 && q < o) ? cur : orig;
     };
 
-    for (int lv = 0; lv < a.nlev; lv++) {
-        const int beg = a.lvl_off[lv], end = a.lvl_off[lv + 1];
-        for (int base = beg; base < end; base += kSlots) {
-            const int id = base + slot;
-            const bool act = id < end;
-            int i = 0, j = 0, o = 0;
-            float Tij = 0, gTx = 0, gTy = 0;
-            if (act) {
-                const int p = a.lvl_pix[id];
-                o = a.lvl_ord[id];
-                i = p / ec;
-                j = p - i * ec;
-                auto inside = [&](int r, int c) { return a.ord[r * ec + c] >= o; };  // INSIDE at the time of `o`
-                auto T = [&](int r, int c) { return a.t[r * ec + c]; };
-                Tij = T(i, j);
-                if (!inside(i, j + 1)) gTx = !inside(i, j - 1) ? (T(i, j + 1) - T(i, j - 1)) * 0.5f : (T(i, j + 1) - Tij);
-                else gTx = !inside(i, j - 1) ? (Tij - T(i, j - 1)) : 0.f;
-                if (!inside(i + 1, j)) gTy = !inside(i - 1, j) ? (T(i + 1, j) - T(i - 1, j)) * 0.5f : (T(i + 1, j) - Tij);
-                else gTy = !inside(i - 1, j) ? (Tij - T(i - 1, j)) : 0.f;
-            }
-            float run = 0.f;  // lanes 0..9 of a group: the sequential accumulator they own
-            if (gl == kAcc - 1) run = 1.0e-20f;
-            for (int t0 = 0; t0 < ntap; t0 += kChunk) {
-                // phase 1: every lane evaluates its taps of this chunk
-                for (int tt = gl; tt < kChunk; tt += kGroup) {
+    int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
+    for (int seg = seg_beg; seg < seg_end; seg++) {
+        const int end = a.lvl_off[seg + 1];
+        for (int base = beg; base < end; base += kFillWaves) {
+            const int id = base + wave;
+            if (id < end) {  // wave-uniform
+                const int p = a.lvl_pix[id], o = a.lvl_ord[id];
+                const int i = p / ec, j = p - i * ec;
+                const int wi0 = i - range - 1, wj0 = j - range - 1;  // padded coordinates of the staged window's corner
+                if (LDSWIN) {
+                    for (int e = lane; e < ws * ws; e += 64) {
+                        const int r = wi0 + e / ws, c = wj0 + e % ws;
+                        int q = 0;
+                        float tv = 0.f;
+                        uint32_t rgb = 0;
+                        if (r >= 0 && c >= 0 && r < er && c < ec) {
+                            q = a.ord[r * ec + c];
+                            tv = a.t[r * ec + c];
+                            if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) rgb = resolve(r, c, q, o);
+                        }
+                        s_word[wave][e] = q;
+                        s_wt[wave][e] = tv;
+                        s_wrgb[wave][e] = rgb;
+                    }
+                    wave_lds_sync();
+                }
+                auto ORD = [&](int r, int c) -> int { return LDSWIN ? s_word[wave][(r - wi0) * ws + (c - wj0)] : a.ord[r * ec + c]; };
+                auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
+                // image pixel (ir,ic) [image coordinates], channel ch
+                auto IMG = [&](int ir, int ic, int ch) -> float {
+                    uint32_t v = LDSWIN ? s_wrgb[wave][(ir + 1 - wi0) * ws + (ic + 1 - wj0)] : resolve(ir + 1, ic + 1, a.ord[(ir + 1) * ec + ic + 1], o);
+                    return (float)((v >> (8 * ch)) & 255u);
+                };
+                const float Tij = TT(i, j);
+                float gTx, gTy;
+                {
+                    const bool r_in = ORD(i, j + 1) >= o, l_in = ORD(i, j - 1) >= o, d_in = ORD(i + 1, j) >= o, u_in = ORD(i - 1, j) >= o;
+                    if (!r_in) gTx = !l_in ? (TT(i, j + 1) - TT(i, j - 1)) * 0.5f : (TT(i, j + 1) - Tij);
+                    else gTx = !l_in ? (Tij - TT(i, j - 1)) : 0.f;
+                    if (!d_in) gTy = !u_in ? (TT(i + 1, j) - TT(i - 1, j)) * 0.5f : (TT(i + 1, j) - Tij);
+                    else gTy = !u_in ? (Tij - TT(i - 1, j)) : 0.f;
+                }
+                float run = lane == kAcc - 1 ? 1.0e-20f : 0.f;  // lanes 0..9: the sequential accumulator they own
+                for (int t0 = 0; t0 < ntap; t0 += 64) {
+                    // phase 1: one window tap per lane
                     float term[kAcc];
 #pragma unroll
                     for (int q = 0; q < kAcc; q++) term[q] = 0.f;
-                    const int tap = t0 + tt;
-                    if (act && tap < ntap) {
+                    const int tap = t0 + lane;
+                    if (tap < ntap) {
                         const int k = i - range + tap / side, l = j - range + tap % side;
-                        if (k > 0 && l > 0 && k < er - 1 && l < ec - 1 && a.ord[k * ec + l] < o &&
-                            (l - j) * (l - j) + (k - i) * (k - i) <= range * range) {
+                        if (k > 0 && l > 0 && k < er - 1 && l < ec - 1 && (l - j) * (l - j) + (k - i) * (k - i) <= range * range && ORD(k, l) < o) {
                             const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
                             const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
                             const float ry = (float)(i - k), rx = (float)(j - l);
                             const float vl = rx * rx + ry * ry;
                             const float dst = (float)(1. / (vl * sqrt((double)vl)));
-                            const float lev = (float)(1. / (1 + fabsf(a.t[k * ec + l] - Tij)));
+                            const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
                             float dir = rx * gTx + ry * gTy;
                             if (fabs(dir) <= 0.01) dir = 0.000001f;
                             const float wgt = (float)fabs(dst * lev * dir);
-                            const bool r_in = a.ord[k * ec + l + 1] >= o, l_in = a.ord[k * ec + l - 1] >= o;
-                            const bool d_in = a.ord[(k + 1) * ec + l] >= o, u_in = a.ord[(k - 1) * ec + l] >= o;
+                            const bool r_in = ORD(k, l + 1) >= o, l_in = ORD(k, l - 1) >= o;
+                            const bool d_in = ORD(k + 1, l) >= o, u_in = ORD(k - 1, l) >= o;
 #pragma unroll
                             for (int ch = 0; ch < 3; ch++) {
                                 float gIx, gIy;
-                                if (!r_in) gIx = !l_in ? (img(km, lp + 1, ch, o) - img(km, lm - 1, ch, o)) * 2.0f : (img(km, lp + 1, ch, o) - img(km, lm, ch, o));
-                                else gIx = !l_in ? (img(km, lp, ch, o) - img(km, lm - 1, ch, o)) : 0.f;
-                                if (!d_in) gIy = !u_in ? (img(kp + 1, lm, ch, o) - img(km - 1, lm, ch, o)) * 2.0f : (img(kp + 1, lm, ch, o) - img(km, lm, ch, o));
-                                else gIy = !u_in ? (img(kp, lm, ch, o) - img(km - 1, lm, ch, o)) : 0.f;
-                                term[ch] = wgt * img(km, lm, ch, o);
+                                if (!r_in) gIx = !l_in ? (IMG(km, lp + 1, ch) - IMG(km, lm - 1, ch)) * 2.0f : (IMG(km, lp + 1, ch) - IMG(km, lm, ch));
+                                else gIx = !l_in ? (IMG(km, lp, ch) - IMG(km, lm - 1, ch)) : 0.f;
+                                if (!d_in) gIy = !u_in ? (IMG(kp + 1, lm, ch) - IMG(km - 1, lm, ch)) * 2.0f : (IMG(kp + 1, lm, ch) - IMG(km, lm, ch));
+                                else gIy = !u_in ? (IMG(kp, lm, ch) - IMG(km - 1, lm, ch)) : 0.f;
+                                term[ch] = wgt * IMG(km, lm, ch);
                                 term[3 + ch] = wgt * (gIx * rx);
                                 term[6 + ch] = wgt * (gIy * ry);
                             }
@@ -347,32 +446,47 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < kAcc; q++) terms[slot][tt][q] = term[q];
-                }
-                __syncthreads();
-                // phase 2: lane q of the group adds the chunk's terms of accumulator q in tap order
-                if (gl < kAcc) {
-                    const bool minus = gl >= 3 && gl < 9;  // Jx, Jy are accumulated with -=
-                    const int lim = min(kChunk, ntap - t0);
-                    for (int tt = 0; tt < lim; tt++) {
-                        float v = terms[slot][tt][gl];
-                        run = minus ? run - v : run + v;
+                    for (int q = 0; q < kAcc; q++) s_terms[wave][lane][q] = term[q];
+                    wave_lds_sync();
+                    // phase 2: lane q adds this chunk's terms of accumulator q in tap (row-major) order
+                    if (lane < kAcc) {
+                        const bool minus = lane >= 3 && lane < 9;  // Jx, Jy are accumulated with -=
+                        const int lim = min(64, ntap - t0);
+                        int tt = 0;
+                        for (; tt + 8 <= lim; tt += 8) {  // batches of independent LDS reads, then the ordered adds
+                            float v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) v[u] = s_terms[wave][tt + u][lane];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) run = minus ? run - v[u] : run + v[u];
+                        }
+                        for (; tt < lim; tt++) {
+                            float v = s_terms[wave][tt][lane];
+                            run = minus ? run - v : run + v;
+                        }
                     }
+                    wave_lds_sync();
                 }
-                __syncthreads();
-            }
-            if (gl < kAcc) accs[slot][gl] = run;
-            __syncthreads();
-            // phase 3: one lane per channel finishes the pixel
-            if (act && gl < 3) {
-                const float Ia = accs[slot][gl], Jx = accs[slot][3 + gl], Jy = accs[slot][6 + gl], s = accs[slot][9];
-                const float sat = (float)((Ia / s + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
-                int iv = (int)rintf(sat);  // cvRound, then saturate
-                iv = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
-                a.out[(ptrdiff_t)(i - 1) * a.out_step + (size_t)(j - 1) * a.cn + gl] = (uint8_t)iv;
+                if (lane < kAcc) s_acc[wave][lane] = run;
+                wave_lds_sync();
+                // phase 3: lane ch finishes channel ch, lane 0 stores the pixel as one dword
+                uint32_t byte = 0;
+                if (lane < 3) {
+                    const float Ia = s_acc[wave][lane], Jx = s_acc[wave][3 + lane], Jy = s_acc[wave][6 + lane], sw = s_acc[wave][9];
+                    const float sat = (float)((Ia / sw + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
+                    int iv = (int)rintf(sat);  // cvRound, then saturate
+                    byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+                }
+                const uint32_t g = __shfl(byte, 1), bl = __shfl(byte, 2);
+                if (lane == 0) {
+                    const size_t at = (size_t)(i - 1) * a.w + (j - 1);
+                    a.out[at] = byte | (g << 8) | (bl << 16) | (a.src[at] & 0xff000000u);
+                }
             }
         }
-        // all colours of this level are written (and visible: one workgroup, one CU) before the next level reads them
+        beg = end;
+        // every colour of this level is written (one workgroup = one CU; later reads are agent-scope loads that
+        // bypass the L1) before the next level of this component starts
         __threadfence_block();
         __syncthreads();
     }
@@ -428,9 +542,14 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
 
     March m;
+    const bool dbg = getenv("OFXCV_DEBUG_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     march_front(mask.data(), w, h, range, m);
+    double t1 = now();
     build_levels(m);
-    const int n = (int)m.pix.size(), nlev = (int)m.lvl_off.size() - 1;
+    double t2 = now();
+    const int n = (int)m.pix.size();
 
     if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, m.t.data(), en * sizeof(float), hipMemcpyHostToDevice, s));
     if (d_order_map) {
@@ -444,9 +563,10 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `order` is a local
     }
     if (n > 0) {
+        const int nseg = (int)m.lvl_off.size(), ncomp = (int)m.comp_off.size() - 1;
         const size_t off_t = 0, off_ord = align_up(off_t + en * 4, 256), off_pix = align_up(off_ord + en * 4, 256),
                      off_po = align_up(off_pix + (size_t)n * 4, 256), off_lo = align_up(off_po + (size_t)n * 4, 256),
-                     total = align_up(off_lo + (size_t)(nlev + 1) * 4, 256);
+                     off_co = align_up(off_lo + (size_t)nseg * 4, 256), total = align_up(off_co + (size_t)(ncomp + 1) * 4, 256);
         int rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
         if (rc) return rc;
         char *dp = (char *)ctx->ip_maps.ptr;
@@ -454,25 +574,43 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_ord, m.ord.data(), en * 4, hipMemcpyHostToDevice, s));
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.lvl_off.data(), (size_t)(nlev + 1) * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.lvl_off.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_co, m.comp_off.data(), (size_t)(ncomp + 1) * 4, hipMemcpyHostToDevice, s));
+        rc = ofxcv_reserve(ctx, ctx->ip_work, 2 * (size_t)w * h * 4);
+        if (rc) return rc;
+        uint32_t *work_src = (uint32_t *)ctx->ip_work.ptr, *work_out = work_src + (size_t)w * h;
+        dim3 pblock(256), pgrid(ofxcv_div_up(w, 256), h);
+        if (channels == 4)
+            hipLaunchKernelGGL(pack_rgbx_kernel<4>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+        else
+            hipLaunchKernelGGL(pack_rgbx_kernel<3>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+        OFXCV_LAUNCH_CHECK(ctx, "pack_rgbx_kernel");
         FillArgs fa;
         fa.t = (const float *)(dp + off_t);
         fa.ord = (const int *)(dp + off_ord);
-        fa.src = d_src;
-        fa.out = d_dst;
-        fa.src_step = src_step;
-        fa.out_step = dst_step;
-        fa.cn = channels;
+        fa.src = work_src;
+        fa.out = work_out;
         fa.w = w;
         fa.h = h;
         fa.range = range;
         fa.lvl_pix = (const int *)(dp + off_pix);
         fa.lvl_ord = (const int *)(dp + off_po);
         fa.lvl_off = (const int *)(dp + off_lo);
-        fa.nlev = nlev;
-        hipLaunchKernelGGL(telea_fill_kernel, dim3(1), dim3(kFillThreads), 0, s, fa);
+        fa.comp_off = (const int *)(dp + off_co);
+        if (range <= kMaxLdsRange)
+            hipLaunchKernelGGL(telea_fill_kernel<true>, dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+        else
+            hipLaunchKernelGGL(telea_fill_kernel<false>, dim3(ncomp), dim3(kFillThreads), 0, s, fa);
         OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
+        if (channels == 4)
+            hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);
+        else
+            hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);
+        OFXCV_LAUNCH_CHECK(ctx, "unpack_rgbx_kernel");
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host vectors above must outlive the copies
+        if (dbg)
+            fprintf(stderr, "inpaint %dx%d: march %.2f ms, levels %.2f ms (%d px, %d segments, %d components), upload+fill %.2f ms\n", w, h,
+                    t1 - t0, t2 - t1, n, nseg, ncomp, now() - t2);
     }
     return OFXCV_OK;
 }

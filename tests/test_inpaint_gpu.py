@@ -91,3 +91,15 @@ def test_render_host_1080p_properties(oracle, gpu_ctx):
     again = gpu_ctx.inpaint_render_host(got, 3.0, 1.0)
     hole_left = oracle.inpaint_mask(got, 1) > 0
     assert np.array_equal(again[~hole_left], got[~hole_left])
+
+
+def test_telea_large_radius_global_path(oracle, gpu_ctx):
+    """radius > 5 takes the kernel variant without the LDS-staged neighbourhood (two tap chunks at radius 6)."""
+    fr = _frame(120, 90, holes=4)
+    mask = oracle.inpaint_mask(fr, 1)
+    rgb = np.ascontiguousarray(fr[..., :3])
+    for radius in (6, 9):
+        ref, t_ref, _, ord_ref = oracle.inpaint_telea(rgb, mask, radius, maps=True)
+        dst, t, order = gpu_ctx.inpaint_telea(_dev(rgb), _dev(mask), radius, maps=True)
+        assert np.array_equal(order.cpu().numpy(), ord_ref) and np.array_equal(t.cpu().numpy(), t_ref)
+        assert np.array_equal(dst.cpu().numpy(), ref)
