@@ -117,6 +117,21 @@ int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
                               double radius, double dilation, uint8_t *h_dst, ptrdiff_t dst_row_bytes,
                               uint8_t *h_mask_out);
 
+/* ---- S: segmentation by pyramid mean-shift filtering ---------------------------------------
+ * stands in for cvPyrSegmentation(image0, image1, storage, &comp, level, thr1, thr2) at
+ * opencv2fx/segment/segment.cpp:296-302.  That routine (OpenCV <= 2.4 legacy module) is not in the reference
+ * tree; BASELINE.json defines the workload as mean-shift, so the semantics are those of
+ * cv::pyrMeanShiftFiltering(src, dst, sp, sr, max_level, TermCriteria(ITER+EPS, max_iter, eps)).
+ * d_src/d_dst: 8-bit images with `channels` (3 or 4) bytes per pixel; a 4th channel is copied through. */
+int ofxcv_pyr_mean_shift_filtering(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels,
+                                   int width, int height, double sp, double sr, int max_level, int max_iter,
+                                   double eps, uint8_t *d_dst, ptrdiff_t dst_step, void *stream);
+
+/* whole segment render() body for host-resident OFX images (segment.cpp:266-323): RGBA in -> RGBA out,
+ * alpha forced to 255 (:315-319); max_iter 5, eps 1 */
+int ofxcv_segment_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t src_row_bytes, int width, int height,
+                              double sp, double sr, int max_level, uint8_t *h_dst, ptrdiff_t dst_row_bytes);
+
 /* ---- stage-level entry points (the internal stages of calcOpticalFlowFarneback) ------------
  * Exposed so each stage can be parity-checked on its own against the oracle's restatement of
  * modules/video/src/optflowgf.cpp.  Planes: a 5-channel field is stored as 5 consecutive planes

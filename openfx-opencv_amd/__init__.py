@@ -58,6 +58,7 @@ EXPORTS = [
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
     "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint_render_host",
+    "ofxcv_pyr_mean_shift_filtering", "ofxcv_segment_render_host",
 ]
 
 
@@ -216,6 +217,26 @@ class Context:
                                                     C.c_int(h), C.c_double(radius), C.c_double(dilation), C.c_void_p(dst.ctypes.data),
                                                     C.c_ssize_t(w * 4), C.c_void_p(mask.ctypes.data) if want_mask else None))
         return (dst, mask) if want_mask else dst
+
+    # ---- segment ----
+    def pyr_mean_shift_filtering(self, src, sp=10.0, sr=20.0, max_level=2, max_iter=5, eps=1.0):
+        """Mirror of cv::pyrMeanShiftFiltering; src HxWx{3,4} uint8 CUDA tensor."""
+        import torch
+        h, w, cn = src.shape
+        dst = torch.empty_like(src)
+        self._call(lib().ofxcv_pyr_mean_shift_filtering, _ptr(src), C.c_ssize_t(src.stride(0)), C.c_int(cn), C.c_int(w), C.c_int(h),
+                   C.c_double(sp), C.c_double(sr), C.c_int(max_level), C.c_int(max_iter), C.c_double(eps), _ptr(dst), C.c_ssize_t(dst.stride(0)))
+        return dst
+
+    def segment_render_host(self, rgba, sp=10.0, sr=20.0, max_level=2):
+        import numpy as np
+        h, w, _ = rgba.shape
+        assert rgba.dtype == np.uint8 and rgba.strides[1] == 4
+        dst = np.empty((h, w, 4), np.uint8)
+        self._check(lib().ofxcv_segment_render_host(self._h, C.c_void_p(rgba.ctypes.data), C.c_ssize_t(rgba.strides[0]), C.c_int(w), C.c_int(h),
+                                                    C.c_double(sp), C.c_double(sr), C.c_int(max_level), C.c_void_p(dst.ctypes.data),
+                                                    C.c_ssize_t(w * 4)))
+        return dst
 
     # ---- stage-level (parity tests) ----
     def farneback_pyr_image(self, img, lw, lh, sigma, ksize):

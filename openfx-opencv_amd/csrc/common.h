@@ -40,6 +40,7 @@ struct ofxcv_ctx {
     DevBuf ip_maps;  // distance / order maps and the per-level pixel lists of the colour fill
     DevBuf ip_img;   // device copies of the host images (render_host)
     DevBuf ip_work;  // 4-byte-per-pixel working images of the colour fill
+    DevBuf seg_work; // mean-shift pyramid (source + result per level) and mask
 
     // measurement hook: event pairs around the dominant kernel (see ofxcv_profile_enable)
     bool prof_on = false;

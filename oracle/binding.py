@@ -199,3 +199,17 @@ def inpaint_render(rgba, radius=3.0, dilation=1.0):
     fn.restype = C.c_int
     fn(_p(rgba), C.c_ssize_t(w * 4), C.c_int(w), C.c_int(h), C.c_double(radius), C.c_double(dilation), _p(dst), C.c_ssize_t(w * 4))
     return dst
+
+
+# ---- segment (mean-shift) ---------------------------------------------------------------------------------
+def pyr_mean_shift(rgb, sp=10.0, sr=20.0, max_level=2, max_iter=5, eps=1.0):
+    """cv::pyrMeanShiftFiltering(rgb, dst, sp, sr, max_level, TermCriteria(ITER+EPS, max_iter, eps))."""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    h, w, _ = rgb.shape
+    out = np.empty_like(rgb)
+    fn = lib().orc_pyr_mean_shift
+    fn.restype = C.c_int
+    rc = fn(_p(rgb), C.c_int(w), C.c_int(h), C.c_double(sp), C.c_double(sr), C.c_int(max_level), C.c_int(max_iter), C.c_double(eps), _p(out))
+    if rc != 0:
+        raise ValueError("orc_pyr_mean_shift rc=%d" % rc)
+    return out
