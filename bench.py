@@ -68,7 +68,7 @@ def main():
     import numpy as np
     import torch
     import openfx_opencv_amd as ofxcv
-    from openfx_opencv_amd import synth
+    from openfx_opencv_amd import sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,7 +88,7 @@ def main():
     ctxs = [ofxcv.Context(local_rank) for _ in range(P)]
     bufs = []
     for i, c in enumerate(ctxs):
-        a, b = synth.flow_pair(W, H, seed=1234 + rank * P + i)
+        a, b = synth.flow_pair(W, H, seed=sharding.seed_for_pair(sharding.pairs_for_rank(world * P, rank, world)[i]))
         with torch.cuda.stream(c.stream):
             bufs.append(dict(a=torch.from_numpy(a).cuda(), b=torch.from_numpy(b).cuda(),
                              ga=torch.empty((H, W), dtype=torch.uint8, device="cuda"),
@@ -134,13 +134,10 @@ def main():
         c.profile_enable(False)
     g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.reduce_elapsed_max(elapsed, dist, "cuda")        # MAX over ranks
+    pairs = sharding.reduce_count_sum(args.steps * P, dist, "cuda")       # units all ranks processed
 
     if rank == 0:
-        pairs = args.steps * world * P
         value = pairs / elapsed
         avg_s = kern_ms / 1e3 / max(1, kern_n)
         achieved = ITER_BYTES_PER_PX * W * H / avg_s / 1e9
