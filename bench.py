@@ -39,6 +39,16 @@ def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
     return total
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh,
+    summary in profiles/): the counters need their own profiler runs, so the figure is measured offline and read here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(ga, gb, budget_s=12.0):
     """Time the CPU oracle (kind 'port': restatement of OpenCV's single-threaded CPU Farneback) on rank 0."""
     from oracle import binding as oracle
@@ -61,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
+    ap.add_argument("--pairs", type=int, default=2, help="independent frame pairs per step, each on its own context/stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -119,19 +129,17 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    # roofline leg: same process, same inputs, same concurrency -- HIP event pairs around every launch of the
-    # dominant kernel (level-0 fused iteration), recorded on the stream the kernel is launched on
-    for c in ctxs:
-        c.profile_enable(True)
-    for _ in range(max(2, min(6, args.steps))):
-        step()
+    # roofline leg: same process, same inputs -- HIP event pairs around every launch of the dominant kernel (the fused
+    # iteration at pyramid level 0), recorded on the stream the kernel is launched on.  One pair at a time here: with
+    # two streams in flight an event pair would also time the wait for the other stream's kernel.
+    c0, t0b = ctxs[0], bufs[0]
+    c0.profile_enable(True)
+    with torch.cuda.stream(c0.stream):
+        for _ in range(max(3, min(10, args.steps))):
+            c0.calc_optical_flow_farneback(t0b["ga"], t0b["gb"], t0b["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
     torch.cuda.synchronize()
-    kern_ms, kern_n = 0.0, 0
-    for c in ctxs:
-        ms, n = c.profile_read()
-        kern_ms += ms
-        kern_n += n
-        c.profile_enable(False)
+    kern_ms, kern_n = c0.profile_read()
+    c0.profile_enable(False)
     g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
 
     elapsed = sharding.reduce_elapsed_max(elapsed, dist, "cuda")        # MAX over ranks
@@ -160,7 +168,7 @@ def main():
                        "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
                        "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "iterate3_kernel<true,1> (fused blur+solve+update, pyramid level 0, %dx%d)" % (W, H),
+                         "traffic": pmc_traffic(), "kernel": "iterate3_kernel<true, 2> (fused blur+solve+update, pyramid level 0, %dx%d)" % (W, H),
                          "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n},
             "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
                            "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},
