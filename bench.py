@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs", type=int, default=2, help="independent frame pairs per step, each on its own context/stream")
+    ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -18,12 +18,32 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+// cache of captured Farneback launch sequences (see ofxcv_calc_optical_flow_farneback)
+#define OFXCV_FB_MAX_LEVELS 10
+constexpr int kFbGraphSlots = 4;
+struct FbGraphKey {
+    const void *prev, *next, *flow;
+    size_t prev_step, next_step, flow_step;
+    int width, height, levels, winsize, iterations, poly_n;
+    double pyr_scale, poly_sigma;
+    const void *planes, *tmp, *cflow;  // scratch addresses baked into the graph
+};
+struct FbGraph {
+    FbGraphKey key;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct ofxcv_ctx {
     int device = 0;
     hipStream_t compute = nullptr;  // default stream for kernels when the caller passes NULL
     hipStream_t copy = nullptr;     // H2D / D2H staging stream of the host-buffer entry points
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};
     hipEvent_t ev_done = nullptr;
+    hipStream_t prep = nullptr;     // Farneback: pyramid + polynomial expansion of all levels, ahead of the level walk
+    hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {};
+    FbGraph fb_graphs[kFbGraphSlots];
+    unsigned fb_graph_next = 0;
+    bool fb_no_graph = false;
     char err[512] = {0};
 
     // F0: 65536-entry 8.8 fixed-point sRGB table (openfx-supportext ofxsLut.h semantics)
@@ -77,6 +97,8 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
 }
 
 static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
+
+int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation stream and the per-level events
 
 // measurement hook helpers (context.hip)
 int ofxcv_prof_mark(ofxcv_ctx *ctx, hipStream_t s);  // records one event of a start/stop pair

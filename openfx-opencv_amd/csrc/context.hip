@@ -48,6 +48,15 @@ int ofxcv_prof_drain(ofxcv_ctx *ctx) {
     return OFXCV_OK;
 }
 
+int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
+    if (ctx->prep) return OFXCV_OK;
+    OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
+    OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->fb_no_graph = getenv("OFXCV_NO_GRAPH") != nullptr;
+    return OFXCV_OK;
+}
+
 int ofxcv_cv_round(double v) { return (int)std::lrint(v); }
 
 extern "C" {
@@ -102,6 +111,12 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (FbGraph &g : ctx->fb_graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (hipEvent_t e : ctx->ev_level)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
     DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);

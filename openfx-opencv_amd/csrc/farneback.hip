@@ -29,6 +29,7 @@ namespace {
 
 constexpr int kMaxGaussTaps = 255;
 constexpr int kMaxPolyN = 15;
+constexpr int kMaxLevels = OFXCV_FB_MAX_LEVELS;
 
 struct GaussTaps {
     int ksize;
@@ -746,6 +747,87 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
     return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, d_flow, flow_step, width, height, winsize, update != 0);
 }
 
+// The launch sequence of one call.  The pyramid images and polynomial expansions of ALL levels depend only on the
+// two input frames, so they run on the context's preparation stream (coarsest level first) while the main stream
+// walks the levels; an event per level hands R0/R1 over.  The coarse levels cannot fill the chip (a 240x135 level
+// is 127 workgroups on 256 CUs), so their iterations overlap with the preparation of the finer levels.
+static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, const uint8_t *const img[2], const size_t step[2],
+                             float *d_flow, size_t flow_step, int width, int height, double pyr_scale, int levels, int winsize,
+                             int iterations, int poly_n, double poly_sigma, bool profile) {
+    int rc;
+    // scratch carving (sizes were reserved by the caller)
+    const size_t field0 = 5 * (size_t)plane_pitch(width) * height;
+    float *base = (float *)ctx->fb_planes.ptr;
+    float *Mbuf[2] = {base, base + field0};
+    float *Rk = base + 2 * field0;  // R0/R1 of level levels, levels-1, ..., 0 packed one after the other
+    float *T1 = (float *)ctx->fb_tmp.ptr;
+    float *I = T1 + (size_t)(width + 4) * height;
+    size_t coarse = 0;
+    if (levels > 0) {
+        int lw, lh, ks;
+        double sg;
+        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
+        coarse = (size_t)lw * lh * 2;
+    }
+    float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + coarse};
+
+    // fork: the preparation stream starts once the inputs are ready on the main stream
+    OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
+    float *R[kMaxLevels + 1][2];
+    {
+        float *p = Rk;
+        for (int k = levels; k >= 0; k--) {
+            int w, h, ksz;
+            double sigma;
+            level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+            const size_t field = 5 * (size_t)plane_pitch(w) * h;
+            for (int i = 0; i < 2; i++) {
+                R[k][i] = p;
+                p += field;
+                rc = launch_pyr_image(ctx, sp, img[i], step[i], width, height, w, h, sigma, ksz, T1, I);
+                if (rc) return rc;
+                rc = launch_polyexp(ctx, sp, I, w, h, R[k][i], poly_n, poly_sigma);
+                if (rc) return rc;
+            }
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[k], sp));
+        }
+    }
+    const float *prev_flow = nullptr;
+    size_t prev_flow_step = 0;
+    int pw = 0, ph = 0;
+    for (int k = levels; k >= 0; k--) {
+        int w, h, ksz;
+        double sigma;
+        level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+        OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
+        const int pitch = plane_pitch(w);
+        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+        if (!prev_flow)
+            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, w, h, pitch, Mbuf[0]);
+        else
+            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, w, h, pitch, Mbuf[0]);
+        OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
+        float *out_flow = k == 0 ? d_flow : cflow[k & 1];
+        size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
+        int cur = 0;
+        for (int i = 0; i < iterations; i++) {
+            bool update = i < iterations - 1;
+            const bool prof = profile && k == 0 && update;
+            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+            rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+            if (rc) return rc;
+            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+            cur ^= 1;
+        }
+        prev_flow = out_flow;
+        prev_flow_step = out_step;
+        pw = w;
+        ph = h;
+    }
+    return OFXCV_OK;
+}
+
 int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step, const uint8_t *d_next,
                                       size_t next_step, float *d_flow, size_t flow_step, int width, int height, double pyr_scale,
                                       int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
@@ -756,68 +838,80 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     if (flags != 0) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: only flags == 0 (box window, no initial flow)");
     if (!(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || iterations < 1 || winsize < 1 || !(winsize & 1))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad parameter");
+    if ((size_t)plane_pitch(width) * height >= (1u << 28))
+        return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: frames above 2^28 pixels exceed the 32-bit buffer offsets");
     hipStream_t s = ofxcv_stream(ctx, stream);
     const uint8_t *img[2] = {d_prev, d_next};
     const size_t step[2] = {prev_step, next_step};
     levels = num_levels(width, height, pyr_scale, levels);
+    if (levels > kMaxLevels) levels = kMaxLevels;
 
-    const size_t field = 5 * (size_t)plane_pitch(width) * height;  // floats per 5-plane field at level 0
-    int rc = ofxcv_reserve(ctx, ctx->fb_planes, sizeof(float) * 4 * field);
-    if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(width + 4) * height + (size_t)width * height));
-    if (rc) return rc;
-    size_t coarse = 0;
-    if (levels > 0) {
-        int lw, lh, ks;
-        double sg;
-        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
-        coarse = (size_t)lw * lh * 2;
-        rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 2 * coarse);
-        if (rc) return rc;
-    }
-    float *R[2] = {(float *)ctx->fb_planes.ptr, (float *)ctx->fb_planes.ptr + field};
-    float *Mbuf[2] = {(float *)ctx->fb_planes.ptr + 2 * field, (float *)ctx->fb_planes.ptr + 3 * field};
-    float *T1 = (float *)ctx->fb_tmp.ptr;
-    float *I = T1 + (size_t)(width + 4) * height;
-    float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + coarse};
-
-    const float *prev_flow = nullptr;
-    size_t prev_flow_step = 0;
-    int pw = 0, ph = 0;
+    // scratch: M ping + M pong (level-0 size) + R0/R1 of every level, blur rows + one pyramid image, two coarse flows
+    size_t rtotal = 0;
     for (int k = levels; k >= 0; k--) {
         int w, h, ksz;
         double sigma;
         level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
-        for (int i = 0; i < 2; i++) {
-            rc = launch_pyr_image(ctx, s, img[i], step[i], width, height, w, h, sigma, ksz, T1, I);
-            if (rc) return rc;
-            rc = launch_polyexp(ctx, s, I, w, h, R[i], poly_n, poly_sigma);
-            if (rc) return rc;
-        }
-        const int pitch = plane_pitch(w);
-        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-        if (!prev_flow)
-            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[0], R[1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, w, h, pitch, Mbuf[0]);
-        else
-            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[0], R[1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, w, h, pitch, Mbuf[0]);
-        OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
-        float *out_flow = k == 0 ? d_flow : cflow[k & 1];
-        size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
-        int cur = 0;
-        for (int i = 0; i < iterations; i++) {
-            bool update = i < iterations - 1;
-            const bool prof = ctx->prof_on && k == 0 && update;
-            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            rc = launch_iteration(ctx, s, R[0], R[1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
-            if (rc) return rc;
-            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            cur ^= 1;
-        }
-        prev_flow = out_flow;
-        prev_flow_step = out_step;
-        pw = w;
-        ph = h;
+        if (ksz > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksz, kMaxGaussTaps);
+        rtotal += 2 * 5 * (size_t)plane_pitch(w) * h;
     }
+    if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
+    const size_t field0 = 5 * (size_t)plane_pitch(width) * height;
+    int rc = ofxcv_reserve(ctx, ctx->fb_planes, sizeof(float) * (2 * field0 + rtotal));
+    if (rc) return rc;
+    rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(width + 4) * height + (size_t)width * height));
+    if (rc) return rc;
+    if (levels > 0) {
+        int lw, lh, ks;
+        double sg;
+        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
+        rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 4 * (size_t)lw * lh);
+        if (rc) return rc;
+    }
+    rc = ofxcv_farneback_streams(ctx);
+    if (rc) return rc;
+    static const bool one_stream = getenv("OFXCV_ONE_STREAM") != nullptr;
+    hipStream_t sp = one_stream ? s : ctx->prep;
+
+    // hipGraph replay: the ~90 launches of a call are captured once per (pointers, geometry, parameters) and replayed
+    // with one hipGraphLaunch (host launch cost 0.55 ms -> ~0.02 ms per call).  The measurement hook needs its event
+    // pairs between launches and therefore uses the eager path.
+    const bool use_graph = !ctx->prof_on && !ctx->fb_no_graph;
+    if (!use_graph)
+        return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations,
+                                 poly_n, poly_sigma, ctx->prof_on);
+    FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, pyr_scale,
+                      poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr};
+    FbGraph *g = nullptr;
+    for (FbGraph &c : ctx->fb_graphs)
+        if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
+    if (!g) {
+        FbGraph *slot = &ctx->fb_graphs[ctx->fb_graph_next++ % kFbGraphSlots];
+        if (slot->exec) {
+            (void)hipGraphExecDestroy(slot->exec);
+            slot->exec = nullptr;
+        }
+        hipGraph_t graph = nullptr;
+        OFXCV_HIP_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
+                               poly_sigma, false);
+        hipError_t e = hipStreamEndCapture(s, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return ofxcv_fail(ctx, OFXCV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            slot->exec = nullptr;
+            return ofxcv_fail(ctx, OFXCV_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        }
+        std::memset(&slot->key, 0, sizeof(slot->key));
+        slot->key = key;
+        g = slot;
+    }
+    OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
     return OFXCV_OK;
 }
 
