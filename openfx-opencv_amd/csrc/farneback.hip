@@ -222,6 +222,105 @@ __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__re
     I[(size_t)dy * lw + dx] = out;
 }
 
+// Fused pyramid image: one workgroup produces an OW x OH tile of the level image.  The 8-bit source footprint
+// of the tile (plus the blur radius, borders reflected on load) is staged in LDS once; the row filter is evaluated
+// at the two source columns every output column interpolates between, into a second LDS buffer; the column filter
+// and the two lerps finish the tile.  Same operations and order as the two-kernel form above (which remains the
+// fall-back when a footprint does not fit in LDS), without the round trip of the half-blurred rows through HBM.
+struct PyrTile {
+    int ow, oh;    // output tile
+    int cw, rh;    // staged source footprint (columns, rows), upper bounds
+};
+
+__global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh, int ntap,
+                                                        GaussTaps gk, PyrTile t, float *__restrict__ I) {
+    extern __shared__ unsigned char pyr_lds[];
+    const int ksize = gk.ksize, r = ksize >> 1;
+    const int ncolh = t.ow * ntap;                 // row-filtered columns kept per source row
+    int *s_xs = (int *)pyr_lds;                    // [ow] source column of each output column
+    float *s_xa = (float *)(s_xs + t.ow);          // [ow][2] horizontal lerp weights
+    int *s_ys = (int *)(s_xa + 2 * t.ow);          // [oh]
+    float *s_yb = (float *)(s_ys + t.oh);          // [oh][2]
+    float *s_h = s_yb + 2 * t.oh;                  // [rh][ncolh] row-filtered samples
+    unsigned char *s_src = (unsigned char *)(s_h + (size_t)t.rh * ncolh);  // [rh][cw] source bytes
+    const int ox0 = blockIdx.x * t.ow, oy0 = blockIdx.y * t.oh;
+    const int tid = threadIdx.x;
+
+    if (tid < t.ow) {
+        int d = min(ox0 + tid, lw - 1), sx;
+        float a0 = 1.f, a1 = 0.f;
+        if (ntap == 1) sx = d;
+        else lerp_coef(d, W, lw, sx, a0, a1);
+        s_xs[tid] = sx;
+        s_xa[2 * tid] = a0;
+        s_xa[2 * tid + 1] = a1;
+    } else if (tid >= 64 && tid < 64 + t.oh) {  // (ow <= 64)
+        int q = tid - 64, d = min(oy0 + q, lh - 1), sy;
+        float b0 = 1.f, b1 = 0.f;
+        if (ntap == 1) sy = d;
+        else lerp_coef(d, H, lh, sy, b0, b1);
+        s_ys[q] = sy;
+        s_yb[2 * q] = b0;
+        s_yb[2 * q + 1] = b1;
+    }
+    __syncthreads();
+    const int c_lo = s_xs[0] - r, r_lo = s_ys[0] - r;
+    const int cw = min(s_xs[t.ow - 1] + (ntap - 1) + r - c_lo + 1, t.cw), rh = min(s_ys[t.oh - 1] + (ntap - 1) + r - r_lo + 1, t.rh);
+
+    for (int e = tid; e < rh * cw; e += 256) {
+        int ry = e / cw, rx = e - ry * cw;
+        s_src[ry * t.cw + rx] = img[(size_t)reflect101(r_lo + ry, H) * step + reflect101(c_lo + rx, W)];
+    }
+    __syncthreads();
+    // row filter at the needed columns (the second of a pair is clamped to W-1 like the unfused kernel)
+    for (int e = tid; e < rh * ncolh; e += 256) {
+        int ry = e / ncolh, j = e - ry * ncolh;
+        int sx = s_xs[ntap == 1 ? j : (j >> 1)];
+        if (ntap == 2) sx = min(sx + (j & 1), W - 1);
+        const unsigned char *S = s_src + ry * t.cw + (sx - c_lo);  // S[i] = source column sx + i (reflected)
+        float v;
+        if (ksize == 3) v = (float)S[0] * gk.k[1] + ((float)S[-1] + (float)S[1]) * gk.k[2];
+        else if (ksize == 5) v = (float)S[0] * gk.k[2] + ((float)S[-1] + (float)S[1]) * gk.k[3] + ((float)S[-2] + (float)S[2]) * gk.k[4];
+        else {
+            v = gk.k[0] * (float)S[-r];
+            for (int q = 1; q < ksize; q++) v += (float)S[q - r] * gk.k[q];
+        }
+        s_h[ry * ncolh + j] = v;
+    }
+    __syncthreads();
+    const float *kc = gk.k + r;
+    auto colf = [&](int j, int sy) -> float {  // column filter at source row sy, filtered column j
+        const float *C = s_h + (sy - r_lo) * ncolh + j;
+        if (ksize == 3) return (C[-ncolh] + C[ncolh]) * kc[1] + C[0] * kc[0];
+        float v = kc[0] * C[0];
+        for (int q = 1; q <= r; q++) v += kc[q] * (C[q * ncolh] + C[-q * ncolh]);
+        return v;
+    };
+    for (int e = tid; e < t.ow * t.oh; e += 256) {
+        int ty = e / t.ow, tx = e - ty * t.ow;
+        int dx = ox0 + tx, dy = oy0 + ty;
+        if (dx >= lw || dy >= lh) continue;
+        float out;
+        if (ntap == 1) {
+            out = colf(tx, s_ys[ty]);
+        } else {
+            const int sx = s_xs[tx], sy = s_ys[ty], sy1 = min(sy + 1, H - 1);
+            const float ax0 = s_xa[2 * tx], ax1 = s_xa[2 * tx + 1], b0 = s_yb[2 * ty], b1 = s_yb[2 * ty + 1];
+            float t00 = colf(2 * tx, sy), t10 = colf(2 * tx, sy1), r0, r1;
+            if (sx + 1 < W) {
+                float t01 = colf(2 * tx + 1, sy), t11 = colf(2 * tx + 1, sy1);
+                r0 = t00 * ax0 + t01 * ax1;
+                r1 = t10 * ax0 + t11 * ax1;
+            } else {
+                r0 = t00 * 1.f;
+                r1 = t10 * 1.f;
+            }
+            out = r0 * b0 + r1 * b1;
+        }
+        I[(size_t)dy * lw + dx] = out;
+    }
+}
+
 // ------------------------------------------------------------------ F3 polynomial expansion
 //
 // One 64x16 output tile per 256-thread block.  The tile of I plus an n-pixel halo is staged in
@@ -231,32 +330,35 @@ __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__re
 
 constexpr int kPeTW = 64, kPeTH = 16;
 
+// NT > 0: poly_n known at compile time (loops fully unrolled); NT == 0: run-time poly_n
+template <int NT>
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
                                                       int pitch, PolyCoef pc) {
     extern __shared__ float lds[];
-    const int n = pc.n;
+    const int n = NT > 0 ? NT : pc.n;
     const int cw = kPeTW + 2 * n;          // staged columns
     const int ldw = cw | 1;                // odd row stride: conflict-free column walks
     const int ih = kPeTH + 2 * n;          // staged rows
     float *sI = lds;                       // [ih][ldw]
     float *sV = lds + ih * ldw;            // [3][kPeTH][ldw]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lx = tid & 63, tq = tid >> 6;
     const int x0 = blockIdx.x * kPeTW, y0 = blockIdx.y * kPeTH;
 
-    for (int i = tid; i < ih * cw; i += 256) {
-        int ry = i / cw, rx = i - ry * cw;
-        int gy = clampi(y0 + ry - n, 0, h - 1), gx = clampi(x0 + rx - n, 0, w - 1);
-        sI[ry * ldw + rx] = I[(size_t)gy * w + gx];
+    // stage I (rows and columns clamped = replicated border); lanes < 2n also fetch the extra halo columns
+    const int gx0 = clampi(x0 + lx - n, 0, w - 1), gx1 = clampi(x0 + 64 + lx - n, 0, w - 1);
+    for (int ry = tq; ry < ih; ry += 4) {
+        const float *row = I + (size_t)clampi(y0 + ry - n, 0, h - 1) * w;
+        sI[ry * ldw + lx] = row[gx0];
+        if (lx < 2 * n) sI[ry * ldw + 64 + lx] = row[gx1];
     }
     __syncthreads();
 
-    const float *g = pc.g + n, *xg = pc.xg + n, *xxg = pc.xxg + n;
-    // vertical pass (float).  Row clamping must follow the *image* border, not the tile border:
-    // the staged rows were clamped on load, so plain offsets +-k already see replicated rows.
-    for (int i = tid; i < kPeTH * cw; i += 256) {
-        int ty = i / cw, cx = i - ty * cw;
+    const float *g = pc.g + pc.n, *xg = pc.xg + pc.n, *xxg = pc.xxg + pc.n;
+    // vertical pass (float): staged rows were clamped on load, so offsets +-k see replicated rows
+    auto vertical = [&](int ty, int cx) {
         const float *col = sI + (ty + n) * ldw + cx;
         float t0 = col[0] * g[0], t1 = 0.f, t2 = 0.f;
+#pragma unroll
         for (int k = 1; k <= n; k++) {
             float s0 = col[-k * ldw], s1 = col[k * ldw];
             float p = s0 + s1;
@@ -267,12 +369,15 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
         sV[(0 * kPeTH + ty) * ldw + cx] = t0;
         sV[(1 * kPeTH + ty) * ldw + cx] = t1;
         sV[(2 * kPeTH + ty) * ldw + cx] = t2;
+    };
+    for (int ty = tq; ty < kPeTH; ty += 4) {
+        vertical(ty, lx);
+        if (lx < 2 * n) vertical(ty, 64 + lx);
     }
     __syncthreads();
 
     const size_t plane = (size_t)pitch * h;
-    const int lx = tid & 63;
-    for (int ty = tid >> 6; ty < kPeTH; ty += 4) {
+    for (int ty = tq; ty < kPeTH; ty += 4) {
         int x = x0 + lx, y = y0 + ty;
         if (x >= w || y >= h) continue;
         const float *r0 = sV + (0 * kPeTH + ty) * ldw + lx + n;
@@ -280,6 +385,7 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
         const float *r2 = sV + (2 * kPeTH + ty) * ldw + lx + n;
         float g0 = g[0];
         double b1 = r0[0] * g0, b2 = 0, b3 = r1[0] * g0, b4 = 0, b5 = r2[0] * g0, b6 = 0;
+#pragma unroll
         for (int k = 1; k <= n; k++) {
             double tg = r0[k] + r0[-k];
             g0 = g[k];
@@ -606,6 +712,92 @@ __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__
     }
 }
 
+// Two iterations per launch (winSize 3).  M is the only state that is carried from one iteration to the next, and
+// an iteration reads it through a 3x3 window: a workgroup that stages its output tile plus a 2-pixel ring of M in
+// LDS can run iteration i on tile + 1 ring (keeping that intermediate M in LDS) and iteration i+1 on the tile.
+// HBM traffic per pixel for TWO iterations: M-in 20 B (x1.33 ring), R0 20 B (the second read is an L1/L2 hit),
+// R1 gather ~20-25 B (the second gather lands on the lines the first one brought in), M-out 20 B: ~90 B instead of
+// 160 B.  The price is the ring recomputation (18 % more solves and gathers) and 51 KiB of LDS per workgroup.
+// Every pixel evaluates exactly the operations of two single iterations in the same order, so results are
+// bit-identical to them.  Window positions outside the image hold the replicated border value, as in the
+// single-iteration kernels.
+constexpr int kFtW = 62, kFtH = 16, kFtThreads = 512;  // tile + 1 ring is 64 wide: one wavefront per ring row
+constexpr int kFtS0 = kFtW + 4;  // row stride of the staged M-in region (tile + 2 ring)
+constexpr int kFtS1 = kFtW + 2;  // row stride of the intermediate M region (tile + 1 ring)
+
+__device__ __forceinline__ void box_solve_lds(const float *__restrict__ sm, int stride, int plane_elems, int ly, int lx, double scale,
+                                              float &fxv, float &fyv) {
+    double acc[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *p = sm + c * plane_elems + (ly - 1) * stride + (lx - 1);
+        double h0 = ((double)p[0] + (double)p[1]) + (double)p[2];
+        double h1 = ((double)p[stride] + (double)p[stride + 1]) + (double)p[stride + 2];
+        double h2 = ((double)p[2 * stride] + (double)p[2 * stride + 1]) + (double)p[2 * stride + 2];
+        acc[c] = (h0 + h1) + h2;
+    }
+    double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+    double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+    fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+    fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+}
+
+__global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                                const float *__restrict__ Min, float *__restrict__ Mout, int w, int h,
+                                                                int pitch, double scale) {
+    __shared__ float s0[5 * (kFtH + 4) * kFtS0];  // M-in on tile + 2 ring
+    __shared__ float s1[5 * (kFtH + 2) * kFtS1];  // M after the first iteration on tile + 1 ring
+    const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4);
+    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, 5 * plane * sizeof(float));
+    constexpr int n0 = (kFtH + 4) * kFtS0, n1 = (kFtH + 2) * kFtS1;
+
+    // stage M-in: position (ry, rx) of the region holds M(clamp(y0 - 2 + ry), clamp(x0 - 2 + rx))
+    for (int e = threadIdx.x; e < n0; e += kFtThreads) {
+        const int ry = e / kFtS0, rx = e - ry * kFtS0;
+        const unsigned off = ((unsigned)clampi(y0 - 2 + ry, 0, h - 1) * (unsigned)pitch + (unsigned)clampi(x0 - 2 + rx, 0, w - 1)) * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) s0[c * n0 + e] = buf_ld(bM, off, c * pb);
+    }
+    __syncthreads();
+
+    // iteration A on tile + 1 ring: region position (ry, rx) <-> image pixel clamp(y0 - 1 + ry, x0 - 1 + rx)
+    for (int e = threadIdx.x; e < n1; e += kFtThreads) {
+        const int ry = e / kFtS1, rx = e - ry * kFtS1;
+        const int y = clampi(y0 - 1 + ry, 0, h - 1), x = clampi(x0 - 1 + rx, 0, w - 1);
+        float fxv, fyv;
+        box_solve_lds(s0, kFtS0, n0, y - (y0 - 2), x - (x0 - 2), scale, fxv, fyv);
+        float r0v[5];
+        const unsigned off = ((unsigned)y * (unsigned)pitch + (unsigned)x) * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) r0v[c] = buf_ld(bR0, off, c * pb);
+        Taps tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
+        M5 mm = update_matrices_finish(r0v, tp, x, y, w, h, fxv, fyv);
+#pragma unroll
+        for (int c = 0; c < 5; c++) s1[c * n1 + e] = mm.v[c];
+    }
+    __syncthreads();
+
+    // iteration B on the tile
+    for (int e = threadIdx.x; e < 64 * kFtH; e += kFtThreads) {  // one wavefront per tile row (62 of 64 lanes)
+        const int ty = e >> 6, tx = e & 63;
+        const int y = y0 + ty, x = x0 + tx;
+        if (tx >= kFtW || y >= h || x >= w) continue;
+        float fxv, fyv;
+        box_solve_lds(s1, kFtS1, n1, ty + 1, tx + 1, scale, fxv, fyv);
+        float r0v[5];
+        const unsigned off = ((unsigned)y * (unsigned)pitch + (unsigned)x) * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) r0v[c] = buf_ld(bR0, off, c * pb);
+        Taps tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
+        M5 mm = update_matrices_finish(r0v, tp, x, y, w, h, fxv, fyv);
+#pragma unroll
+        for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], off, c * pb);
+    }
+}
+
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -637,6 +829,28 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk);
     int ntap = (lw == W && lh == H) ? 1 : 2;
+    // fused tile kernel when the source footprint of a 32x8 (64x8 for small decimation) tile fits in LDS
+    static const bool no_fused = getenv("OFXCV_PYR_UNFUSED") != nullptr;
+    PyrTile t;
+    t.ow = (double)W / lw <= 2.01 ? 64 : 32;
+    t.oh = 8;
+    // coarse levels: smaller tiles until there are enough workgroups to spread over the 256 CUs
+    while ((long)ofxcv_div_up(lw, t.ow) * ofxcv_div_up(lh, t.oh) < 512 && (t.ow > 16 || t.oh > 2)) {
+        if (t.ow > 16 && t.ow >= 4 * t.oh) t.ow >>= 1;
+        else if (t.oh > 2) t.oh >>= 1;
+        else t.ow >>= 1;
+    }
+    const int r = ksize / 2;
+    t.cw = ((int)std::ceil((double)(t.ow - 1) * W / lw) + 2 * r + 4 + 3) & ~3;
+    t.rh = (int)std::ceil((double)(t.oh - 1) * H / lh) + 2 * r + 4;
+    const size_t lds = sizeof(int) * (t.ow + t.oh) + sizeof(float) * 2 * (t.ow + t.oh) + sizeof(float) * (size_t)t.rh * t.ow * ntap +
+                       (size_t)t.rh * t.cw;
+    if (!no_fused && lds <= 60 * 1024 && lw >= 2 && lh >= 2) {
+        hipLaunchKernelGGL(pyr_fused_kernel, dim3(ofxcv_div_up(lw, t.ow), ofxcv_div_up(lh, t.oh)), dim3(256), lds, s, d_img, step, W, H, lw, lh, ntap,
+                           gk, t, d_I);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_kernel");
+        return OFXCV_OK;
+    }
     int ncol = lw * ntap;
     hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, d_img, step, W, H, lw, ntap, gk, d_T1);
     OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
@@ -652,8 +866,10 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
     make_poly_coef(poly_n, poly_sigma, pc);
     int cw = kPeTW + 2 * poly_n, ldw = cw | 1, ih = kPeTH + 2 * poly_n;
     size_t lds = sizeof(float) * ((size_t)ih * ldw + 3 * kPeTH * ldw);
-    hipLaunchKernelGGL(polyexp_kernel, dim3(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH)), dim3(256), lds, s, d_I, w, h, d_R,
-                       plane_pitch(w), pc);
+    dim3 grid(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH));
+    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
+    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
+    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
     OFXCV_LAUNCH_CHECK(ctx, "polyexp_kernel");
     return OFXCV_OK;
 }
@@ -691,6 +907,14 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     else
         hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
     OFXCV_LAUNCH_CHECK(ctx, "blur_solve_update_kernel");
+    return OFXCV_OK;
+}
+
+// two fused iterations M -> M'' (winsize 3 only)
+int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h) {
+    hipLaunchKernelGGL(iterate3x2_kernel, dim3(ofxcv_div_up(w, kFtW), ofxcv_div_up(h, kFtH)), dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h,
+                       plane_pitch(w), 1. / 9.);
+    OFXCV_LAUNCH_CHECK(ctx, "iterate3x2_kernel");
     return OFXCV_OK;
 }
 
@@ -811,11 +1035,19 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         float *out_flow = k == 0 ? d_flow : cflow[k & 1];
         size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
         int cur = 0;
-        for (int i = 0; i < iterations; i++) {
-            bool update = i < iterations - 1;
-            const bool prof = profile && k == 0 && update;
+        static const bool no_fuse = getenv("OFXCV_NO_FUSE2") != nullptr;
+        const bool fuse = !no_fuse && winsize == 3;
+        for (int i = 0; i < iterations;) {
+            const bool prof = profile && k == 0 && i < iterations - 1;
             if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+            if (fuse && i + 2 <= iterations - 1) {  // two updating iterations in one launch
+                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h);
+                i += 2;
+            } else {
+                bool update = i < iterations - 1;
+                rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                i += 1;
+            }
             if (rc) return rc;
             if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             cur ^= 1;
