@@ -45,6 +45,13 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
 /* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL) */
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 
+/* context options:
+ *   "farneback.opencv_rounding" 0|1  evaluate the Farneback box window with OpenCV's own running sums (every row
+ *                                    difference rounded to f32 before it is accumulated in f64) -- a validation mode,
+ *                                    ~20x slower, that reproduces the reference's rounding noise sample for sample;
+ *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1). */
+int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
+
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
  * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of its dominant kernel --
  * the fused blur+solve+update iteration at pyramid level 0 -- with a hipEvent pair on the stream it

@@ -53,7 +53,7 @@ def lib():
 # every symbol include/ofxcv_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -117,6 +117,9 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ofxcv_ctx_synchronize(self._h, None))
+
+    def set_option(self, name, value):
+        self._check(lib().ofxcv_ctx_set_option(self._h, name.encode(), C.c_int(int(value))))
 
     def profile_enable(self, on=True):
         self._check(lib().ofxcv_profile_enable(self._h, C.c_int(1 if on else 0)))

@@ -26,7 +26,7 @@ struct FbGraphKey {
     size_t prev_step, next_step, flow_step;
     int width, height, levels, winsize, iterations, poly_n;
     double pyr_scale, poly_sigma;
-    const void *planes, *tmp, *cflow;  // scratch addresses baked into the graph
+    const void *planes, *tmp, *cflow, *vsum;  // scratch addresses baked into the graph
 };
 struct FbGraph {
     FbGraphKey key;
@@ -54,6 +54,8 @@ struct ofxcv_ctx {
     DevBuf fb_tmp;     // blurred half-resolution rows (pyramid) + pyramid image I
     DevBuf fb_flow;    // two ping-pong coarse flow fields
     DevBuf fb_coef;    // polyexp / blur coefficient tables
+    DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
+    bool fb_opencv_rounding = false;
 
     // inpaint scratch
     DevBuf ip_tmp;   // undilated mask

@@ -53,7 +53,7 @@ int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
     OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->fb_no_graph = getenv("OFXCV_NO_GRAPH") != nullptr;
+    if (getenv("OFXCV_NO_GRAPH")) ctx->fb_no_graph = true;
     return OFXCV_OK;
 }
 
@@ -117,7 +117,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_level)
         if (e) (void)hipEventDestroy(e);
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
@@ -135,6 +135,19 @@ const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "nu
 int ofxcv_ctx_device(const ofxcv_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute : nullptr; }
+
+int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return OFXCV_ERR_INVALID;
+    if (!std::strcmp(name, "farneback.opencv_rounding")) {
+        ctx->fb_opencv_rounding = value != 0;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.graph")) {
+        ctx->fb_no_graph = value == 0;
+        return OFXCV_OK;
+    }
+    return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "unknown option '%s'", name);
+}
 
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable) {
     if (!ctx) return OFXCV_ERR_INVALID;

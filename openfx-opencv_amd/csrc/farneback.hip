@@ -798,6 +798,57 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------ OpenCV-rounding mode of the box window
+//
+// FarnebackUpdateFlow_Blur keeps a running vertical sum per column and channel,
+//     vsum(y) = vsum(y-1) + (double)(float)(M[min(y+1,h-1)] - M[max(y-2,0)]),   vsum(-1) = (double)(float)(3 * M[0]),
+// i.e. every row difference is rounded to f32 before it is accumulated in f64.  That rounding noise is part of
+// OpenCV's result; at ill-conditioned pixels it is amplified past 1e-4.  The default kernels above sum each window
+// directly (no such noise).  With the context option "farneback.opencv_rounding" the iteration is evaluated the
+// reference's way instead: one thread per (column, channel) walks the rows sequentially -- the recurrence is a true
+// serial dependency -- and stores vsum(y) as f64 planes; a second kernel adds the three columns and does the solve
+// and the matrix update.  This is a validation mode (about 20x slower), used by the parity tests to show that the
+// GPU path matches the faithful oracle at every sample once the same rounding is applied.
+__global__ __launch_bounds__(256) void strict_colscan_kernel(const float *__restrict__ M, int w, int h, int pitch, double *__restrict__ V) {
+    const int x = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (x >= w) return;
+    const float *m = M + (size_t)c * pitch * h + x;
+    double *v = V + (size_t)c * pitch * h + x;
+    double acc = (double)(m[0] * 3.f);  // vsum[x] = srow0[x]*(m+2), a float product
+    for (int y = 0; y < h; y++) {
+        const float a = m[(size_t)min(y + 1, h - 1) * pitch], b = m[(size_t)max(y - 2, 0) * pitch];
+        acc += (double)(a - b);
+        v[(size_t)y * pitch] = acc;
+    }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restrict__ R0, const float *__restrict__ R1, const double *__restrict__ V,
+                                                           float *__restrict__ Mout, float *__restrict__ flow, size_t flow_step, int w, int h,
+                                                           int pitch, double scale) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)pitch * h;
+    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1);
+    double acc[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const double *row = V + c * plane + (size_t)y * pitch;
+        acc[c] = (row[xm] + row[x]) + row[xp];  // the reference's horizontal running sum, evaluated per pixel (f64 on f64)
+    }
+    double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+    double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+    float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+    float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
+    if (UPDATE) {
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        const size_t o = (size_t)y * pitch + x;
+#pragma unroll
+        for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
+    }
+}
+
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -878,6 +929,19 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
                      size_t flow_step, int w, int h, int winsize, bool update) {
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
+    if (ctx->fb_opencv_rounding && winsize == 3) {
+        const int pitch = plane_pitch(w);
+        double *V = (double *)ctx->fb_vsum.ptr;  // reserved by the caller
+        hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, Min, w, h, pitch, V);
+        OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
+        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+        if (update)
+            hipLaunchKernelGGL(strict_solve_kernel<true>, grid, block, 0, s, R0, R1, (const double *)V, Mout, flow, flow_step, w, h, pitch, scale);
+        else
+            hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, R0, R1, (const double *)V, Mout, flow, flow_step, w, h, pitch, scale);
+        OFXCV_LAUNCH_CHECK(ctx, "strict_solve_kernel");
+        return OFXCV_OK;
+    }
     if (winsize == 3) {
         // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
         const int cols = ofxcv_div_up(w, 64);
@@ -968,6 +1032,10 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
     if (!d_M_in || width <= 0 || height <= 0 || winsize < 1 || !(winsize & 1) || (d_flow && (flow_step & 7)) ||
         (update && (!d_R0 || !d_R1 || !d_M_out || d_M_out == d_M_in)) || (!update && !d_flow))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_flow_blur: bad argument");
+    if (ctx->fb_opencv_rounding) {
+        int rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * 5 * (size_t)plane_pitch(width) * height);
+        if (rc) return rc;
+    }
     return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, d_flow, flow_step, width, height, winsize, update != 0);
 }
 
@@ -1036,7 +1104,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
         int cur = 0;
         static const bool no_fuse = getenv("OFXCV_NO_FUSE2") != nullptr;
-        const bool fuse = !no_fuse && winsize == 3;
+        const bool fuse = !no_fuse && winsize == 3 && !ctx->fb_opencv_rounding;
         for (int i = 0; i < iterations;) {
             const bool prof = profile && k == 0 && i < iterations - 1;
             if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
@@ -1100,6 +1168,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 4 * (size_t)lw * lh);
         if (rc) return rc;
     }
+    if (ctx->fb_opencv_rounding) {
+        rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * field0);
+        if (rc) return rc;
+    }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;
     static const bool one_stream = getenv("OFXCV_ONE_STREAM") != nullptr;
@@ -1113,7 +1185,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations,
                                  poly_n, poly_sigma, ctx->prof_on);
     FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, pyr_scale,
-                      poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr};
+                      poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr, ctx->fb_opencv_rounding ? ctx->fb_vsum.ptr : nullptr};
     FbGraph *g = nullptr;
     for (FbGraph &c : ctx->fb_graphs)
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;

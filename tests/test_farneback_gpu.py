@@ -171,3 +171,43 @@ def test_gray_lut_and_scatter(oracle, ofxcv, gpu_ctx):
         ref = oracle.flow_to_rgba(flow, base.copy(), [(mu >> c) & 1 for c in range(4)], [(mv >> c) & 1 for c in range(4)], *rs)
         got = gpu_ctx.flow_to_rgba(_dev(flow), _dev(base), mu, mv, *rs).cpu().numpy()
         assert np.array_equal(ref, got)
+
+
+@pytest.fixture()
+def strict_ctx(ofxcv):
+    """a context in the OpenCV-rounding validation mode (the box window evaluated with the reference's running sums)"""
+    ctx = ofxcv.Context(0)
+    ctx.set_option("farneback.opencv_rounding", 1)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (333, 257), (640, 480)])
+def test_opencv_rounding_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx, w, h):
+    """With the reference's f32 rounding of the vertical running sums reproduced, EVERY sample is within the north_star
+    tolerance of the faithful oracle -- the outliers of the default path are that rounding noise and nothing else."""
+    ga, gb = _gray_pair(oracle, w, h)
+    got = strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    err = np.abs(ref - got)
+    assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "max err %g, outside %g" % (err.max(), (err > REL_TOL * np.maximum(1, np.abs(ref))).mean())
+
+
+def test_opencv_rounding_mode_single_step_and_1080p(oracle, ofxcv, strict_ctx):
+    rng = np.random.default_rng(13)
+    h, w = 119, 161
+    R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
+    M = oracle.update_matrices(R0, R1, rng.normal(0, 1, size=(h, w, 2)).astype(np.float32))
+    ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 3, True, oracle.BLUR_FAITHFUL)
+    flow, Mo = strict_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), ofxcv.hwc_to_planes(_dev(M)), w, 3, True)
+    err = np.abs(ref_flow - flow.cpu().numpy())
+    assert (err <= 1e-6 * np.maximum(1, np.abs(ref_flow))).all(), err.max()     # only the f64 order of the 3-column sum differs
+    # BASELINE config 3 size
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(1920, 1080)
+    ga, gb = oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
+    got = strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    err = np.abs(ref - got)
+    assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "max err %g" % err.max()
