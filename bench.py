@@ -24,8 +24,9 @@ if ROOT not in sys.path:
 W, H = 1920, 1080
 LEVELS, ITERS, POLY_N, POLY_SIGMA, WINSIZE, PYR_SCALE = 3, 15, 5, 1.1, 3, 0.5  # VectorGenerator.cpp:804-834, :391-395
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
-# fused iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
-ITER_BYTES_PER_PX = 80.0
+# one fused iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel; the dominant
+# kernel (iterate3x2_kernel) runs TWO iterations per launch, i.e. 160 algorithmic bytes per pixel per launch
+ITER_BYTES_PER_PX = 160.0
 
 
 def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
@@ -168,7 +169,7 @@ def main():
                        "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
                        "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(), "kernel": "iterate3_kernel<true, 2> (fused blur+solve+update, pyramid level 0, %dx%d)" % (W, H),
+                         "traffic": pmc_traffic(), "kernel": "iterate3x2_kernel (two fused blur+solve+update iterations per launch, pyramid level 0, %dx%d)" % (W, H),
                          "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n},
             "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
                            "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},

@@ -1106,9 +1106,10 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         static const bool no_fuse = getenv("OFXCV_NO_FUSE2") != nullptr;
         const bool fuse = !no_fuse && winsize == 3 && !ctx->fb_opencv_rounding;
         for (int i = 0; i < iterations;) {
-            const bool prof = profile && k == 0 && i < iterations - 1;
+            const bool pair = fuse && i + 2 <= iterations - 1;
+            const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
             if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            if (fuse && i + 2 <= iterations - 1) {  // two updating iterations in one launch
+            if (pair) {  // two updating iterations in one launch
                 rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h);
                 i += 2;
             } else {
