@@ -713,17 +713,20 @@ __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__
 }
 
 // Two iterations per launch (winSize 3).  M is the only state that is carried from one iteration to the next, and
-// an iteration reads it through a 3x3 window: a workgroup that stages its output tile plus a 2-pixel ring of M in
-// LDS can run iteration i on tile + 1 ring (keeping that intermediate M in LDS) and iteration i+1 on the tile.
-// HBM traffic per pixel for TWO iterations: M-in 20 B (x1.33 ring), R0 20 B (the second read is an L1/L2 hit),
-// R1 gather ~20-25 B (the second gather lands on the lines the first one brought in), M-out 20 B: ~90 B instead of
-// 160 B.  The price is the ring recomputation (18 % more solves and gathers) and 51 KiB of LDS per workgroup.
-// Every pixel evaluates exactly the operations of two single iterations in the same order, so results are
-// bit-identical to them.  Window positions outside the image hold the replicated border value, as in the
-// single-iteration kernels.
-constexpr int kFtW = 62, kFtH = 16, kFtThreads = 512;  // tile + 1 ring is 64 wide: one wavefront per ring row
-constexpr int kFtS0 = kFtW + 4;  // row stride of the staged M-in region (tile + 2 ring)
-constexpr int kFtS1 = kFtW + 2;  // row stride of the intermediate M region (tile + 1 ring)
+// an iteration reads it through a 3x3 window: a workgroup that stages its 62x14 output tile plus a 2-pixel ring of
+// M in LDS runs iteration i on tile + 1 ring (64x16: exactly one wavefront per ring row, that intermediate M stays
+// in LDS) and iteration i+1 on the tile.  The work is cut into two halves of 8 ring rows: first-iteration rows
+// 0..7, second-iteration rows that are complete by then, first-iteration rows 8..15, the remaining second-iteration
+// rows -- so the second gather of a pixel follows its first one within one phase (it finds R1's lines in the
+// cache instead of re-fetching them from HBM), and every wave meets "its" pixel row again, so R0 stays in
+// registers.  Algorithmic bytes per pixel for TWO iterations are 160; this kernel moves about
+// M-in 27 + R0 23 + R1 ~30 + M-out 20.  Every pixel evaluates exactly the operations of two single iterations in
+// the same order, so results are bit-identical to them.  Window positions outside the image hold the replicated
+// border value, as in the single-iteration kernels.
+constexpr int kFtW = 62, kFtH = 14, kFtThreads = 512;
+constexpr int kFtS0 = kFtW + 4;  // row stride of the staged M-in region (tile + 2 ring): 66
+constexpr int kFtS1 = kFtW + 2;  // row stride of the intermediate M region (tile + 1 ring): 64 = one wavefront
+static_assert(kFtS1 == 64 && kFtH + 2 == 2 * (kFtThreads / 64), "one wavefront per ring row, two rounds of eight rows");
 
 __device__ __forceinline__ void box_solve_lds(const float *__restrict__ sm, int stride, int plane_elems, int ly, int lx, double scale,
                                               float &fxv, float &fyv) {
@@ -748,12 +751,62 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     __shared__ float s0[5 * (kFtH + 4) * kFtS0];  // M-in on tile + 2 ring
     __shared__ float s1[5 * (kFtH + 2) * kFtS1];  // M after the first iteration on tile + 1 ring
     const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t plane = (size_t)pitch * h;
     const unsigned pb = (unsigned)(plane * 4);
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
               bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, 5 * plane * sizeof(float));
     constexpr int n0 = (kFtH + 4) * kFtS0, n1 = (kFtH + 2) * kFtS1;
 
+    // ring position (r, lane) <-> image pixel (clamp(y0 - 1 + r), clamp(x0 - 1 + lane)); wave `wave` owns ring rows
+    // `wave` (first half) and 8 + `wave` (second half) and keeps their R0 values in registers for the second iteration
+    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);
+    struct Px {  // one pixel between "flow known, taps requested" and "M written"
+        Taps tp;
+        float fxv, fyv;
+        int y;
+        bool active;
+    };
+    auto first_prepare = [&](int r) {
+        Px p;
+        p.y = clampi(y0 - 1 + r, 0, h - 1);
+        p.active = true;
+        box_solve_lds(s0, kFtS0, n0, p.y - (y0 - 2), x - (x0 - 2), scale, p.fxv, p.fyv);
+        p.tp = gather_taps(bR1, x, p.y, w, h, pitch, pb, p.fxv, p.fyv);
+        return p;
+    };
+    auto first_finish = [&](int r, const Px &p, const float r0v[5]) {
+        M5 mm = update_matrices_finish(r0v, p.tp, x, p.y, w, h, p.fxv, p.fyv);
+#pragma unroll
+        for (int c = 0; c < 5; c++) s1[c * n1 + r * kFtS1 + lane] = mm.v[c];
+    };
+    auto second_prepare = [&](int r, bool wave_has_row) {  // ring row r = tile row r - 1
+        Px p;
+        p.y = y0 - 1 + r;
+        p.active = wave_has_row && lane >= 1 && lane <= kFtW && xr < w && p.y < h;  // not the ring itself, inside the image
+        p.fxv = p.fyv = 0.f;
+        if (p.active) {
+            box_solve_lds(s1, kFtS1, n1, r, lane, scale, p.fxv, p.fyv);
+            p.tp = gather_taps(bR1, xr, p.y, w, h, pitch, pb, p.fxv, p.fyv);
+        }
+        return p;
+    };
+    auto second_finish = [&](const Px &p, const float r0v[5]) {
+        if (!p.active) return;
+        M5 mm = update_matrices_finish(r0v, p.tp, xr, p.y, w, h, p.fxv, p.fyv);
+        const unsigned off = ((unsigned)p.y * (unsigned)pitch + (unsigned)xr) * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], off, c * pb);
+    };
+
+    // R0 of both owned rows is requested first: it does not depend on M
+    float r0keep[2][5];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const unsigned off = ((unsigned)clampi(y0 - 1 + 8 * q + wave, 0, h - 1) * (unsigned)pitch + (unsigned)x) * 4u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) r0keep[q][c] = buf_ld(bR0, off, c * pb);
+    }
     // stage M-in: position (ry, rx) of the region holds M(clamp(y0 - 2 + ry), clamp(x0 - 2 + rx))
     for (int e = threadIdx.x; e < n0; e += kFtThreads) {
         const int ry = e / kFtS0, rx = e - ry * kFtS0;
@@ -763,38 +816,22 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     }
     __syncthreads();
 
-    // iteration A on tile + 1 ring: region position (ry, rx) <-> image pixel clamp(y0 - 1 + ry, x0 - 1 + rx)
-    for (int e = threadIdx.x; e < n1; e += kFtThreads) {
-        const int ry = e / kFtS1, rx = e - ry * kFtS1;
-        const int y = clampi(y0 - 1 + ry, 0, h - 1), x = clampi(x0 - 1 + rx, 0, w - 1);
-        float fxv, fyv;
-        box_solve_lds(s0, kFtS0, n0, y - (y0 - 2), x - (x0 - 2), scale, fxv, fyv);
-        float r0v[5];
-        const unsigned off = ((unsigned)y * (unsigned)pitch + (unsigned)x) * 4u;
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0v[c] = buf_ld(bR0, off, c * pb);
-        Taps tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
-        M5 mm = update_matrices_finish(r0v, tp, x, y, w, h, fxv, fyv);
-#pragma unroll
-        for (int c = 0; c < 5; c++) s1[c * n1 + e] = mm.v[c];
+    {   // first iteration, ring rows 0..7
+        Px a = first_prepare(wave);
+        first_finish(wave, a, r0keep[0]);
     }
     __syncthreads();
-
-    // iteration B on the tile
-    for (int e = threadIdx.x; e < 64 * kFtH; e += kFtThreads) {  // one wavefront per tile row (62 of 64 lanes)
-        const int ty = e >> 6, tx = e & 63;
-        const int y = y0 + ty, x = x0 + tx;
-        if (tx >= kFtW || y >= h || x >= w) continue;
-        float fxv, fyv;
-        box_solve_lds(s1, kFtS1, n1, ty + 1, tx + 1, scale, fxv, fyv);
-        float r0v[5];
-        const unsigned off = ((unsigned)y * (unsigned)pitch + (unsigned)x) * 4u;
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0v[c] = buf_ld(bR0, off, c * pb);
-        Taps tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
-        M5 mm = update_matrices_finish(r0v, tp, x, y, w, h, fxv, fyv);
-#pragma unroll
-        for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], off, c * pb);
+    {   // second iteration on tile rows 0..5 (ring rows 1..6 need rows 0..7) and first iteration on ring rows 8..15,
+        // which nobody reads yet
+        Px c0 = second_prepare(wave, wave >= 1 && wave <= 6);
+        second_finish(c0, r0keep[0]);
+        Px b1 = first_prepare(8 + wave);
+        first_finish(8 + wave, b1, r0keep[1]);
+    }
+    __syncthreads();
+    {   // remaining second-iteration rows: tile row 6 (ring row 7, wave 7) and tile rows 7..13 (ring rows 8..14)
+        Px c1 = second_prepare(wave == 7 ? 7 : 8 + wave, true);
+        second_finish(c1, wave == 7 ? r0keep[0] : r0keep[1]);
     }
 }
 
