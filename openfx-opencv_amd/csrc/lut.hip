@@ -63,30 +63,36 @@ __device__ __forceinline__ uint8_t lut_byte(const uint16_t *__restrict__ lut, fl
     return (uint8_t)((lut[__float_as_uint(l) >> 16] + 0x80) >> 8);
 }
 
-// 4 pixels per lane: RGBA rows are read as float4 per pixel, the 4 gray bytes leave as one dword.
+// One pixel per lane and instruction: consecutive lanes read consecutive RGBA pixels (a coalesced 1 KiB request per
+// wavefront for RGBA), and the gray bytes of a wavefront leave as one 64-byte row segment.  Each lane walks 4 such
+// segments, 256 pixels apart, so the loads of all four are in flight together.
 template <int NCOMP>
 __global__ __launch_bounds__(256) void gray_lut_kernel(const float *__restrict__ src, ptrdiff_t src_row_bytes,
                                                        int width, int height, uint8_t *__restrict__ dst,
                                                        ptrdiff_t dst_row_bytes, const uint16_t *__restrict__ lut) {
-    int y = blockIdx.y;
-    int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (x0 >= width) return;
-    const float *s = (const float *)((const char *)src + (ptrdiff_t)y * src_row_bytes) + (size_t)x0 * NCOMP;
-    uint8_t *d = dst + (ptrdiff_t)y * dst_row_bytes + x0;
-    uint8_t out[4];
-    int n = min(4, width - x0);
-    for (int i = 0; i < n; i++) {
-        if (NCOMP == 4 && (((uintptr_t)s) & 15) == 0) {
-            float4 p = *(const float4 *)(s + i * 4);
-            out[i] = lut_byte(lut, p.x, p.y, p.z);
-        } else {
-            out[i] = lut_byte(lut, s[i * NCOMP], s[i * NCOMP + 1], s[i * NCOMP + 2]);
+    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * 1024 + threadIdx.x;
+    const float *srow = (const float *)((const char *)src + (ptrdiff_t)y * src_row_bytes);
+    uint8_t *drow = dst + (ptrdiff_t)y * dst_row_bytes;
+    const bool vec = NCOMP == 4 && (((uintptr_t)srow) & 15) == 0;
+    float r[4], g[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + i * 256;
+        r[i] = g[i] = b[i] = 0.f;
+        if (x < width) {
+            if (vec) {
+                float4 p = *(const float4 *)(srow + (size_t)x * 4);
+                r[i] = p.x; g[i] = p.y; b[i] = p.z;
+            } else {
+                r[i] = srow[(size_t)x * NCOMP]; g[i] = srow[(size_t)x * NCOMP + 1]; b[i] = srow[(size_t)x * NCOMP + 2];
+            }
         }
     }
-    if (n == 4 && (((uintptr_t)d) & 3) == 0) {
-        *(uint32_t *)d = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
-    } else {
-        for (int i = 0; i < n; i++) d[i] = out[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = x0 + i * 256;
+        if (x < width) drow[x] = lut_byte(lut, r[i], g[i], b[i]);
     }
 }
 
@@ -126,7 +132,7 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
     hipStream_t s = ofxcv_stream(ctx, stream);
     int rc = ensure_lut(ctx, s);
     if (rc) return rc;
-    dim3 block(256), grid(ofxcv_div_up(ofxcv_div_up(width, 4), 256), height);
+    dim3 block(256), grid(ofxcv_div_up(width, 1024), height);
     if (ncomp == 4)
         hipLaunchKernelGGL(gray_lut_kernel<4>, grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
     else
