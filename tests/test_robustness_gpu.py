@@ -1,0 +1,116 @@
+"""Error behaviour of the C ABI and concurrency of the drop-in boundary (GPU)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_c_abi_rejects_bad_arguments(ofxcv, gpu_ctx):
+    import torch
+    lib = ofxcv.lib()
+    h = gpu_ctx._h
+    g = torch.zeros((48, 64), dtype=torch.uint8, device="cuda")
+    fl = torch.zeros((48, 64, 2), dtype=torch.float32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    call = lambda **kw: lib.ofxcv_calc_optical_flow_farneback(
+        h, kw.get("prev", P(g)), C.c_size_t(kw.get("pstep", 64)), P(g), C.c_size_t(64), kw.get("flow", P(fl)), C.c_size_t(kw.get("fstep", 512)),
+        C.c_int(kw.get("w", 64)), C.c_int(kw.get("h", 48)), C.c_double(kw.get("ps", 0.5)), C.c_int(3), C.c_int(kw.get("win", 3)),
+        C.c_int(kw.get("it", 15)), C.c_int(kw.get("n", 5)), C.c_double(1.1), C.c_int(kw.get("flags", 0)), None)
+    assert call() == 0
+    assert call(prev=None) == -1 and call(flow=None) == -1                 # NULL pointers
+    assert call(w=0) == -1 and call(h=-3) == -1                            # sizes
+    assert call(pstep=32) == -1 and call(fstep=100) == -1                  # strides smaller than a row / unaligned
+    assert call(ps=1.0) == -1 and call(ps=0.0) == -1 and call(it=0) == -1 and call(win=4) == -1
+    assert call(flags=4) == -4 and call(flags=256) == -4                   # USE_INITIAL_FLOW / FARNEBACK_GAUSSIAN: unsupported
+    assert b"flags" in lib.ofxcv_last_error(h)
+    assert call(n=99) == -4                                                # poly_n beyond the coefficient tables
+    assert lib.ofxcv_ctx_set_option(h, b"no.such.option", 1) == -1
+    assert lib.ofxcv_to_byte_grayscale(h, P(fl), C.c_ssize_t(512), C.c_int(2), 64, 48, P(g), C.c_ssize_t(64), None) == -4   # 2 components
+    assert lib.ofxcv_inpaint_telea(h, P(g), C.c_ssize_t(64), C.c_int(1), P(g), C.c_ssize_t(64), 16, 16, C.c_double(3.0), P(g), C.c_ssize_t(64), None, None, None) == -1
+    assert lib.ofxcv_pyr_mean_shift_filtering(h, P(g), C.c_ssize_t(64), 3, 16, 16, C.c_double(10), C.c_double(20), 9, 5, C.c_double(1), P(fl), C.c_ssize_t(64), None) == -1
+    assert call() == 0                                                      # the context is still usable after errors
+
+
+def test_other_window_sizes_use_the_generic_kernel(oracle, gpu_ctx):
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(160, 120)
+    ga, gb = oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
+    for win in (1, 5):
+        got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), winsize=win, iterations=4).cpu().numpy()
+        ref = oracle.calc_optical_flow_farneback(ga, gb, winsize=win, iterations=4, blur_mode=oracle.BLUR_DIRECT)
+        assert np.array_equal(ref, got), win
+    # odd / even iteration counts exercise the pair + single launch mix of the fused kernel
+    for it in (1, 2, 3, 6):
+        got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), iterations=it).cpu().numpy()
+        assert np.array_equal(oracle.calc_optical_flow_farneback(ga, gb, iterations=it, blur_mode=oracle.BLUR_DIRECT), got), it
+
+
+def test_graph_replay_and_eager_agree(ofxcv, oracle):
+    import torch
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(320, 240)
+    ga, gb = _dev(oracle.to_byte_grayscale(a)), _dev(oracle.to_byte_grayscale(b))
+    c1, c2 = ofxcv.Context(0), ofxcv.Context(0)
+    c2.set_option("farneback.graph", 0)
+    f_out = torch.empty((240, 320, 2), device="cuda")
+    first = c1.calc_optical_flow_farneback(ga, gb, f_out).clone()          # capture + launch
+    again = c1.calc_optical_flow_farneback(ga, gb, f_out).clone()          # replay of the cached graph
+    eager = c2.calc_optical_flow_farneback(ga, gb)
+    assert torch.equal(first, again) and torch.equal(first, eager)
+    other = c1.calc_optical_flow_farneback(gb, ga, f_out).clone()          # different pointers: a new graph, not a stale replay
+    assert torch.equal(other, c2.calc_optical_flow_farneback(gb, ga)) and not torch.equal(other, first)
+    c1.close()
+    c2.close()
+
+
+def test_concurrent_renders_on_one_instance(oracle):
+    """VectorGenerator is eRenderFullySafe (VectorGenerator.cpp:108): the host may call render() on one instance from
+    several threads at different times.  Four threads render four frames concurrently through the OFX boundary."""
+    import os
+    import subprocess
+    import test_ofx_boundary as tb
+    Plugin = tb.Plugin
+    subprocess.check_call(["make", "-s", "-C", os.path.join(tb.ROOT, "tests", "mock_host")])
+    import torch  # noqa: F401
+    h = C.CDLL(os.path.join(tb.ROOT, "tests", "mock_host", "libmockhost.so"))
+    h.mh_open.restype = C.c_void_p
+    h.mh_create_instance.restype = C.c_void_p
+    h.mh_last_message.restype = C.c_char_p
+    h.mh_plugin_identifier.restype = C.c_char_p
+    from openfx_opencv_amd import synth
+    w, hh = 256, 192
+    frames = [synth.flow_pair(w, hh, seed=100 + i)[0] for i in range(6)]    # frames t = 0..5
+    pl = Plugin(h, "VectorGenerator")
+    inst = pl.instance()
+    outs = {}
+    for t, fr in enumerate(frames):
+        pl.set_image(inst, "Source", float(t), fr, "OfxBitDepthFloat")
+    for t in range(1, 5):
+        outs[t] = np.zeros((hh, w, 4), np.float32)
+        pl.set_image(inst, "Output", float(t), outs[t], "OfxBitDepthFloat")
+    status = {}
+
+    def work(t):
+        status[t] = pl.render(inst, float(t), w, hh)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(1, 5)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert all(status[t] == 0 for t in range(1, 5)), status
+    gray = [oracle.to_byte_grayscale(f) for f in frames]
+    for t in range(1, 5):
+        fwd = oracle.calc_optical_flow_farneback(gray[t], gray[t + 1], blur_mode=oracle.BLUR_DIRECT)
+        bwd = oracle.calc_optical_flow_farneback(gray[t], gray[t - 1], blur_mode=oracle.BLUR_DIRECT)
+        assert np.array_equal(outs[t][..., :2], fwd) and np.array_equal(outs[t][..., 2:], bwd), t
+    assert h.mh_clip_balance(inst, b"Source") == 0 and h.mh_clip_balance(inst, b"Output") == 0
+    pl.destroy(inst)
