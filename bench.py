@@ -86,12 +86,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    # BENCH_BACKEND=gloo + BENCH_SHARE_DEVICE=1 let the N > 1 code path be exercised on a single-GPU box (all ranks on
+    # device 0, CPU tensors for the two reduces); the driver's multi-GPU runs use the defaults (one GPU per rank, RCCL).
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # One step = one batch of `pairs` independent frame pairs, each on its own context (own HIP stream and
     # scratch): frame pairs never exchange data, so they shard across streams exactly as they shard across GPUs.
@@ -143,8 +152,8 @@ def main():
     c0.profile_enable(False)
     g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
 
-    elapsed = sharding.reduce_elapsed_max(elapsed, dist, "cuda")        # MAX over ranks
-    pairs = sharding.reduce_count_sum(args.steps * P, dist, "cuda")       # units all ranks processed
+    elapsed = sharding.reduce_elapsed_max(elapsed, dist, red_dev)        # MAX over ranks
+    pairs = sharding.reduce_count_sum(args.steps * P, dist, red_dev)       # units all ranks processed
 
     if rank == 0:
         value = pairs / elapsed

@@ -132,6 +132,15 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // imgwarp.cpp resize(INTER_LINEAR) coefficient rule for destination index d
+__device__ __forceinline__ void lerp_coef_scaled(int d, int ssize, double scale, int &s, float &a0, float &a1) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    a0 = 1.f - f;
+    a1 = f;
+}
 __device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, float &a0, float &a1) {
     double scale = (double)ssize / dsize;
     float f = (float)((d + 0.5) * scale - 0.5);
@@ -525,8 +534,8 @@ __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, c
 template <int MODE>
 __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ flow, size_t flow_step, int pw, int ph,
-                                                              double inv_pyr_scale, int w, int h, int pitch,
-                                                              float *__restrict__ M) {
+                                                              double inv_pyr_scale, double scale_x, double scale_y, int w, int h,
+                                                              int pitch, float *__restrict__ M) {
     int x = blockIdx.x * 64 + threadIdx.x;
     int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
@@ -534,8 +543,8 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
     if (MODE == 1) {
         int sx, sy;
         float ax0, ax1, b0, b1;
-        lerp_coef(x, pw, w, sx, ax0, ax1);
-        lerp_coef(y, ph, h, sy, b0, b1);
+        lerp_coef_scaled(x, pw, scale_x, sx, ax0, ax1);  // scale = (double)pw / w, divided once on the host
+        lerp_coef_scaled(y, ph, scale_y, sy, b0, b1);
         int sy1 = min(sy + 1, ph - 1);
         const float2 *S0 = (const float2 *)((const char *)flow + (size_t)sy * flow_step);
         const float2 *S1 = (const float2 *)((const char *)flow + (size_t)sy1 * flow_step);
@@ -1058,7 +1067,7 @@ int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const flo
     if (!d_R0 || !d_R1 || !d_flow || !d_M || width <= 0 || height <= 0 || (flow_step & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
     hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
-                       ofxcv_stream(ctx, stream), d_R0, d_R1, d_flow, flow_step, 0, 0, 1.0, width, height, plane_pitch(width), d_M);
+                       ofxcv_stream(ctx, stream), d_R0, d_R1, d_flow, flow_step, 0, 0, 1.0, 1.0, 1.0, width, height, plane_pitch(width), d_M);
     OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
     return OFXCV_OK;
 }
@@ -1133,9 +1142,9 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const int pitch = plane_pitch(w);
         dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
         if (!prev_flow)
-            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, w, h, pitch, Mbuf[0]);
+            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0]);
         else
-            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, w, h, pitch, Mbuf[0]);
+            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, w, h, pitch, Mbuf[0]);
         OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
         float *out_flow = k == 0 ? d_flow : cflow[k & 1];
         size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
