@@ -150,6 +150,19 @@ def main():
     torch.cuda.synchronize()
     kern_ms, kern_n = c0.profile_read()
     c0.profile_enable(False)
+    # for reference, the same event pairs with all `pairs` streams in flight (what a kernel trace of the timed region shows)
+    conc_ms, conc_n = 0.0, 0
+    if P > 1:
+        for c in ctxs:
+            c.profile_enable(True)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            ms, n = c.profile_read()
+            conc_ms += ms
+            conc_n += n
+            c.profile_enable(False)
     g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
 
     elapsed = sharding.reduce_elapsed_max(elapsed, dist, red_dev)        # MAX over ranks
@@ -178,8 +191,10 @@ def main():
                        "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
                        "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(), "kernel": "iterate3x2_kernel (two fused blur+solve+update iterations per launch, pyramid level 0, %dx%d)" % (W, H),
-                         "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n},
+                         "traffic": pmc_traffic(), "kernel": "iterate3x2_kernel<true> (two fused blur+solve+update iterations per launch; <true> = the pyramid level 0 launches, %dx%d)" % (W, H),
+                         "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n,
+                         "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r01_bench_pairs1_kernel_stats.csv)",
+                         "avg_launch_us_all_streams_in_flight": (conc_ms / conc_n * 1e3) if conc_n else None},
             "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
                            "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},
         }

@@ -754,6 +754,8 @@ __device__ __forceinline__ void box_solve_lds(const float *__restrict__ sm, int 
     fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
 }
 
+// LEVEL0 only tags the symbol: the launches on the full-resolution level get their own row in a kernel trace
+template <bool LEVEL0>
 __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                                 const float *__restrict__ Min, float *__restrict__ Mout, int w, int h,
                                                                 int pitch, double scale) {
@@ -1021,9 +1023,13 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
 }
 
 // two fused iterations M -> M'' (winsize 3 only)
-int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h) {
-    hipLaunchKernelGGL(iterate3x2_kernel, dim3(ofxcv_div_up(w, kFtW), ofxcv_div_up(h, kFtH)), dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h,
-                       plane_pitch(w), 1. / 9.);
+int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
+                          bool level0) {
+    dim3 grid(ofxcv_div_up(w, kFtW), ofxcv_div_up(h, kFtH));
+    if (level0)
+        hipLaunchKernelGGL(iterate3x2_kernel<true>, grid, dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h, plane_pitch(w), 1. / 9.);
+    else
+        hipLaunchKernelGGL(iterate3x2_kernel<false>, grid, dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h, plane_pitch(w), 1. / 9.);
     OFXCV_LAUNCH_CHECK(ctx, "iterate3x2_kernel");
     return OFXCV_OK;
 }
@@ -1156,7 +1162,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
             if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             if (pair) {  // two updating iterations in one launch
-                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h);
+                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h, k == 0);
                 i += 2;
             } else {
                 bool update = i < iterations - 1;
