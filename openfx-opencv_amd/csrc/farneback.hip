@@ -330,6 +330,47 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restric
     }
 }
 
+// 3-tap levels (k = 0: sigma 0 -> [1/4 1/2 1/4], identity resize; k = 1: sigma 0.5, half size): the footprint of an
+// output sample is at most 4x4 source bytes, so each lane simply reads it through the L1 -- no staging, no barriers.
+// Same operations in the same order as the generic kernels.
+__global__ __launch_bounds__(256) void pyr_direct3_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh,
+                                                          int ntap, float k0, float k1, double scale_x, double scale_y,
+                                                          float *__restrict__ I) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= lw || dy >= lh) return;
+    int sx = dx, sy = dy;
+    float ax0 = 1.f, ax1 = 0.f, b0 = 1.f, b1 = 0.f;
+    if (ntap == 2) {
+        lerp_coef_scaled(dx, W, scale_x, sx, ax0, ax1);
+        lerp_coef_scaled(dy, H, scale_y, sy, b0, b1);
+    }
+    // row filter of source row `ry` at column `cx`:  S[0]*k0 + (S[-1] + S[1])*k1
+    auto rowf = [&](int ry, int cx) -> float {
+        const uint8_t *S = img + (size_t)reflect101(ry, H) * step;
+        return (float)S[cx] * k0 + ((float)S[reflect101(cx - 1, W)] + (float)S[reflect101(cx + 1, W)]) * k1;
+    };
+    // column filter at source row `cy`:  (T[-1] + T[1])*k1 + T[0]*k0
+    auto colf = [&](int cy, int cx) -> float { return (rowf(cy - 1, cx) + rowf(cy + 1, cx)) * k1 + rowf(cy, cx) * k0; };
+    float out;
+    if (ntap == 1) {
+        out = colf(sy, sx);
+    } else {
+        const int sy1 = min(sy + 1, H - 1);
+        float t00 = colf(sy, sx), t10 = colf(sy1, sx), r0, r1;
+        if (sx + 1 < W) {
+            const int sx1 = min(sx + 1, W - 1);
+            float t01 = colf(sy, sx1), t11 = colf(sy1, sx1);
+            r0 = t00 * ax0 + t01 * ax1;
+            r1 = t10 * ax0 + t11 * ax1;
+        } else {
+            r0 = t00 * 1.f;
+            r1 = t10 * 1.f;
+        }
+        out = r0 * b0 + r1 * b1;
+    }
+    I[(size_t)dy * lw + dx] = out;
+}
+
 // ------------------------------------------------------------------ F3 polynomial expansion
 //
 // One 64x16 output tile per 256-thread block.  The tile of I plus an n-pixel halo is staged in
@@ -928,8 +969,14 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk);
     int ntap = (lw == W && lh == H) ? 1 : 2;
-    // fused tile kernel when the source footprint of a 32x8 (64x8 for small decimation) tile fits in LDS
     static const bool no_fused = getenv("OFXCV_PYR_UNFUSED") != nullptr;
+    if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
+        hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_img, step, W, H, lw, lh, ntap,
+                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3_kernel");
+        return OFXCV_OK;
+    }
+    // fused tile kernel when the source footprint of a 32x8 (64x8 for small decimation) tile fits in LDS
     PyrTile t;
     t.ow = (double)W / lw <= 2.01 ? 64 : 32;
     t.oh = 8;
