@@ -49,7 +49,10 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.opencv_rounding" 0|1  evaluate the Farneback box window with OpenCV's own running sums (every row
  *                                    difference rounded to f32 before it is accumulated in f64) -- a validation mode,
  *                                    ~20x slower, that reproduces the reference's rounding noise sample for sample;
- *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1). */
+ *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1);
+ *   "farneback.fuse_iterations" 0|1  run two iterations per launch through LDS (default 1; 0 = one launch each);
+ *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
+ *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels). */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------

@@ -43,7 +43,7 @@ struct ofxcv_ctx {
     hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {};
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned fb_graph_next = 0;
-    bool fb_no_graph = false;
+    bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
     char err[512] = {0};
 
     // F0: 65536-entry 8.8 fixed-point sRGB table (openfx-supportext ofxsLut.h semantics)

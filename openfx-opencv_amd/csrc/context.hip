@@ -53,7 +53,6 @@ int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
     OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    if (getenv("OFXCV_NO_GRAPH")) ctx->fb_no_graph = true;
     return OFXCV_OK;
 }
 
@@ -144,6 +143,18 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "farneback.graph")) {
         ctx->fb_no_graph = value == 0;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.fuse_iterations")) {
+        ctx->fb_no_fuse = value == 0;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.prep_stream")) {
+        ctx->fb_one_stream = value == 0;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.fused_pyramid")) {
+        ctx->fb_unfused_pyr = value == 0;
         return OFXCV_OK;
     }
     return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "unknown option '%s'", name);

@@ -969,7 +969,7 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk);
     int ntap = (lw == W && lh == H) ? 1 : 2;
-    static const bool no_fused = getenv("OFXCV_PYR_UNFUSED") != nullptr;
+    const bool no_fused = ctx->fb_unfused_pyr;
     if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
         hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_img, step, W, H, lw, lh, ntap,
                            gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I);
@@ -1042,7 +1042,6 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         const int cols = ofxcv_div_up(w, 64);
         int rows = 4;
         while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
-        if (const char *e = getenv("OFXCV_ROWS")) rows = atoi(e);
         dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
         const int pitch = plane_pitch(w);
 #define OFXCV_LAUNCH_IT(UPD, RW) \
@@ -1202,8 +1201,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         float *out_flow = k == 0 ? d_flow : cflow[k & 1];
         size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
         int cur = 0;
-        static const bool no_fuse = getenv("OFXCV_NO_FUSE2") != nullptr;
-        const bool fuse = !no_fuse && winsize == 3 && !ctx->fb_opencv_rounding;
+        const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding;
         for (int i = 0; i < iterations;) {
             const bool pair = fuse && i + 2 <= iterations - 1;
             const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
@@ -1274,8 +1272,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;
-    static const bool one_stream = getenv("OFXCV_ONE_STREAM") != nullptr;
-    hipStream_t sp = one_stream ? s : ctx->prep;
+    hipStream_t sp = ctx->fb_one_stream ? s : ctx->prep;
 
     // hipGraph replay: the ~90 launches of a call are captured once per (pointers, geometry, parameters) and replayed
     // with one hipGraphLaunch (host launch cost 0.55 ms -> ~0.02 ms per call).  The measurement hook needs its event
@@ -1295,21 +1292,24 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
             (void)hipGraphExecDestroy(slot->exec);
             slot->exec = nullptr;
         }
+        // Relaxed mode: the captured region itself makes no capture-unsafe call, and other host threads (each with
+        // its own context: allocations, synchronising copies) must not be able to invalidate this capture.  If the
+        // capture cannot be completed anyway, the call falls back to plain launches and stops using graphs.
         hipGraph_t graph = nullptr;
-        OFXCV_HIP_CHECK(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
-                               poly_sigma, false);
-        hipError_t e = hipStreamEndCapture(s, &graph);
-        if (rc) {
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+            rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
+                                   poly_sigma, false);
+            ok = hipStreamEndCapture(s, &graph) == hipSuccess && rc == OFXCV_OK && graph != nullptr;
+            if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
-            return rc;
         }
-        if (e != hipSuccess) return ofxcv_fail(ctx, OFXCV_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) {
+        if (!ok) {
             slot->exec = nullptr;
-            return ofxcv_fail(ctx, OFXCV_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+            (void)hipGetLastError();  // clear the sticky capture error
+            ctx->fb_no_graph = true;
+            return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
+                                     poly_sigma, false);
         }
         std::memset(&slot->key, 0, sizeof(slot->key));
         slot->key = key;

@@ -21,7 +21,6 @@
 //     associative and the result is rounded twice, so the order matters for bit-exact colours).
 #include <algorithm>
 #include <cfloat>
-#include <chrono>
 #include <climits>
 #include <cmath>
 #include <queue>
@@ -542,13 +541,8 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
 
     March m;
-    const bool dbg = getenv("OFXCV_DEBUG_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now();
     march_front(mask.data(), w, h, range, m);
-    double t1 = now();
     build_levels(m);
-    double t2 = now();
     const int n = (int)m.pix.size();
 
     if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, m.t.data(), en * sizeof(float), hipMemcpyHostToDevice, s));
@@ -608,9 +602,6 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
             hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);
         OFXCV_LAUNCH_CHECK(ctx, "unpack_rgbx_kernel");
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host vectors above must outlive the copies
-        if (dbg)
-            fprintf(stderr, "inpaint %dx%d: march %.2f ms, levels %.2f ms (%d px, %d segments, %d components), upload+fill %.2f ms\n", w, h,
-                    t1 - t0, t2 - t1, n, nseg, ncomp, now() - t2);
     }
     return OFXCV_OK;
 }

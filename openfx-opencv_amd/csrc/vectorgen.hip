@@ -95,15 +95,26 @@ extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptr
     OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow, d_flow, (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
 
+    // write-back into the host-owned destination (:507-516): channel c receives flow.y if mapped to v, else flow.x if
+    // mapped to u, else stays untouched.  The channel -> coordinate table is resolved once, not per pixel.
     const unsigned mu = chan_u_mask & 15u, mv = chan_v_mask & 15u;
-    for (int y = 0; y < height; y++) {
+    int nmap = 0, dst_c[4], src_c[4];
+    for (int c = 0; c < 4; c++) {
+        if (mv & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 1; }
+        else if (mu & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 0; }
+    }
+    for (int y = 0; y < height && nmap; y++) {
         float *d = (float *)((char *)h_dst + (ptrdiff_t)y * dst_row_bytes);
-        const float *s = h_flow + (size_t)y * width * 2;
-        for (int x = 0; x < width; x++) {
-            for (int c = 0; c < 4; c++) {
-                if (mv & (1u << c)) d[x * 4 + c] = s[x * 2 + 1];
-                else if (mu & (1u << c)) d[x * 4 + c] = s[x * 2];
+        const float *sf = h_flow + (size_t)y * width * 2;
+        if (nmap == 2) {
+            const int d0 = dst_c[0], d1 = dst_c[1], s0 = src_c[0], s1 = src_c[1];
+            for (int x = 0; x < width; x++) {
+                d[x * 4 + d0] = sf[x * 2 + s0];
+                d[x * 4 + d1] = sf[x * 2 + s1];
             }
+        } else {
+            for (int x = 0; x < width; x++)
+                for (int k = 0; k < nmap; k++) d[x * 4 + dst_c[k]] = sf[x * 2 + src_c[k]];
         }
     }
     return OFXCV_OK;

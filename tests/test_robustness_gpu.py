@@ -71,6 +71,27 @@ def test_graph_replay_and_eager_agree(ofxcv, oracle):
     c2.close()
 
 
+def test_every_kernel_variant_gives_the_same_flow(ofxcv, oracle):
+    """fused / unfused iterations, prep stream on / off, fused / two-pass pyramid: identical results."""
+    import torch
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(333, 257)
+    ga, gb = _dev(oracle.to_byte_grayscale(a)), _dev(oracle.to_byte_grayscale(b))
+    base = None
+    for opts in [{}, {"farneback.fuse_iterations": 0}, {"farneback.prep_stream": 0}, {"farneback.fused_pyramid": 0},
+                 {"farneback.graph": 0, "farneback.fuse_iterations": 0, "farneback.prep_stream": 0, "farneback.fused_pyramid": 0}]:
+        c = ofxcv.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        f = c.calc_optical_flow_farneback(ga, gb).clone()
+        c.close()
+        if base is None:
+            base = f
+            assert np.array_equal(f.cpu().numpy(), oracle.calc_optical_flow_farneback(ga.cpu().numpy(), gb.cpu().numpy(), blur_mode=oracle.BLUR_DIRECT))
+        else:
+            assert torch.equal(base, f), opts
+
+
 def test_concurrent_renders_on_one_instance(oracle):
     """VectorGenerator is eRenderFullySafe (VectorGenerator.cpp:108): the host may call render() on one instance from
     several threads at different times.  Four threads render four frames concurrently through the OFX boundary."""
