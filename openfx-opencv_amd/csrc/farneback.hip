@@ -152,6 +152,18 @@ __device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, f
     a1 = f;
 }
 
+// Workgroup -> tile mapping.  The dispatcher is observed to place workgroup b on XCD b % 8 and every XCD has its own
+// L2, so with the plain mapping two neighbouring tiles -- which share halo rows/columns and the cache lines of the
+// R1 samples -- never share an L2.  This bijective remap hands every XCD a contiguous row-major run of tiles
+// (cdna_hip_programming.md T1).  It only changes which workgroup computes which tile: results are unaffected.
+__device__ __forceinline__ void xcd_tile(int &bx, int &by) {
+    const unsigned gx = gridDim.x, nwg = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    const unsigned xcd = id & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    by = (int)(t / gx);
+    bx = (int)(t - (unsigned)by * gx);
+}
+
 // ------------------------------------------------------------------ F1/F2 pyramid image
 //
 // OpenCV blurs at full resolution and then decimates; only the two source columns / rows that
@@ -252,7 +264,9 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restric
     float *s_yb = (float *)(s_ys + t.oh);          // [oh][2]
     float *s_h = s_yb + 2 * t.oh;                  // [rh][ncolh] row-filtered samples
     unsigned char *s_src = (unsigned char *)(s_h + (size_t)t.rh * ncolh);  // [rh][cw] source bytes
-    const int ox0 = blockIdx.x * t.ow, oy0 = blockIdx.y * t.oh;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int ox0 = tbx * t.ow, oy0 = tby * t.oh;
     const int tid = threadIdx.x;
 
     if (tid < t.ow) {
@@ -336,7 +350,9 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restric
 __global__ __launch_bounds__(256) void pyr_direct3_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh,
                                                           int ntap, float k0, float k1, double scale_x, double scale_y,
                                                           float *__restrict__ I) {
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int dx = tbx * 64 + threadIdx.x, dy = tby * 4 + threadIdx.y;
     if (dx >= lw || dy >= lh) return;
     int sx = dx, sy = dy;
     float ax0 = 1.f, ax1 = 0.f, b0 = 1.f, b1 = 0.f;
@@ -392,7 +408,9 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
     float *sI = lds;                       // [ih][ldw]
     float *sV = lds + ih * ldw;            // [3][kPeTH][ldw]
     const int tid = threadIdx.x, lx = tid & 63, tq = tid >> 6;
-    const int x0 = blockIdx.x * kPeTW, y0 = blockIdx.y * kPeTH;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x0 = tbx * kPeTW, y0 = tby * kPeTH;
 
     // stage I (rows and columns clamped = replicated border); lanes < 2n also fetch the extra halo columns
     const int gx0 = clampi(x0 + lx - n, 0, w - 1), gx1 = clampi(x0 + 64 + lx - n, 0, w - 1);
@@ -577,8 +595,10 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
                                                               const float *__restrict__ flow, size_t flow_step, int pw, int ph,
                                                               double inv_pyr_scale, double scale_x, double scale_y, int w, int h,
                                                               int pitch, float *__restrict__ M) {
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = blockIdx.y * 4 + threadIdx.y;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    int x = tbx * 64 + threadIdx.x;
+    int y = tby * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
@@ -622,8 +642,10 @@ __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__r
                                                                 const float *__restrict__ Min, float *__restrict__ Mout,
                                                                 float *__restrict__ flow, size_t flow_step, int w, int h,
                                                                 int pitch, int m, double scale) {
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = blockIdx.y * 4 + threadIdx.y;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    int x = tbx * 64 + threadIdx.x;
+    int y = tby * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     const size_t plane = (size_t)pitch * h;
     double acc[5];
@@ -684,9 +706,11 @@ __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__
                                                        float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
                                                        double scale) {
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x = tbx * 256 + threadIdx.x;
     if ((x & ~63) >= w) return;  // whole wave outside
-    const int y0 = blockIdx.y * ROWS;
+    const int y0 = tby * ROWS;
     const bool live = x < w;
     const int xc = min(x, w - 1);
     // halo column of this wave: lane 0 fetches x-1, lane 63 fetches x+1 (clamped = replicated border)
@@ -802,7 +826,9 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
                                                                 int pitch, double scale) {
     __shared__ float s0[5 * (kFtH + 4) * kFtS0];  // M-in on tile + 2 ring
     __shared__ float s1[5 * (kFtH + 2) * kFtS1];  // M after the first iteration on tile + 1 ring
-    const int x0 = blockIdx.x * kFtW, y0 = blockIdx.y * kFtH;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x0 = tbx * kFtW, y0 = tby * kFtH;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t plane = (size_t)pitch * h;
     const unsigned pb = (unsigned)(plane * 4);
