@@ -106,6 +106,9 @@ def main():
     # scratch): frame pairs never exchange data, so they shard across streams exactly as they shard across GPUs.
     P = max(1, args.pairs)
     ctxs = [ofxcv.Context(local_rank) for _ in range(P)]
+    for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):  # A/B of kernel variants: name=value,...
+        for c in ctxs:
+            c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     bufs = []
     for i, c in enumerate(ctxs):
         a, b = synth.flow_pair(W, H, seed=sharding.seed_for_pair(sharding.pairs_for_rank(world * P, rank, world)[i]))

@@ -44,6 +44,8 @@ struct ofxcv_ctx {
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned fb_graph_next = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
+    int fb_polyexp_variant = 5;
+    int num_cus = 256;
     char err[512] = {0};
 
     // F0: 65536-entry 8.8 fixed-point sRGB table (openfx-supportext ofxsLut.h semantics)

@@ -89,6 +89,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
         OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
+        OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
         for (int i = 0; i < 2; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
@@ -137,6 +138,16 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute
 
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return OFXCV_ERR_INVALID;
+    // captured launch sequences bake the kernel choice in: drop them whenever an option changes
+    for (FbGraph &g : ctx->fb_graphs)
+        if (g.exec) {
+            (void)hipGraphExecDestroy(g.exec);
+            g.exec = nullptr;
+        }
+    if (!std::strcmp(name, "farneback.polyexp_variant")) {
+        ctx->fb_polyexp_variant = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.opencv_rounding")) {
         ctx->fb_opencv_rounding = value != 0;
         return OFXCV_OK;

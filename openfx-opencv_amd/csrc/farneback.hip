@@ -473,6 +473,116 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
     }
 }
 
+// Persistent form for the compile-time neighbourhoods (poly_n 5 = the plugin default, 7).  Same arithmetic, in the
+// same order per output sample, as polyexp_kernel; what changes is how it is scheduled:
+//  * a workgroup loops over tiles (a contiguous run per XCD, interleaved between that XCD's workgroups) and requests the
+//    next tile's samples into registers before it computes the current one, so the loads overlap the arithmetic;
+//  * the vertical pass handles two neighbouring columns per lane with packed f32 instructions and stores its three sums
+//    per column as one 16-byte LDS word {t0, t1, t1, t2}; the horizontal pass then needs one 16-byte LDS read per tap
+//    and forms (t0,t1) differences and (t1,t2) sums with packed instructions before they enter the f64 accumulators.
+// The kernel is VALU-bound (about 165 vector instructions per sample, a third of them f64).
+typedef float ofxcv_f2 __attribute__((ext_vector_type(2)));
+typedef float ofxcv_f4 __attribute__((ext_vector_type(4)));
+
+template <int N, int TH>
+__global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
+                                                                 int pitch, PolyCoef pc, int tiles_x, int ntiles) {
+    constexpr int CW = kPeTW + 2 * N, LDW = CW + 2, IH = TH + 2 * N;  // staged columns / row stride (even) / rows
+    constexpr int NSR = (IH + 3) / 4;                                 // staged rows per wavefront
+    constexpr int NV = (CW / 2) * TH;                                 // column pairs x rows of the vertical pass
+    __shared__ float sI[IH * LDW];
+    __shared__ ofxcv_f4 sV[TH * CW];
+    const int tid = threadIdx.x, lx = tid & 63, tq = tid >> 6;
+    // XCD b % 8 works through tiles [lo, hi); its workgroups take them round-robin
+    const unsigned xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
+    const int lo = (int)((long)ntiles * xcd / 8), hi = (int)((long)ntiles * (xcd + 1) / 8);
+    const float *g = pc.g + pc.n, *xg = pc.xg + pc.n, *xxg = pc.xxg + pc.n;
+    const size_t plane = (size_t)pitch * h;
+
+    // staging: wavefront tq fetches rows tq, tq + 4, ...; lane lx column lx, lanes < 2N also column 64 + lx
+    float pre[NSR], pre2[NSR];
+    auto request = [&](int t) {
+        const int ty0 = t / tiles_x, x0 = (t - ty0 * tiles_x) * kPeTW, y0 = ty0 * TH;
+        const int gx0 = clampi(x0 + lx - N, 0, w - 1), gx1 = clampi(x0 + 64 + lx - N, 0, w - 1);
+#pragma unroll
+        for (int i = 0; i < NSR; i++) {
+            const int ry = tq + 4 * i;
+            const float *row = I + (size_t)clampi(y0 + ry - N, 0, h - 1) * w;
+            pre[i] = row[gx0];
+            pre2[i] = lx < 2 * N ? row[gx1] : 0.f;
+        }
+    };
+    int t = lo + (int)(blockIdx.x >> 3);
+    if (t < hi) request(t);
+    while (t < hi) {
+#pragma unroll
+        for (int i = 0; i < NSR; i++) {
+            const int ry = tq + 4 * i;
+            if (ry < IH) {
+                sI[ry * LDW + lx] = pre[i];
+                if (lx < 2 * N) sI[ry * LDW + 64 + lx] = pre2[i];
+            }
+        }
+        __syncthreads();
+        const int tn = t + (int)per;
+        if (tn < hi) request(tn);
+
+        // vertical pass (f32), two columns per lane
+        for (int e = tid; e < NV; e += 256) {
+            const int row = e / (CW / 2), c2 = (e - row * (CW / 2)) * 2;
+            const float *col = sI + (row + N) * LDW + c2;
+            const ofxcv_f2 v0 = *(const ofxcv_f2 *)col;
+            ofxcv_f2 t0 = v0 * g[0], t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const ofxcv_f2 s0 = *(const ofxcv_f2 *)(col - k * LDW), s1 = *(const ofxcv_f2 *)(col + k * LDW);
+                const ofxcv_f2 p = s0 + s1;
+                t0 = t0 + g[k] * p;
+                t1 = t1 + xg[k] * (s1 - s0);
+                t2 = t2 + xxg[k] * p;
+            }
+            sV[row * CW + c2] = ofxcv_f4{t0.x, t1.x, t1.x, t2.x};
+            sV[row * CW + c2 + 1] = ofxcv_f4{t0.y, t1.y, t1.y, t2.y};
+        }
+        __syncthreads();
+
+        // horizontal pass (f64 accumulators)
+        const int ty0 = t / tiles_x, x0 = (t - ty0 * tiles_x) * kPeTW, y0 = ty0 * TH;
+        const int x = x0 + lx;
+#pragma unroll
+        for (int i = 0; i < TH / 4; i++) {
+            const int ty = tq + 4 * i, y = y0 + ty;
+            const ofxcv_f4 *v = sV + ty * CW + lx + N;
+            const ofxcv_f4 c = v[0];
+            const float g0 = g[0];
+            double b1 = c.x * g0, b2 = 0, b3 = c.y * g0, b4 = 0, b5 = c.w * g0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; k++) {
+                const ofxcv_f4 A = v[k], B = v[-k];
+                const double tg = A.x + B.x;
+                const ofxcv_f2 d = (ofxcv_f2{A.x, A.y} - ofxcv_f2{B.x, B.y}) * xg[k];
+                const ofxcv_f2 sm = (ofxcv_f2{A.z, A.w} + ofxcv_f2{B.z, B.w}) * g[k];
+                b1 += tg * g[k];
+                b4 += tg * xxg[k];
+                b2 += d.x;
+                b3 += sm.x;
+                b6 += d.y;
+                b5 += sm.y;
+            }
+            if (x < w && y < h) {
+                const size_t o = (size_t)y * pitch + x;
+                R[o + 1 * plane] = (float)(b2 * pc.ig11);
+                R[o + 0 * plane] = (float)(b3 * pc.ig11);
+                R[o + 3 * plane] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+                R[o + 2 * plane] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+                R[o + 4 * plane] = (float)(b6 * pc.ig55);
+            }
+        }
+        __syncthreads();
+        t = tn;
+    }
+}
+
 // ------------------------------------------------------------------ F4 update matrices (per pixel)
 
 struct M5 {
@@ -496,9 +606,10 @@ __device__ __forceinline__ float buf_ld(const Buf &b, unsigned voff_bytes, unsig
 __device__ __forceinline__ void buf_st(const Buf &b, float v, unsigned voff_bytes, unsigned soff_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, 0);
 }
-// two horizontally adjacent taps of one plane.  Measured on gfx950 (tools/ubench/l1rate.hip): a coalesced
-// dword wave-load costs ~5 clk of the CU's texture-addresser, a dwordx2 one ~18 clk, so the pair is
-// fetched as two dword loads (the second is an L1 hit on the line the first one brought in).
+// two horizontally adjacent taps of one plane.  Written as two dword loads; the compiler merges each pair into one
+// buffer_load_dwordx2.  Measured on the fused iteration kernel: keeping them apart (20 gather instructions per pixel
+// instead of 10) makes the launch 46 -> 56 us -- for gathers the per-instruction address work dominates, unlike the
+// coalesced streaming loads where a dword wave-load is the cheapest form (tools/ubench/l1rate.hip).
 struct TapPair {
     float a, b;
 };
@@ -829,7 +940,7 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int x0 = tbx * kFtW, y0 = tby * kFtH;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index in an SGPR
     const size_t plane = (size_t)pitch * h;
     const unsigned pb = (unsigned)(plane * 4);
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
@@ -1039,6 +1150,24 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
     int cw = kPeTW + 2 * poly_n, ldw = cw | 1, ih = kPeTH + 2 * poly_n;
     size_t lds = sizeof(float) * ((size_t)ih * ldw + 3 * kPeTH * ldw);
     dim3 grid(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH));
+    if (ctx->fb_polyexp_variant >= 1 && (poly_n == 5 || poly_n == 7)) {
+        const int v = ctx->fb_polyexp_variant;
+        const int th = (v & 1) ? 16 : 8, wgs_per_cu = v <= 2 ? 4 : (v <= 4 ? 5 : 6);
+        const int tiles_x = (int)grid.x, tiles_y = ofxcv_div_up(h, th), ntiles = tiles_x * tiles_y;
+        const int nwg = std::min((ntiles + 7) & ~7, ctx->num_cus * wgs_per_cu & ~7);  // a multiple of the 8 XCDs
+#define OFXCV_LAUNCH_PE(N, TH) \
+    hipLaunchKernelGGL((polyexp_persistent_kernel<N, TH>), dim3(nwg), dim3(256), 0, s, d_I, w, h, d_R, plane_pitch(w), pc, tiles_x, ntiles)
+        if (poly_n == 5) {
+            if (th == 16) OFXCV_LAUNCH_PE(5, 16);
+            else OFXCV_LAUNCH_PE(5, 8);
+        } else {
+            if (th == 16) OFXCV_LAUNCH_PE(7, 16);
+            else OFXCV_LAUNCH_PE(7, 8);
+        }
+#undef OFXCV_LAUNCH_PE
+        OFXCV_LAUNCH_CHECK(ctx, "polyexp_persistent_kernel");
+        return OFXCV_OK;
+    }
     if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
     else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
     else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);

@@ -13,7 +13,7 @@ out = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_bench"
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob(out + "/p*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
         key = (name[:40], r["Grid_Size"], r["Counter_Name"])
         agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
 with open(out + "/summary.txt", "w") as fo:
