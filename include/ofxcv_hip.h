@@ -74,7 +74,11 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
  * iterations, poly_n, poly_sigma, flags) at VectorGenerator/VectorGenerator.cpp:403
  * (the copyMakeBorder calls at :387-388 pad by zero pixels and are the identity).
  * prev/next: 8-bit single channel, flow: 2-channel interleaved f32 (CV_32FC2), all in HBM.
- * Only flags == 0 is supported (the reference hard-codes 0). */
+ * flags: 0 (what the reference passes), OFXCV_OPTFLOW_USE_INITIAL_FLOW (d_flow is read as the
+ * initial flow: INTER_AREA-resized to the top pyramid level), OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN
+ * (separable Gaussian window instead of the box), or both; anything else is UNSUPPORTED. */
+#define OFXCV_OPTFLOW_USE_INITIAL_FLOW 4     /* cv::OPTFLOW_USE_INITIAL_FLOW */
+#define OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN 256 /* cv::OPTFLOW_FARNEBACK_GAUSSIAN */
 int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step,
                                       const uint8_t *d_next, size_t next_step, float *d_flow,
                                       size_t flow_step, int width, int height, double pyr_scale,

@@ -51,6 +51,9 @@ def lib():
 
 
 # every symbol include/ofxcv_hip.h declares (checked by tests/test_abi.py)
+OPTFLOW_USE_INITIAL_FLOW = 4      # cv::OPTFLOW_USE_INITIAL_FLOW: `flow` is read as the initial flow
+OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian window instead of the box
+
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
     "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",

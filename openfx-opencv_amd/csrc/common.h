@@ -24,7 +24,7 @@ constexpr int kFbGraphSlots = 4;
 struct FbGraphKey {
     const void *prev, *next, *flow;
     size_t prev_step, next_step, flow_step;
-    int width, height, levels, winsize, iterations, poly_n;
+    int width, height, levels, winsize, iterations, poly_n, flags, pad_;
     double pyr_scale, poly_sigma;
     const void *planes, *tmp, *cflow, *vsum;  // scratch addresses baked into the graph
 };

@@ -1024,6 +1024,142 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------ OPTFLOW_FARNEBACK_GAUSSIAN window
+//
+// FarnebackUpdateFlow_GaussianBlur: separable Gaussian window (sigma = (winsize/2) * 0.3), both passes accumulate in
+// f32 in the reference's order  v = c*k[0]; for i = 1..m: v += (plus_i + minus_i) * k[i],  borders replicated.  Two
+// kernels per iteration: the vertical pass writes its five sums per pixel to a scratch field, the horizontal pass
+// finishes the window, solves and (UPDATE) evaluates the next M in the same pass.
+constexpr int kMaxWinTaps = 64;  // winsize <= 127
+struct WinTaps {
+    int m;
+    float k[kMaxWinTaps];
+};
+
+__global__ __launch_bounds__(256) void gauss_vpass_kernel(const float *__restrict__ M, int w, int h, int pitch, WinTaps t, float *__restrict__ V) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x = tbx * 64 + threadIdx.x, y = tby * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)pitch * h;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *P = M + c * plane + x;
+        float v = P[(size_t)y * pitch] * t.k[0];
+        for (int i = 1; i <= t.m; i++) v += (P[(size_t)min(y + i, h - 1) * pitch] + P[(size_t)max(y - i, 0) * pitch]) * t.k[i];
+        V[c * plane + (size_t)y * pitch + x] = v;
+    }
+}
+
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void gauss_hpass_solve_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                                const float *__restrict__ V, float *__restrict__ Mout,
+                                                                float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
+                                                                WinTaps t) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int x = tbx * 64 + threadIdx.x, y = tby * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t plane = (size_t)pitch * h;
+    float sum[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const float *row = V + c * plane + (size_t)y * pitch;
+        float v = row[x] * t.k[0];
+        for (int i = 1; i <= t.m; i++) v += (row[min(x + i, w - 1)] + row[max(x - i, 0)]) * t.k[i];
+        sum[c] = v;
+    }
+    const double g11 = sum[0], g12 = sum[1], g22 = sum[2], h1 = sum[3], h2 = sum[4];
+    const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    const float fxv = (float)((g11 * h2 - g12 * h1) * idet), fyv = (float)((g22 * h1 - g12 * h2) * idet);
+    if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
+    if (UPDATE) {
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        const size_t o = (size_t)y * pitch + x;
+#pragma unroll
+        for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
+    }
+}
+
+// ------------------------------------------------------------------ OPTFLOW_USE_INITIAL_FLOW
+//
+// Top pyramid level: flow = resize(flow0, level size, INTER_AREA) * scale (imgproc resize.cpp, f32, shrinking).
+// Integer factors: ResizeAreaFast_ (row-major cell sum, four at a time, times 1/area); other factors: ResizeArea_ with
+// the computeResizeAreaTab weights.  One thread per destination pixel, both channels.
+struct AreaTaps {
+    int first;          // first source cell
+    int n;              // number of cells
+    float a0, am, a1;   // weight of the first, the middle and the last cell
+    bool has0, has1;    // partial first / last cell present
+};
+__device__ __forceinline__ void area_taps(int d, int ssize, double scale, int &sx1, int &sx2, bool &left, float &al, float &am, bool &right, float &ar) {
+    const double f1 = d * scale, f2 = f1 + scale;
+    const double cell = fmin(scale, ssize - f1);
+    sx1 = (int)ceil(f1);
+    sx2 = min((int)floor(f2), ssize - 1);
+    sx1 = min(sx1, sx2);
+    left = sx1 - f1 > 1e-3;
+    al = (float)((sx1 - f1) / cell);
+    am = (float)(1.0 / cell);
+    right = f2 - sx2 > 1e-3;
+    ar = (float)(fmin(fmin(f2 - sx2, 1.), cell) / cell);
+}
+
+__global__ __launch_bounds__(256) void initial_flow_kernel(const float *__restrict__ flow0, size_t flow0_step, int W, int H,
+                                                           float *__restrict__ dst, int w, int h, double mul) {
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx >= w || dy >= h) return;
+    auto src = [&](int sy, int sx, int c) { return ((const float *)((const char *)flow0 + (size_t)sy * flow0_step))[(size_t)sx * 2 + c]; };
+    float out[2];
+    if (W == w && H == h) {
+        out[0] = src(dy, dx, 0);
+        out[1] = src(dy, dx, 1);
+    } else {
+        const double scale_x = (double)W / w, scale_y = (double)H / h;
+        const int ix = (int)scale_x, iy = (int)scale_y;
+        if (fabs(scale_x - ix) < DBL_EPSILON && fabs(scale_y - iy) < DBL_EPSILON) {
+            const int area = ix * iy;
+            const float scale = 1.f / area;
+            for (int c = 0; c < 2; c++) {
+                auto S = [&](int k) { return src(dy * iy + k / ix, dx * ix + k % ix, c); };
+                float sum = 0;
+                int k = 0;
+                for (; k <= area - 4; k += 4) sum += S(k) + S(k + 1) + S(k + 2) + S(k + 3);
+                for (; k < area; k++) sum += S(k);
+                out[c] = sum * scale;
+            }
+        } else {
+            int x1, x2, y1, y2;
+            bool xl, xr, yl, yr;
+            float xal, xam, xar, yal, yam, yar;
+            area_taps(dx, W, scale_x, x1, x2, xl, xal, xam, xr, xar);
+            area_taps(dy, H, scale_y, y1, y2, yl, yal, yam, yr, yar);
+            for (int c = 0; c < 2; c++) {
+                auto hrow = [&](int sy) {
+                    float buf = 0;
+                    if (xl) buf = buf + src(sy, x1 - 1, c) * xal;
+                    for (int sx = x1; sx < x2; sx++) buf = buf + src(sy, sx, c) * xam;
+                    if (xr) buf = buf + src(sy, x2, c) * xar;
+                    return buf;
+                };
+                float sum = 0;
+                bool first = true;
+                auto vadd = [&](int sy, float beta) {
+                    const float b = hrow(sy);
+                    sum = first ? beta * b : sum + beta * b;
+                    first = false;
+                };
+                if (yl) vadd(y1 - 1, yal);
+                for (int sy = y1; sy < y2; sy++) vadd(sy, yam);
+                if (yr) vadd(y2, yar);
+                out[c] = sum;
+            }
+        }
+    }
+    dst[((size_t)dy * w + dx) * 2] = (float)(out[0] * mul);
+    dst[((size_t)dy * w + dx) * 2 + 1] = (float)(out[1] * mul);
+}
+
 // ------------------------------------------------------------------ OpenCV-rounding mode of the box window
 //
 // FarnebackUpdateFlow_Blur keeps a running vertical sum per column and channel,
@@ -1223,6 +1359,33 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     return OFXCV_OK;
 }
 
+int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
+                           size_t flow_step, int w, int h, int winsize, bool update) {
+    WinTaps t;
+    t.m = winsize / 2;
+    if (t.m + 1 > kMaxWinTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "Gaussian window of %d exceeds %d", winsize, 2 * kMaxWinTaps - 1);
+    const double sigma = t.m * 0.3;
+    double sum = 1.;
+    t.k[0] = 1.f;
+    for (int i = 1; i <= t.m; i++) {
+        t.k[i] = (float)std::exp(-i * i / (2 * sigma * sigma));
+        sum += t.k[i] * 2;
+    }
+    sum = 1. / sum;
+    for (int i = 0; i <= t.m; i++) t.k[i] = (float)(t.k[i] * sum);
+    const int pitch = plane_pitch(w);
+    float *V = (float *)ctx->fb_vsum.ptr;  // reserved by the caller
+    dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+    hipLaunchKernelGGL(gauss_vpass_kernel, grid, block, 0, s, Min, w, h, pitch, t, V);
+    OFXCV_LAUNCH_CHECK(ctx, "gauss_vpass_kernel");
+    if (update)
+        hipLaunchKernelGGL(gauss_hpass_solve_kernel<true>, grid, block, 0, s, R0, R1, (const float *)V, Mout, flow, flow_step, w, h, pitch, t);
+    else
+        hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, R0, R1, (const float *)V, Mout, flow, flow_step, w, h, pitch, t);
+    OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
+    return OFXCV_OK;
+}
+
 // two fused iterations M -> M'' (winsize 3 only)
 int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
                           bool level0) {
@@ -1298,7 +1461,7 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
 // is 127 workgroups on 256 CUs), so their iterations overlap with the preparation of the finer levels.
 static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, const uint8_t *const img[2], const size_t step[2],
                              float *d_flow, size_t flow_step, int width, int height, double pyr_scale, int levels, int winsize,
-                             int iterations, int poly_n, double poly_sigma, bool profile) {
+                             int iterations, int poly_n, double poly_sigma, int flags, bool profile) {
     int rc;
     // scratch carving (sizes were reserved by the caller)
     const size_t field0 = 5 * (size_t)plane_pitch(width) * height;
@@ -1348,7 +1511,21 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
         const int pitch = plane_pitch(w);
         dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-        if (!prev_flow)
+        if (!prev_flow && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
+            // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
+            const float *init = d_flow;
+            size_t init_step = flow_step;
+            if (k > 0) {
+                double scale = 1;
+                for (int i = 0; i < k; i++) scale *= pyr_scale;
+                float *top = cflow[(k & 1) ^ 1];
+                hipLaunchKernelGGL(initial_flow_kernel, grid, block, 0, s, (const float *)d_flow, flow_step, width, height, top, w, h, scale);
+                OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
+                init = top;
+                init_step = (size_t)w * 8;
+            }
+            hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R[k][0], R[k][1], init, init_step, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0]);
+        } else if (!prev_flow)
             hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0]);
         else
             hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, w, h, pitch, Mbuf[0]);
@@ -1356,7 +1533,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         float *out_flow = k == 0 ? d_flow : cflow[k & 1];
         size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
         int cur = 0;
-        const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding;
+        const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
+        const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         for (int i = 0; i < iterations;) {
             const bool pair = fuse && i + 2 <= iterations - 1;
             const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
@@ -1366,7 +1544,10 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                 i += 2;
             } else {
                 bool update = i < iterations - 1;
-                rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                if (gaussian)
+                    rc = launch_gauss_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                else
+                    rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
                 i += 1;
             }
             if (rc) return rc;
@@ -1388,7 +1569,8 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     if (!d_prev || !d_next || !d_flow || width <= 0 || height <= 0 || prev_step < (size_t)width || next_step < (size_t)width ||
         flow_step < (size_t)width * 8 || (flow_step & 7) || (((uintptr_t)d_flow) & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument");
-    if (flags != 0) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: only flags == 0 (box window, no initial flow)");
+    if (flags & ~(OFXCV_OPTFLOW_USE_INITIAL_FLOW | OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN))
+        return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: flags 0x%x not supported (USE_INITIAL_FLOW, FARNEBACK_GAUSSIAN)", flags);
     if (!(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || iterations < 1 || winsize < 1 || !(winsize & 1))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad parameter");
     if ((size_t)plane_pitch(width) * height >= (1u << 28))
@@ -1421,7 +1603,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 4 * (size_t)lw * lh);
         if (rc) return rc;
     }
-    if (ctx->fb_opencv_rounding) {
+    if (ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
         rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * field0);
         if (rc) return rc;
     }
@@ -1435,9 +1617,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     const bool use_graph = !ctx->prof_on && !ctx->fb_no_graph;
     if (!use_graph)
         return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations,
-                                 poly_n, poly_sigma, ctx->prof_on);
-    FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, pyr_scale,
-                      poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr, ctx->fb_opencv_rounding ? ctx->fb_vsum.ptr : nullptr};
+                                 poly_n, poly_sigma, flags, ctx->prof_on);
+    FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, flags, 0,
+                      pyr_scale, poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr,
+                      (ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) ? ctx->fb_vsum.ptr : nullptr};
     FbGraph *g = nullptr;
     for (FbGraph &c : ctx->fb_graphs)
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
@@ -1454,7 +1637,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
-                                   poly_sigma, false);
+                                   poly_sigma, flags, false);
             ok = hipStreamEndCapture(s, &graph) == hipSuccess && rc == OFXCV_OK && graph != nullptr;
             if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
@@ -1464,7 +1647,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
             (void)hipGetLastError();  // clear the sticky capture error
             ctx->fb_no_graph = true;
             return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
-                                     poly_sigma, false);
+                                     poly_sigma, flags, false);
         }
         std::memset(&slot->key, 0, sizeof(slot->key));
         slot->key = key;

@@ -123,13 +123,21 @@ def farneback_pyr_image(img, lw, lh, sigma, ksize):
     return I
 
 
+OPTFLOW_USE_INITIAL_FLOW = 4
+OPTFLOW_FARNEBACK_GAUSSIAN = 256
+
+
 def calc_optical_flow_farneback(prev, nxt, pyr_scale=0.5, levels=3, winsize=3, iterations=15, poly_n=5,
-                                poly_sigma=1.1, flags=0, blur_mode=BLUR_FAITHFUL):
+                                poly_sigma=1.1, flags=0, blur_mode=BLUR_FAITHFUL, initial_flow=None):
     prev = np.ascontiguousarray(prev, np.uint8)
     nxt = np.ascontiguousarray(nxt, np.uint8)
     assert prev.shape == nxt.shape and prev.ndim == 2
     h, w = prev.shape
-    flow = np.empty((h, w, 2), np.float32)
+    if flags & OPTFLOW_USE_INITIAL_FLOW:
+        flow = np.array(initial_flow, np.float32, order="C", copy=True)
+        assert flow.shape == (h, w, 2)
+    else:
+        flow = np.empty((h, w, 2), np.float32)
     f = lib().orc_calc_optical_flow_farneback
     f.restype = C.c_int
     rc = f(_p(prev), _p(nxt), C.c_size_t(w), C.c_int(w), C.c_int(h), _p(flow), C.c_double(pyr_scale),
@@ -138,6 +146,24 @@ def calc_optical_flow_farneback(prev, nxt, pyr_scale=0.5, levels=3, winsize=3, i
     if rc != 0:
         raise ValueError("orc_calc_optical_flow_farneback rc=%d" % rc)
     return flow
+
+
+def update_flow_gaussian(R0, R1, flow, M, winsize, update):
+    """One FarnebackUpdateFlow_GaussianBlur pass; returns (flow, M) copies."""
+    R0 = np.ascontiguousarray(R0, np.float32); R1 = np.ascontiguousarray(R1, np.float32)
+    flow = np.array(flow, np.float32, order="C", copy=True); M = np.array(M, np.float32, order="C", copy=True)
+    h, w, _ = flow.shape
+    lib().orc_update_flow_gaussian(_p(R0), _p(R1), _p(flow), _p(M), C.c_int(w), C.c_int(h), C.c_int(winsize), C.c_int(int(update)))
+    return flow, M
+
+
+def resize_area(src, dw, dh):
+    src = np.ascontiguousarray(src, np.float32)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.float32)
+    lib().orc_resize_area_f32(_p(src), C.c_int(sw), C.c_int(sh), C.c_int(cn), _p(dst), C.c_int(dw), C.c_int(dh))
+    return dst
 
 
 def srgb_lut():

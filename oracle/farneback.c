@@ -453,6 +453,144 @@ void orc_update_flow_blur(const float *R0, const float *R1, float *flow, float *
     else update_flow_blur_faithful(R0, R1, flow, M, w, h, block_size, update_matrices);
 }
 
+/*
+ * optflowgf.cpp FarnebackUpdateFlow_GaussianBlur (flags & OPTFLOW_FARNEBACK_GAUSSIAN): the window is a separable
+ * Gaussian, sigma = (block_size/2) * 0.3, taps normalised in double and stored as float; both passes accumulate in
+ * FLOAT:  v = row[m]*k[0]; for i = 1..m: v += (row[m+i] + row[m-i]) * k[i]   (rows / columns replicated at the
+ * border).  The sums enter the 2x2 solve as they are (the taps already sum to one).  UpdateMatrices follows on row
+ * stripes that the window has left behind, which is the same as updating all rows after the pass.
+ */
+void orc_update_flow_gaussian(const float *R0, const float *R1, float *flow_, float *matM, int width, int height,
+                              int block_size, int update_matrices)
+{
+    const int m = block_size / 2;
+    const double sigma = m * 0.3;
+    double s = 1.;
+    float *kernel = (float *)malloc(sizeof(float) * (size_t)(m + 1));
+    float *vbuf = (float *)malloc(sizeof(float) * (size_t)(width + m * 2 + 2) * 5);
+    float *vsum = vbuf + (m + 1) * 5;
+    kernel[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)exp(-i * i / (2 * sigma * sigma));
+        kernel[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) kernel[i] = (float)(kernel[i] * s);
+
+    for (int y = 0; y < height; y++) {
+        float *flow = flow_ + (size_t)y * width * 2;
+        const float *rc = matM + (size_t)y * width * 5;
+        for (int x = 0; x < width * 5; x++) {
+            float s0 = rc[x] * kernel[0];
+            for (int i = 1; i <= m; i++) {
+                const float *rm = matM + (size_t)(y - i > 0 ? y - i : 0) * width * 5;
+                const float *rp = matM + (size_t)(y + i < height - 1 ? y + i : height - 1) * width * 5;
+                s0 += (rp[x] + rm[x]) * kernel[i];
+            }
+            vsum[x] = s0;
+        }
+        for (int x = 0; x < m * 5; x++) {
+            vsum[-1 - x] = vsum[4 - x];
+            vsum[width * 5 + x] = vsum[width * 5 + x - 5];
+        }
+        for (int x = 0; x < width; x++) {
+            float sum[5];
+            for (int c = 0; c < 5; c++) {
+                float s0 = vsum[x * 5 + c] * kernel[0];
+                for (int i = 1; i <= m; i++) s0 += (vsum[(x + i) * 5 + c] + vsum[(x - i) * 5 + c]) * kernel[i];
+                sum[c] = s0;
+            }
+            double g11 = sum[0], g12 = sum[1], g22 = sum[2], h1 = sum[3], h2 = sum[4];
+            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+    if (update_matrices) orc_update_matrices(R0, R1, flow_, matM, width, height, 0, height);
+    free(kernel);
+    free(vbuf);
+}
+
+/*
+ * imgproc resize(..., INTER_AREA) for f32, as calcOpticalFlowFarneback uses it on the caller's initial flow
+ * (OPTFLOW_USE_INITIAL_FLOW: resize(flow0, flow, top-level size, INTER_AREA); flow *= scale).  Shrinking only.
+ *  - equal sizes: a copy;
+ *  - integer factors (ResizeAreaFast_): float sum over the fx*fy cell, row-major, taken four at a time
+ *    (sum += S0 + S1 + S2 + S3) then singly, times (float)(1/(fx*fy));
+ *  - otherwise (ResizeArea_ with computeResizeAreaTab): per destination index the covered source cells with weights
+ *    [partial left] (ceil(f1) - f1)/cw, full cells 1/cw, [partial right] min(min(f2 - floor(f2), 1), cw)/cw where
+ *    f1 = d*scale, f2 = f1 + scale, cw = min(scale, ssize - f1), partial cells only if wider than 1e-3; a source row
+ *    is reduced horizontally into buf (float, buf += S*alpha from 0), rows are combined as sum = beta*buf for the
+ *    first row of a destination row and sum += beta*buf after.
+ */
+typedef struct { int si; float alpha; } area_tap;
+static int area_taps(int d, int ssize, double scale, area_tap *t)
+{
+    int n = 0;
+    double fsx1 = d * scale, fsx2 = fsx1 + scale;
+    double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    if (sx2 > ssize - 1) sx2 = ssize - 1;
+    if (sx1 > sx2) sx1 = sx2;
+    if (sx1 - fsx1 > 1e-3) { t[n].si = sx1 - 1; t[n++].alpha = (float)((sx1 - fsx1) / cell); }
+    for (int sx = sx1; sx < sx2; sx++) { t[n].si = sx; t[n++].alpha = (float)(1.0 / cell); }
+    if (fsx2 - sx2 > 1e-3) {
+        double a = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+        if (a > cell) a = cell;
+        t[n].si = sx2; t[n++].alpha = (float)(a / cell);
+    }
+    return n;
+}
+
+void orc_resize_area_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh)
+{
+    if (sw == dw && sh == dh) {
+        memcpy(dst, src, sizeof(float) * (size_t)sw * sh * cn);
+        return;
+    }
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    const int ix = (int)scale_x, iy = (int)scale_y;
+    if (fabs(scale_x - ix) < DBL_EPSILON && fabs(scale_y - iy) < DBL_EPSILON) {
+        const int area = ix * iy;
+        const float scale = 1.f / area;
+        int *ofs = (int *)malloc(sizeof(int) * (size_t)area);
+        for (int sy = 0, k = 0; sy < iy; sy++)
+            for (int sx = 0; sx < ix; sx++) ofs[k++] = (sy * sw + sx) * cn;
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    const float *S = src + ((size_t)dy * iy * sw + (size_t)dx * ix) * cn + c;
+                    float sum = 0;
+                    int k = 0;
+                    for (; k <= area - 4; k += 4) sum += S[ofs[k]] + S[ofs[k + 1]] + S[ofs[k + 2]] + S[ofs[k + 3]];
+                    for (; k < area; k++) sum += S[ofs[k]];
+                    dst[((size_t)dy * dw + dx) * cn + c] = sum * scale;
+                }
+        free(ofs);
+        return;
+    }
+    area_tap *xt = (area_tap *)malloc(sizeof(area_tap) * (size_t)(ix + 3)), *yt = (area_tap *)malloc(sizeof(area_tap) * (size_t)(iy + 3));
+    for (int dy = 0; dy < dh; dy++) {
+        int ny = area_taps(dy, sh, scale_y, yt);
+        for (int dx = 0; dx < dw; dx++) {
+            int nx = area_taps(dx, sw, scale_x, xt);
+            for (int c = 0; c < cn; c++) {
+                float sum = 0;
+                for (int j = 0; j < ny; j++) {
+                    const float *S = src + (size_t)yt[j].si * sw * cn + c;
+                    float buf = 0;
+                    for (int k = 0; k < nx; k++) buf = buf + S[(size_t)xt[k].si * cn] * xt[k].alpha;
+                    sum = j == 0 ? yt[j].alpha * buf : sum + yt[j].alpha * buf;
+                }
+                dst[((size_t)dy * dw + dx) * cn + c] = sum;
+            }
+        }
+    }
+    free(xt);
+    free(yt);
+}
+
 /* level clip of FarnebackOpticalFlowImpl::calc: stop before a side drops under min_size=32 */
 int orc_farneback_num_levels(int w, int h, double pyr_scale, int levels)
 {
@@ -492,13 +630,13 @@ void orc_farneback_pyr_image(const uint8_t *img, size_t step, int w, int h,
     free(blur);
 }
 
-/* optflowgf.cpp FarnebackOpticalFlowImpl::calc (CPU path), flags == 0 */
+/* optflowgf.cpp FarnebackOpticalFlowImpl::calc (CPU path); flags: ORC_OPTFLOW_USE_INITIAL_FLOW, ORC_OPTFLOW_FARNEBACK_GAUSSIAN */
 int orc_calc_optical_flow_farneback(const uint8_t *prev, const uint8_t *next, size_t step,
                                     int w, int h, float *flow0,
                                     double pyr_scale, int levels, int winsize, int iterations,
                                     int poly_n, double poly_sigma, int flags, int blur_mode)
 {
-    if (flags != 0 || !(pyr_scale < 1) || w <= 0 || h <= 0) return -1;
+    if ((flags & ~(ORC_OPTFLOW_USE_INITIAL_FLOW | ORC_OPTFLOW_FARNEBACK_GAUSSIAN)) || !(pyr_scale < 1) || w <= 0 || h <= 0) return -1;
     const uint8_t *img[2] = {prev, next};
     levels = orc_farneback_num_levels(w, h, pyr_scale, levels);
 
@@ -506,12 +644,18 @@ int orc_calc_optical_flow_farneback(const uint8_t *prev, const uint8_t *next, si
     int pw = 0, ph = 0;
     for (int k = levels; k >= 0; k--) {
         int width, height, ksz;
-        double sigma;
+        double sigma, scale = 1;
+        for (int i = 0; i < k; i++) scale *= pyr_scale;
         orc_farneback_level_geom(w, h, pyr_scale, k, &width, &height, &sigma, &ksz);
         size_t npx = (size_t)width * height;
         float *flow = k > 0 ? (float *)malloc(sizeof(float) * npx * 2) : flow0;
         if (!prevFlow) {
-            memset(flow, 0, sizeof(float) * npx * 2);
+            if (flags & ORC_OPTFLOW_USE_INITIAL_FLOW) {
+                if (k > 0) orc_resize_area_f32(flow0, w, h, 2, flow, width, height); /* k == 0: flow IS flow0 */
+                for (size_t i = 0; i < npx * 2; i++) flow[i] = (float)(flow[i] * scale);
+            } else {
+                memset(flow, 0, sizeof(float) * npx * 2);
+            }
         } else {
             orc_resize_linear_f32(prevFlow, pw, ph, 2, flow, width, height);
             double mul = 1. / pyr_scale;
@@ -524,8 +668,12 @@ int orc_calc_optical_flow_farneback(const uint8_t *prev, const uint8_t *next, si
             orc_polyexp(I, width, height, R[i], poly_n, poly_sigma);
         }
         orc_update_matrices(R[0], R[1], flow, M, width, height, 0, height);
-        for (int i = 0; i < iterations; i++)
-            orc_update_flow_blur(R[0], R[1], flow, M, width, height, winsize, i < iterations - 1, blur_mode);
+        for (int i = 0; i < iterations; i++) {
+            if (flags & ORC_OPTFLOW_FARNEBACK_GAUSSIAN)
+                orc_update_flow_gaussian(R[0], R[1], flow, M, width, height, winsize, i < iterations - 1);
+            else
+                orc_update_flow_blur(R[0], R[1], flow, M, width, height, winsize, i < iterations - 1, blur_mode);
+        }
         free(R[0]); free(R[1]); free(I); free(M);
         if (prevFlow) free(prevFlow);
         prevFlow = flow;

@@ -80,9 +80,18 @@ void orc_farneback_level_geom(int w, int h, double pyr_scale, int k,
 void orc_farneback_pyr_image(const uint8_t *img, size_t step, int w, int h,
                              int lw, int lh, double sigma, int ksize, float *I);
 
+/* FarnebackUpdateFlow_GaussianBlur (flags & OPTFLOW_FARNEBACK_GAUSSIAN): separable Gaussian window, f32 sums */
+void orc_update_flow_gaussian(const float *R0, const float *R1, float *flow, float *M,
+                              int w, int h, int block_size, int update_matrices);
+/* resize(INTER_AREA) for f32 (shrinking), used on the initial flow */
+void orc_resize_area_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);
+
+#define ORC_OPTFLOW_USE_INITIAL_FLOW   4   /* cv::OPTFLOW_USE_INITIAL_FLOW   */
+#define ORC_OPTFLOW_FARNEBACK_GAUSSIAN 256 /* cv::OPTFLOW_FARNEBACK_GAUSSIAN */
+
 /* cv::calcOpticalFlowFarneback(prev,next,flow,pyr_scale,levels,winsize,iterations,poly_n,poly_sigma,flags)
- * 8-bit single channel inputs with row stride `step`, flow is w*h*2 f32 interleaved.
- * Only flags==0 (box window, no initial flow) is restated.  returns 0 on success. */
+ * 8-bit single channel inputs with row stride `step`, flow is w*h*2 f32 interleaved (read as the initial flow with
+ * ORC_OPTFLOW_USE_INITIAL_FLOW).  blur_mode applies to the box window only.  returns 0 on success. */
 int orc_calc_optical_flow_farneback(const uint8_t *prev, const uint8_t *next, size_t step,
                                     int w, int h, float *flow,
                                     double pyr_scale, int levels, int winsize, int iterations,

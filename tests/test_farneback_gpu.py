@@ -211,3 +211,43 @@ def test_opencv_rounding_mode_single_step_and_1080p(oracle, ofxcv, strict_ctx):
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
     err = np.abs(ref - got)
     assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "max err %g" % err.max()
+
+
+# ---- OPTFLOW_FARNEBACK_GAUSSIAN / OPTFLOW_USE_INITIAL_FLOW ----
+
+@pytest.mark.parametrize("w,h,winsize", [(64, 48, 3), (160, 120, 5), (333, 257, 7), (320, 240, 9)])
+def test_gaussian_window_bit_exact(oracle, ofxcv, gpu_ctx, w, h, winsize):
+    """Both passes of the Gaussian window accumulate in f32 in the reference's order: identical to the oracle."""
+    ga, gb = _gray_pair(oracle, w, h)
+    ref = oracle.calc_optical_flow_farneback(ga, gb, winsize=winsize, flags=oracle.OPTFLOW_FARNEBACK_GAUSSIAN)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), winsize=winsize, flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN)
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("w,h,levels", [(320, 240, 3), (333, 257, 3), (160, 120, 0), (640, 480, 2)])
+def test_initial_flow_bit_exact(oracle, ofxcv, gpu_ctx, w, h, levels):
+    """USE_INITIAL_FLOW: INTER_AREA resize of the caller's flow to the top level (integer factor 320->40, fractional
+    333->42, same size for levels=0), then the usual walk; compared with the oracle's DIRECT evaluation."""
+    ga, gb = _gray_pair(oracle, w, h)
+    rng = np.random.default_rng(3)
+    init = (rng.standard_normal((h, w, 2)) * 2).astype(np.float32)
+    ref = oracle.calc_optical_flow_farneback(ga, gb, levels=levels, iterations=4, flags=oracle.OPTFLOW_USE_INITIAL_FLOW,
+                                             initial_flow=init, blur_mode=oracle.BLUR_DIRECT)
+    flow = _dev(init.copy())
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=flow, levels=levels, iterations=4,
+                                              flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)
+    assert got.data_ptr() == flow.data_ptr()
+    assert np.array_equal(got.cpu().numpy(), ref)
+
+
+def test_both_flags_and_rejected_flags(oracle, ofxcv, gpu_ctx):
+    w, h = 200, 150
+    ga, gb = _gray_pair(oracle, w, h)
+    init = np.full((h, w, 2), 0.5, np.float32)
+    fl = oracle.OPTFLOW_USE_INITIAL_FLOW | oracle.OPTFLOW_FARNEBACK_GAUSSIAN
+    ref = oracle.calc_optical_flow_farneback(ga, gb, winsize=5, iterations=3, flags=fl, initial_flow=init)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=_dev(init.copy()), winsize=5, iterations=3, flags=fl)
+    assert np.array_equal(got.cpu().numpy(), ref)
+    with pytest.raises(ofxcv.OfxcvError) as e:
+        gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flags=1)
+    assert e.value.status == -4  # OFXCV_ERR_UNSUPPORTED

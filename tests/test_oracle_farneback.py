@@ -187,3 +187,56 @@ def test_flow_to_rgba_leaves_unmapped_channels(oracle):
     oracle.flow_to_rgba(flow, dst, [1, 0, 0, 0], [0, 1, 0, 0], 0.5, 0.25)
     assert np.array_equal(dst[..., 0], flow[..., 0] / 0.5) and np.array_equal(dst[..., 1], flow[..., 1] / 0.25)
     assert (dst[..., 2:] == -1.0).all()
+
+
+# ---- OPTFLOW_USE_INITIAL_FLOW / OPTFLOW_FARNEBACK_GAUSSIAN ----
+
+def test_resize_area_integer_factor_is_the_cell_mean(oracle):
+    rng = np.random.default_rng(5)
+    a = rng.random((48, 64, 2), dtype=np.float32)
+    for f in (2, 4, 8):
+        r = oracle.resize_area(a, 64 // f, 48 // f)
+        ref = a.reshape(48 // f, f, 64 // f, f, 2).astype(np.float64).mean(axis=(1, 3))
+        assert np.abs(r - ref).max() < 1e-6
+    assert np.array_equal(oracle.resize_area(a, 64, 48), a)  # equal sizes: a copy
+
+
+def test_resize_area_fractional_factor_weights_sum_to_one(oracle):
+    c = np.full((37, 53), 3.25, np.float32)
+    for (dw, dh) in [(7, 5), (20, 9), (52, 36)]:
+        assert np.abs(oracle.resize_area(c, dw, dh) - 3.25).max() < 1e-5
+    # a horizontal ramp keeps its mean and stays monotone
+    ramp = np.tile(np.arange(53, dtype=np.float32), (37, 1))
+    r = oracle.resize_area(ramp, 7, 5)
+    assert abs(float(r.mean()) - 26.0) < 1e-3 and np.all(np.diff(r[0]) > 0)
+
+
+def test_gaussian_window_taps_are_normalised(oracle):
+    """A constant M field passes the Gaussian window unchanged: the flow is the solve of the constants."""
+    h, w = 24, 32
+    M = np.empty((h, w, 5), np.float32)
+    M[:] = np.array([2.0, 0.5, 3.0, 1.0, -2.0], np.float32)
+    R = np.zeros((h, w, 5), np.float32)
+    for ws in (3, 5, 9):
+        flow, _ = oracle.update_flow_gaussian(R, R, np.zeros((h, w, 2), np.float32), M, ws, False)
+        idet = 1.0 / (2.0 * 3.0 - 0.25 + 1e-3)
+        assert np.allclose(flow[..., 0], (2.0 * -2.0 - 0.5 * 1.0) * idet, rtol=1e-5)
+        assert np.allclose(flow[..., 1], (3.0 * 1.0 - 0.5 * -2.0) * idet, rtol=1e-5)
+
+
+def test_gaussian_flag_and_initial_flow_recover_the_translation(oracle):
+    from openfx_opencv_amd import synth
+    a, b = synth.flow_pair(160, 120)
+    ga, gb = oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
+    u, v = synth.known_flow(160, 120)
+    truth = np.stack([u, v], axis=-1)[24:-24, 24:-24]
+    box = oracle.calc_optical_flow_farneback(ga, gb)
+    gau = oracle.calc_optical_flow_farneback(ga, gb, winsize=5, flags=oracle.OPTFLOW_FARNEBACK_GAUSSIAN)
+    err = lambda f: float(np.abs(f[24:-24, 24:-24] - truth).mean())
+    assert err(gau) < 0.5 and err(box) < 0.5
+    # two iterations on one level from the converged flow stay there; from zero they do not get close
+    warm = oracle.calc_optical_flow_farneback(ga, gb, levels=0, iterations=2, flags=oracle.OPTFLOW_USE_INITIAL_FLOW, initial_flow=box)
+    cold = oracle.calc_optical_flow_farneback(ga, gb, levels=0, iterations=2)
+    assert err(warm) < 0.5 < err(cold)
+    with pytest.raises(ValueError):
+        oracle.calc_optical_flow_farneback(ga, gb, flags=1)

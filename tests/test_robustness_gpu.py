@@ -29,7 +29,7 @@ def test_c_abi_rejects_bad_arguments(ofxcv, gpu_ctx):
     assert call(w=0) == -1 and call(h=-3) == -1                            # sizes
     assert call(pstep=32) == -1 and call(fstep=100) == -1                  # strides smaller than a row / unaligned
     assert call(ps=1.0) == -1 and call(ps=0.0) == -1 and call(it=0) == -1 and call(win=4) == -1
-    assert call(flags=4) == -4 and call(flags=256) == -4                   # USE_INITIAL_FLOW / FARNEBACK_GAUSSIAN: unsupported
+    assert call(flags=1) == -4 and call(flags=4 | 256 | 8) == -4             # only USE_INITIAL_FLOW (4) and FARNEBACK_GAUSSIAN (256) exist
     assert b"flags" in lib.ofxcv_last_error(h)
     assert call(n=99) == -4                                                # poly_n beyond the coefficient tables
     assert lib.ofxcv_ctx_set_option(h, b"no.such.option", 1) == -1
