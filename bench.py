@@ -67,6 +67,25 @@ def cpu_baseline(ga, gb, budget_s=12.0):
                       "oracle/farneback.c single thread, %.1f s" % (n, W, H, el)}
 
 
+def cpu_baseline_all_cores(ga, gb, per_thread=4, max_threads=32):
+    """The same port, one independent frame pair per host thread (ctypes drops the GIL): what the host CPU of this box
+    delivers on the partitioned workload.  SURVEY.md 8(d) asks for the single-thread and the all-cores figure."""
+    import concurrent.futures as cf
+    from oracle import binding as oracle
+    oracle.lib()
+    n_thr = max(1, min(max_threads, os.cpu_count() or 1))
+
+    def work(_):
+        for _ in range(per_thread):
+            oracle.calc_optical_flow_farneback(ga, gb, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0, oracle.BLUR_FAITHFUL)
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(n_thr) as ex:
+        list(ex.map(work, range(n_thr)))
+    el = time.perf_counter() - t0
+    return {"value": n_thr * per_thread / el, "unit": "frame-pairs/s", "cores": n_thr, "kind": "port",
+            "sample": "%d threads x %d Farneback frame pairs at %dx%d, one pair per thread at a time, %.1f s" % (n_thr, per_thread, W, H, el)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +224,7 @@ def main():
             ga = g_a.cpu().numpy()
             gb = g_b.cpu().numpy()
             line["cpu_baseline"] = cpu_baseline(ga, gb)
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ga, gb)
         elif world > 1:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -123,6 +123,15 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
                         const uint8_t *d_mask, ptrdiff_t mask_step, int width, int height, double radius,
                         uint8_t *d_dst, ptrdiff_t dst_step, float *d_t_map, int *d_order_map, void *stream);
 
+/* cvInpaint(src, mask, dst, radius, method) with either method of photo/src/inpaint.cpp.  The reference plugin
+ * hard-codes CV_INPAINT_TELEA (opencv2fx/inpaint/inpaint.cpp:311); CV_INPAINT_NS (Navier-Stokes, icvNSInpaintFMM) is the
+ * other value of that argument: same front march and fill order, colour rule from the isophote direction. */
+#define OFXCV_INPAINT_NS 0
+#define OFXCV_INPAINT_TELEA 1
+int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels,
+                  const uint8_t *d_mask, ptrdiff_t mask_step, int width, int height, double radius, int method,
+                  uint8_t *d_dst, ptrdiff_t dst_step, float *d_t_map, int *d_order_map, void *stream);
+
 /* ---- whole inpaint render() body for host-resident OFX images (noise == 0 path) --------------
  * replaces opencv2fx/inpaint/inpaint.cpp:286-358: RGBA in -> RGBA out, alpha forced to 255.  h_mask_out
  * (optional, width*height) receives the dilated hole mask so the caller can apply the libc-rand() noise of

@@ -51,6 +51,8 @@ def lib():
 
 
 # every symbol include/ofxcv_hip.h declares (checked by tests/test_abi.py)
+INPAINT_NS = 0     # CV_INPAINT_NS
+INPAINT_TELEA = 1  # CV_INPAINT_TELEA
 OPTFLOW_USE_INITIAL_FLOW = 4      # cv::OPTFLOW_USE_INITIAL_FLOW: `flow` is read as the initial flow
 OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian window instead of the box
 
@@ -60,7 +62,7 @@ EXPORTS = [
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
-    "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint_render_host",
+    "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_render_host",
     "ofxcv_pyr_mean_shift_filtering", "ofxcv_segment_render_host",
 ]
 
@@ -200,17 +202,20 @@ class Context:
                    _ptr(mask), C.c_ssize_t(w))
         return mask
 
-    def inpaint_telea(self, src, mask, radius=3.0, maps=False):
-        """Mirror of cvInpaint(src, mask, dst, radius, CV_INPAINT_TELEA); src HxWx{3,4} uint8, mask HxW uint8."""
+    def inpaint(self, src, mask, radius=3.0, method=INPAINT_TELEA, maps=False):
+        """Mirror of cvInpaint(src, mask, dst, radius, method); src HxWx{3,4} uint8, mask HxW uint8."""
         import torch
         h, w, cn = src.shape
         dst = torch.empty_like(src)
         t = torch.empty((h + 2, w + 2), dtype=torch.float32, device=src.device) if maps else None
         order = torch.empty((h, w), dtype=torch.int32, device=src.device) if maps else None
-        self._call(lib().ofxcv_inpaint_telea, _ptr(src), C.c_ssize_t(src.stride(0)), C.c_int(cn), _ptr(mask), C.c_ssize_t(mask.stride(0)),
-                   C.c_int(w), C.c_int(h), C.c_double(radius), _ptr(dst), C.c_ssize_t(dst.stride(0)),
+        self._call(lib().ofxcv_inpaint, _ptr(src), C.c_ssize_t(src.stride(0)), C.c_int(cn), _ptr(mask), C.c_ssize_t(mask.stride(0)),
+                   C.c_int(w), C.c_int(h), C.c_double(radius), C.c_int(method), _ptr(dst), C.c_ssize_t(dst.stride(0)),
                    _ptr(t) if maps else None, _ptr(order) if maps else None)
         return (dst, t, order) if maps else dst
+
+    def inpaint_telea(self, src, mask, radius=3.0, maps=False):
+        return self.inpaint(src, mask, radius, INPAINT_TELEA, maps)
 
     def inpaint_render_host(self, rgba, radius=3.0, dilation=1.0, want_mask=False):
         """Whole inpaint render() body on a host image (numpy HxWx4 uint8)."""

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "ofxcv_hip.h"
@@ -46,6 +47,7 @@ struct ofxcv_ctx {
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
     int fb_polyexp_variant = 5;
     int num_cus = 256;
+    hipStream_t last_stream = nullptr;  // last caller-supplied stream (ofxcv_stream)
     char err[512] = {0};
 
     // F0: 65536-entry 8.8 fixed-point sRGB table (openfx-supportext ofxsLut.h semantics)
@@ -97,8 +99,16 @@ int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes);
     } while (0)
 
 static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
+    if (stream) ctx->last_stream = reinterpret_cast<hipStream_t>(stream);  // may still be using the scratch buffers
     return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->compute;
 }
+
+// Process-wide lock around the operations that must not overlap another thread's stream capture on ROCm 7.2 (the
+// capture itself, device allocations and frees): a capture in flight was seen to be invalidated by them.
+std::mutex &ofxcv_capture_mutex();
+// Waits for everything this context has in flight (its own streams and the last caller-supplied one); never a
+// device-wide synchronisation, which would stall -- and invalidate the captures of -- other contexts' threads.
+int ofxcv_ctx_quiesce(ofxcv_ctx *ctx);
 
 static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
 

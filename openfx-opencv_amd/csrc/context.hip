@@ -14,10 +14,24 @@ int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
+std::mutex &ofxcv_capture_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
+    hipStream_t streams[] = {ctx->compute, ctx->copy, ctx->prep, ctx->last_stream};
+    for (hipStream_t st : streams)
+        if (st) OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return OFXCV_OK;
+}
+
 int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes) return OFXCV_OK;
+    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
     if (b.ptr) {
-        OFXCV_HIP_CHECK(ctx, hipDeviceSynchronize());
+        int rc = ofxcv_ctx_quiesce(ctx);
+        if (rc) return rc;
         OFXCV_HIP_CHECK(ctx, hipFree(b.ptr));
         b.ptr = nullptr;
         b.bytes = 0;
@@ -109,7 +123,8 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
+    (void)ofxcv_ctx_quiesce(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (FbGraph &g : ctx->fb_graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);

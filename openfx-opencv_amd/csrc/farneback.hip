@@ -21,6 +21,7 @@
 // difference to f32 before accumulating it); here each pixel sums its own 3x3 window in f64.
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1634,6 +1635,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         // its own context: allocations, synchronising copies) must not be able to invalidate this capture.  If the
         // capture cannot be completed anyway, the call falls back to plain launches and stops using graphs.
         hipGraph_t graph = nullptr;
+        // one capture at a time per process, and no device allocation / free / context teardown of another host thread
+        // during it (ofxcv_capture_mutex): either was seen to invalidate a capture on ROCm 7.2.  Launches, copies
+        // and graph replays of other threads stay concurrent.
+        std::unique_lock<std::mutex> capture_lock(ofxcv_capture_mutex());
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
@@ -1642,11 +1647,16 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
             if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
         }
+        capture_lock.unlock();
         if (!ok) {
+            // plain launches from here on, all on the caller's stream (the preparation stream may have been left in
+            // the abandoned capture)
             slot->exec = nullptr;
             (void)hipGetLastError();  // clear the sticky capture error
             ctx->fb_no_graph = true;
-            return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
+            ctx->fb_one_stream = true;
+            ctx->err[0] = 0;
+            return enqueue_farneback(ctx, s, s, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
                                      poly_sigma, flags, false);
         }
         std::memset(&slot->key, 0, sizeof(slot->key));

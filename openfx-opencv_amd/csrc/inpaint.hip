@@ -140,7 +140,7 @@ struct March {
 };
 
 // cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
-void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
+void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_ring, March &m) {
     const int ec = w + 2, er = h + 2;
     const size_t en = (size_t)ec * er;
     m.w = w;
@@ -167,6 +167,9 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
                 outq.push(i, j, 0);
                 m.t[i * ec + j] = 0;
             }
+    int ii, jj;
+    float *t = m.t.data();
+    if (outside_ring) {  // CV_INPAINT_TELEA only; CV_INPAINT_NS leaves T = 1e6 off the band
     // outward distances (negated) on the ring = dilate(mask, (2r+1)^2) - mask - band
     dilate_host(mask, ring, er, ec, range, false);
     bool any_ring = false;
@@ -177,8 +180,6 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
     if (!any_ring) return;  // Out->Init fails in the reference: cvInpaint returns without filling
     for (size_t i = 0; i < en; i++) ring[i] = ring[i] > band[i] ? ring[i] - band[i] : 0;
     zero_frame(ring, er, ec);
-    int ii, jj;
-    float *t = m.t.data();
     {
         uint8_t *f = ring.data();
         while (outq.pop(ii, jj)) {
@@ -196,6 +197,7 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, March &m) {
         }
         for (size_t i = 0; i < en; i++)
             if (f[i] == CHANGE) t[i] = -t[i];
+    }
     }
     // inward front over the hole; the reference passes `mask` ({KNOWN, INSIDE}) as the flag map
     for (size_t i = 0; i < en; i++)
@@ -345,7 +347,11 @@ __global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__rest
 
 // LDSWIN: the (2r+3)^2 neighbourhood of the pixel is staged in LDS (range <= kMaxLdsRange); otherwise every
 // access goes to global memory (any range up to 100).
-template <bool LDSWIN>
+//
+// NS: the colour rule of icvNSInpaintFMM instead of icvTeleaInpaintFMM (weights from the isophote direction, built
+// from absolute byte differences, no level-set term): per channel the accumulators are Ia (lanes 0..2) and the weight
+// sum s (lanes 3..5); everything else -- fill order, dependency levels, staging, ordered accumulation -- is shared.
+template <bool LDSWIN, bool NS>
 __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     __shared__ float s_terms[kFillWaves][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
     __shared__ float s_acc[kFillWaves][kAcc];
@@ -409,7 +415,8 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     if (!d_in) gTy = !u_in ? (TT(i + 1, j) - TT(i - 1, j)) * 0.5f : (TT(i + 1, j) - Tij);
                     else gTy = !u_in ? (Tij - TT(i - 1, j)) : 0.f;
                 }
-                float run = lane == kAcc - 1 ? 1.0e-20f : 0.f;  // lanes 0..9: the sequential accumulator they own
+                // lanes 0..9: the sequential accumulator they own (s starts at 1e-20)
+                float run = (NS ? (lane >= 3 && lane < 6) : lane == kAcc - 1) ? 1.0e-20f : 0.f;
                 for (int t0 = 0; t0 < ntap; t0 += 64) {
                     // phase 1: one window tap per lane
                     float term[kAcc];
@@ -423,6 +430,29 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                             const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
                             const float ry = (float)(i - k), rx = (float)(j - l);
                             const float vl = rx * rx + ry * ry;
+                            if (NS) {
+                                const float dst = 1 / (vl * vl + 1);
+                                const bool r_in = ORD(k, l + 1) >= o, l_in = ORD(k, l - 1) >= o;
+                                const bool d_in = ORD(k + 1, l) >= o, u_in = ORD(k - 1, l) >= o;
+#pragma unroll
+                                for (int ch = 0; ch < 3; ch++) {
+                                    auto I = [&](int r, int c) { return (int)IMG(r, c, ch); };
+                                    float gx, gy;
+                                    if (!d_in) gx = !u_in ? (float)(abs(I(kp + 1, lm) - I(kp, lm)) + abs(I(kp, lm) - I(km - 1, lm)))
+                                                          : (float)(abs(I(kp + 1, lm) - I(kp, lm))) * 2.0f;
+                                    else gx = !u_in ? (float)(abs(I(kp, lm) - I(km - 1, lm))) * 2.0f : 0.f;
+                                    if (!r_in) gy = !l_in ? (float)(abs(I(km, lp + 1) - I(km, lm)) + abs(I(km, lm) - I(km, lm - 1)))
+                                                          : (float)(abs(I(km, lp + 1) - I(km, lm))) * 2.0f;
+                                    else gy = !l_in ? (float)(abs(I(km, lm) - I(km, lm - 1))) * 2.0f : 0.f;
+                                    gx = -gx;
+                                    float dir = rx * gx + ry * gy;
+                                    if (fabs(dir) <= 0.01) dir = 0.000001f;
+                                    else dir = (float)fabs((rx * gx + ry * gy) / sqrt((double)(vl * (gx * gx + gy * gy))));
+                                    const float wgt = dst * dir;
+                                    term[ch] = wgt * IMG(km, lm, ch);
+                                    term[3 + ch] = wgt;
+                                }
+                            } else {
                             const float dst = (float)(1. / (vl * sqrt((double)vl)));
                             const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
                             float dir = rx * gTx + ry * gTy;
@@ -442,6 +472,7 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                                 term[6 + ch] = wgt * (gIy * ry);
                             }
                             term[9] = wgt;
+                            }
                         }
                     }
 #pragma unroll
@@ -449,7 +480,7 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     wave_lds_sync();
                     // phase 2: lane q adds this chunk's terms of accumulator q in tap (row-major) order
                     if (lane < kAcc) {
-                        const bool minus = lane >= 3 && lane < 9;  // Jx, Jy are accumulated with -=
+                        const bool minus = !NS && lane >= 3 && lane < 9;  // Telea: Jx, Jy are accumulated with -=
                         const int lim = min(64, ntap - t0);
                         int tt = 0;
                         for (; tt + 8 <= lim; tt += 8) {  // batches of independent LDS reads, then the ordered adds
@@ -470,7 +501,11 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 wave_lds_sync();
                 // phase 3: lane ch finishes channel ch, lane 0 stores the pixel as one dword
                 uint32_t byte = 0;
-                if (lane < 3) {
+                if (NS && lane < 3) {
+                    const float Ia = s_acc[wave][lane], sw = s_acc[wave][3 + lane];
+                    int iv = (int)rint((double)Ia / sw);  // saturate_cast<uchar>(double)
+                    byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+                } else if (lane < 3) {
                     const float Ia = s_acc[wave][lane], Jx = s_acc[wave][3 + lane], Jy = s_acc[wave][6 + lane], sw = s_acc[wave][9];
                     const float sat = (float)((Ia / sw + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
                     int iv = (int)rintf(sat);  // cvRound, then saturate
@@ -525,9 +560,19 @@ int ofxcv_inpaint_mask(ofxcv_ctx *ctx, const uint8_t *d_rgba, ptrdiff_t row_byte
 int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels, const uint8_t *d_mask,
                         ptrdiff_t mask_step, int width, int height, double radius, uint8_t *d_dst, ptrdiff_t dst_step,
                         float *d_t_map, int *d_order_map, void *stream) {
+    return ofxcv_inpaint(ctx, d_src, src_step, channels, d_mask, mask_step, width, height, radius, OFXCV_INPAINT_TELEA, d_dst, dst_step,
+                         d_t_map, d_order_map, stream);
+}
+
+int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels, const uint8_t *d_mask,
+                  ptrdiff_t mask_step, int width, int height, double radius, int method, uint8_t *d_dst, ptrdiff_t dst_step,
+                  float *d_t_map, int *d_order_map, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     if (!d_src || !d_mask || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || d_src == d_dst)
-        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_telea: bad argument");
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint: bad argument");
+    if (method != OFXCV_INPAINT_NS && method != OFXCV_INPAINT_TELEA)
+        return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "inpaint: method %d (CV_INPAINT_NS = 0, CV_INPAINT_TELEA = 1)", method);
+    const bool ns = method == OFXCV_INPAINT_NS;
     hipStream_t s = ofxcv_stream(ctx, stream);
     int range = ofxcv_cv_round(radius);
     range = std::min(std::max(range, 1), 100);
@@ -541,7 +586,7 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
 
     March m;
-    march_front(mask.data(), w, h, range, m);
+    march_front(mask.data(), w, h, range, !ns, m);
     build_levels(m);
     const int n = (int)m.pix.size();
 
@@ -591,10 +636,13 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
         fa.lvl_ord = (const int *)(dp + off_po);
         fa.lvl_off = (const int *)(dp + off_lo);
         fa.comp_off = (const int *)(dp + off_co);
-        if (range <= kMaxLdsRange)
-            hipLaunchKernelGGL(telea_fill_kernel<true>, dim3(ncomp), dim3(kFillThreads), 0, s, fa);
-        else
-            hipLaunchKernelGGL(telea_fill_kernel<false>, dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+        if (range <= kMaxLdsRange) {
+            if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+            else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+        } else {
+            if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+            else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+        }
         OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
         if (channels == 4)
             hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);

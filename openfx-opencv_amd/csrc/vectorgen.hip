@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ fl
 
 int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_pinned_bytes) return OFXCV_OK;
+    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
     if (ctx->h_pinned) {
+        int rc = ofxcv_ctx_quiesce(ctx);
+        if (rc) return rc;
         OFXCV_HIP_CHECK(ctx, hipHostFree(ctx->h_pinned));
         ctx->h_pinned = nullptr;
         ctx->h_pinned_bytes = 0;

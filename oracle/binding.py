@@ -202,8 +202,12 @@ def inpaint_mask(rgba, dilate_iters=1):
     return mask
 
 
-def inpaint_telea(rgb, mask, radius=3.0, maps=False):
-    """cvInpaint(rgb, mask, out, radius, CV_INPAINT_TELEA); maps=True also returns (t, f, order)."""
+INPAINT_NS = 0
+INPAINT_TELEA = 1
+
+
+def inpaint(rgb, mask, radius=3.0, method=INPAINT_TELEA, maps=False):
+    """cvInpaint(rgb, mask, out, radius, method); maps=True also returns (t, f, order)."""
     rgb = np.ascontiguousarray(rgb, np.uint8)
     mask = np.ascontiguousarray(mask, np.uint8)
     h, w, _ = rgb.shape
@@ -211,10 +215,16 @@ def inpaint_telea(rgb, mask, radius=3.0, maps=False):
     t = np.empty((h + 2, w + 2), np.float32)
     f = np.empty((h + 2, w + 2), np.uint8)
     order = np.empty((h, w), np.int32)
-    fn = lib().orc_inpaint_telea
+    fn = lib().orc_inpaint
     fn.restype = C.c_int
-    fn(_p(rgb), _p(mask), C.c_int(w), C.c_int(h), C.c_double(radius), _p(out), _p(t), _p(f), _p(order))
+    rc = fn(_p(rgb), _p(mask), C.c_int(w), C.c_int(h), C.c_double(radius), C.c_int(method), _p(out), _p(t), _p(f), _p(order))
+    if rc != 0:
+        raise ValueError("orc_inpaint rc=%d" % rc)
     return (out, t, f, order) if maps else out
+
+
+def inpaint_telea(rgb, mask, radius=3.0, maps=False):
+    return inpaint(rgb, mask, radius, INPAINT_TELEA, maps)
 
 
 def inpaint_render(rgba, radius=3.0, dilation=1.0):

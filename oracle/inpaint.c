@@ -162,8 +162,9 @@ static void calc_fmm_negate(uint8_t *f, float *t, Heap *hp, int erows, int ecols
 
 #define IMG(r, c, ch) ((float)out[((size_t)(r) * w + (c)) * 3 + (ch)])
 
-/* photo/src/inpaint.cpp icvTeleaInpaintFMM, 3-channel branch */
-static void telea_fmm(uint8_t *f, float *t, uint8_t *out, int w, int h, int range, Heap *hp, int32_t *order)
+/* photo/src/inpaint.cpp icvTeleaInpaintFMM (method 1) / icvNSInpaintFMM (method 0), 3-channel branches: the same
+ * front march, a different colour rule for the pixel that has just received its T */
+static void inpaint_fmm(uint8_t *f, float *t, uint8_t *out, int w, int h, int range, Heap *hp, int32_t *order, int method)
 {
     const int erows = h + 2, ecols = w + 2;
     int ii, jj, filled = 0;
@@ -182,7 +183,51 @@ static void telea_fmm(uint8_t *f, float *t, uint8_t *out, int w, int h, int rang
             t[i * ecols + j] = dist;
 #define F(a, b) f[(a) * ecols + (b)]
 #define T(a, b) t[(a) * ecols + (b)]
-            for (int color = 0; color <= 2; color++) {
+            for (int color = 0; method == ORC_INPAINT_NS && color <= 2; color++) {
+                /* icvNSInpaintFMM: weights from the isophote direction (gradient rotated by 90 degrees, taken from
+                 * absolute byte differences), no level-set term; VectorLength() is the squared length as in Telea */
+                float Ia = 0, s = 1.0e-20f, wgt, dst, dir, gx, gy, rx, ry;
+#define IMGI(r, c, ch) ((int)out[((size_t)(r) * w + (c)) * 3 + (ch)])
+                for (int k = i - range; k <= i + range; k++) {
+                    int km = k - 1 + (k == 1), kp = k - 1 - (k == erows - 2);
+                    for (int l = j - range; l <= j + range; l++) {
+                        int lm = l - 1 + (l == 1), lp = l - 1 - (l == ecols - 2);
+                        if (!(k > 0 && l > 0 && k < erows - 1 && l < ecols - 1)) continue;
+                        if (F(k, l) == INSIDE || (l - j) * (l - j) + (k - i) * (k - i) > range * range) continue;
+                        ry = (float)(i - k);
+                        rx = (float)(j - l);
+                        float vl = rx * rx + ry * ry;
+                        dst = 1 / (vl * vl + 1);
+                        if (F(k + 1, l) != INSIDE) {
+                            if (F(k - 1, l) != INSIDE)
+                                gx = (float)(abs(IMGI(kp + 1, lm, color) - IMGI(kp, lm, color)) + abs(IMGI(kp, lm, color) - IMGI(km - 1, lm, color)));
+                            else gx = (float)(abs(IMGI(kp + 1, lm, color) - IMGI(kp, lm, color))) * 2.0f;
+                        } else {
+                            if (F(k - 1, l) != INSIDE) gx = (float)(abs(IMGI(kp, lm, color) - IMGI(km - 1, lm, color))) * 2.0f;
+                            else gx = 0;
+                        }
+                        if (F(k, l + 1) != INSIDE) {
+                            if (F(k, l - 1) != INSIDE)
+                                gy = (float)(abs(IMGI(km, lp + 1, color) - IMGI(km, lm, color)) + abs(IMGI(km, lm, color) - IMGI(km, lm - 1, color)));
+                            else gy = (float)(abs(IMGI(km, lp + 1, color) - IMGI(km, lm, color))) * 2.0f;
+                        } else {
+                            if (F(k, l - 1) != INSIDE) gy = (float)(abs(IMGI(km, lm, color) - IMGI(km, lm - 1, color))) * 2.0f;
+                            else gy = 0;
+                        }
+                        gx = -gx;
+                        dir = rx * gx + ry * gy;
+                        if (fabs(dir) <= 0.01) dir = 0.000001f;
+                        else dir = (float)fabs((rx * gx + ry * gy) / sqrt((double)(vl * (gx * gx + gy * gy))));
+                        wgt = dst * dir;
+                        Ia += (float)wgt * (float)(IMGI(km, lm, color));
+                        s += wgt;
+                    }
+                }
+#undef IMGI
+                int iv = (int)lrint((double)Ia / s); /* cv::saturate_cast<uchar>(double) */
+                out[((size_t)(i - 1) * w + (j - 1)) * 3 + color] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+            }
+            for (int color = 0; method == ORC_INPAINT_TELEA && color <= 2; color++) {
                 float gradIx, gradIy, gradTx, gradTy, rx, ry;
                 float Ia = 0, Jx = 0, Jy = 0, s = 1.0e-20f, wgt, dst, lev, dir, sat;
                 if (F(i, j + 1) != INSIDE) {
@@ -247,9 +292,10 @@ static void telea_fmm(uint8_t *f, float *t, uint8_t *out, int w, int h, int rang
     }
 }
 
-int orc_inpaint_telea(const uint8_t *rgb, const uint8_t *mask_in, int w, int h, double radius,
-                      uint8_t *out, float *t_map, uint8_t *f_map, int32_t *order)
+int orc_inpaint(const uint8_t *rgb, const uint8_t *mask_in, int w, int h, double radius, int method,
+                uint8_t *out, float *t_map, uint8_t *f_map, int32_t *order)
 {
+    if (method != ORC_INPAINT_NS && method != ORC_INPAINT_TELEA) return -1;
     int range = orc_cv_round(radius);
     if (range < 1) range = 1;
     if (range > 100) range = 100;
@@ -280,24 +326,29 @@ int orc_inpaint_telea(const uint8_t *rgb, const uint8_t *mask_in, int w, int h, 
             if (band[i]) { f[i] = BAND; t[i] = 0; }
             if (mask[i]) f[i] = INSIDE;
         }
-        /* CV_INPAINT_TELEA: distances outside the hole (negative), within `range` of it */
-        dilate_map(mask, ring, erows, ecols, range, 0);
-        int nring = 0;
-        for (size_t i = 0; i < en; i++) {
-            ring[i] = (uint8_t)(ring[i] > mask[i] ? ring[i] - mask[i] : 0);
-            nring += ring[i] != 0;
-        }
-        if (nring > 0) {
-            heap_init(&outq, nring);
-            for (int i = 0; i < erows; i++)
-                for (int j = 0; j < ecols; j++)
-                    if (band[i * ecols + j] != 0) heap_push(&outq, i, j, 0);
-            for (size_t i = 0; i < en; i++) ring[i] = (uint8_t)(ring[i] > band[i] ? ring[i] - band[i] : 0);
-            set_border0(ring, erows, ecols);
-            calc_fmm_negate(ring, t, &outq, erows, ecols);
-            /* the reference passes `mask` (INSIDE where hole, KNOWN elsewhere) as the flag map */
-            telea_fmm(mask, t, out, w, h, range, &hp, order);
-            free(outq.e);
+        if (method == ORC_INPAINT_TELEA) {
+            /* CV_INPAINT_TELEA: distances outside the hole (negative), within `range` of it */
+            dilate_map(mask, ring, erows, ecols, range, 0);
+            int nring = 0;
+            for (size_t i = 0; i < en; i++) {
+                ring[i] = (uint8_t)(ring[i] > mask[i] ? ring[i] - mask[i] : 0);
+                nring += ring[i] != 0;
+            }
+            if (nring > 0) {
+                heap_init(&outq, nring);
+                for (int i = 0; i < erows; i++)
+                    for (int j = 0; j < ecols; j++)
+                        if (band[i * ecols + j] != 0) heap_push(&outq, i, j, 0);
+                for (size_t i = 0; i < en; i++) ring[i] = (uint8_t)(ring[i] > band[i] ? ring[i] - band[i] : 0);
+                set_border0(ring, erows, ecols);
+                calc_fmm_negate(ring, t, &outq, erows, ecols);
+                /* the reference passes `mask` (INSIDE where hole, KNOWN elsewhere) as the flag map */
+                inpaint_fmm(mask, t, out, w, h, range, &hp, order, method);
+                free(outq.e);
+            }
+        } else {
+            /* CV_INPAINT_NS: no outside distances; T stays 1e6 off the band */
+            inpaint_fmm(mask, t, out, w, h, range, &hp, order, method);
         }
         free(hp.e);
     }
@@ -305,6 +356,12 @@ int orc_inpaint_telea(const uint8_t *rgb, const uint8_t *mask_in, int w, int h, 
     if (f_map) memcpy(f_map, mask, en);
     free(mask); free(band); free(ring); free(f); free(t);
     return rc;
+}
+
+int orc_inpaint_telea(const uint8_t *rgb, const uint8_t *mask_in, int w, int h, double radius,
+                      uint8_t *out, float *t_map, uint8_t *f_map, int32_t *order)
+{
+    return orc_inpaint(rgb, mask_in, w, h, radius, ORC_INPAINT_TELEA, out, t_map, f_map, order);
 }
 
 /* cvCvtColor(RGBA2GRAY) 8-bit: (R*4899 + G*9617 + B*1868 + 8192) >> 14 ; threshold BINARY_INV at 0 ; 3x3 rect dilate x iters */

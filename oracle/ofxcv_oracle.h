@@ -115,6 +115,11 @@ void orc_inpaint_mask(const uint8_t *rgba, ptrdiff_t row_bytes, int w, int h, in
 /* cvInpaint(rgb, mask, out, radius, CV_INPAINT_TELEA) on packed 3-channel images.
  * Optional outputs (may be NULL): t_map (h+2)*(w+2) f32 final distance map,
  * f_map (h+2)*(w+2) u8 final flags, order w*h int32 fill order (1-based, 0 = not filled). */
+#define ORC_INPAINT_NS    0 /* CV_INPAINT_NS    (never reachable in the reference plugin: inpaint.cpp:311) */
+#define ORC_INPAINT_TELEA 1 /* CV_INPAINT_TELEA */
+/* cvInpaint(src, mask, dst, radius, method) on 8-bit 3-channel images; maps as for orc_inpaint_telea */
+int orc_inpaint(const uint8_t *rgb, const uint8_t *mask, int w, int h, double radius, int method,
+                uint8_t *out, float *t_map, uint8_t *f_map, int32_t *order);
 int orc_inpaint_telea(const uint8_t *rgb, const uint8_t *mask, int w, int h, double radius,
                       uint8_t *out, float *t_map, uint8_t *f_map, int32_t *order);
 /* full render() body of the inpaint plugin for noise==0: RGBA in -> RGBA out (alpha 255) */

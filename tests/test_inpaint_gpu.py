@@ -103,3 +103,32 @@ def test_telea_large_radius_global_path(oracle, gpu_ctx):
         dst, t, order = gpu_ctx.inpaint_telea(_dev(rgb), _dev(mask), radius, maps=True)
         assert np.array_equal(order.cpu().numpy(), ord_ref) and np.array_equal(t.cpu().numpy(), t_ref)
         assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+# ---- CV_INPAINT_NS: the other value of cvInpaint's method argument ----
+
+@pytest.mark.parametrize("w,h,radius,cn", [(64, 48, 3, 3), (160, 120, 3, 4), (200, 150, 5, 3), (97, 83, 1, 4), (120, 90, 12, 3)])
+def test_ns_maps_and_colours(oracle, ofxcv, gpu_ctx, w, h, radius, cn):
+    fr = _frame(w, h, holes=6)
+    mask = oracle.inpaint_mask(fr, 1)
+    rgb = np.ascontiguousarray(fr[..., :3])
+    ref, t_ref, f_ref, ord_ref = oracle.inpaint(rgb, mask, radius, oracle.INPAINT_NS, maps=True)
+    src = rgb if cn == 3 else fr
+    dst, t, order = gpu_ctx.inpaint(_dev(src), _dev(mask), radius, ofxcv.INPAINT_NS, maps=True)
+    assert np.array_equal(order.cpu().numpy(), ord_ref)
+    assert np.array_equal(t.cpu().numpy(), t_ref)                            # no negated ring: 1e6 off the band
+    got = dst.cpu().numpy()
+    assert np.array_equal(got[..., :3], ref), "colours differ at %d pixels" % (got[..., :3] != ref).any(axis=2).sum()
+    known = mask == 0
+    assert np.array_equal(got[..., :3][known], rgb[known])
+
+
+def test_ns_constant_colour_and_bad_method(oracle, ofxcv, gpu_ctx):
+    c = np.full((40, 50, 3), 77, np.uint8)
+    m = np.zeros((40, 50), np.uint8)
+    m[10:20, 15:30] = 255
+    got = gpu_ctx.inpaint(_dev(c), _dev(m), 3.0, ofxcv.INPAINT_NS).cpu().numpy()
+    assert np.all(got == 77)
+    with pytest.raises(ofxcv.OfxcvError) as e:
+        gpu_ctx.inpaint(_dev(c), _dev(m), 3.0, 7)
+    assert e.value.status == -4

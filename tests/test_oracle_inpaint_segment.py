@@ -1,5 +1,6 @@
 """Known-answer tests pinning the CPU oracle's inpaint and mean-shift restatements (SURVEY.md 8(c) KATs 6-8). CPU only."""
 import numpy as np
+import pytest
 
 
 def test_mask_rule_integer_luma(oracle):
@@ -83,3 +84,26 @@ def test_mean_shift_kats(oracle):
     out = oracle.pyr_mean_shift(noisy, 5, 30, 0)
     assert out.astype(float).std() < 0.5 * noisy.astype(float).std()
     assert out.min() >= noisy.min() and out.max() <= noisy.max()
+
+
+def test_ns_shares_the_front_and_keeps_constant_colour(oracle):
+    """CV_INPAINT_NS: same fill order and inside distances as Telea (the march depends on the mask only), no negated
+    ring outside, and a constant image is reproduced exactly."""
+    from openfx_opencv_amd import synth
+    fr = synth.inpaint_frame(96, 72, n_holes=4)
+    mask = oracle.inpaint_mask(fr, 1)
+    rgb = np.ascontiguousarray(fr[..., :3])
+    a, ta, fa, oa = oracle.inpaint(rgb, mask, 3.0, oracle.INPAINT_TELEA, maps=True)
+    b, tb, fb, ob = oracle.inpaint(rgb, mask, 3.0, oracle.INPAINT_NS, maps=True)
+    assert np.array_equal(oa, ob)
+    inside = mask > 0
+    assert np.array_equal(ta[1:-1, 1:-1][inside], tb[1:-1, 1:-1][inside])
+    assert ta.min() < 0 and tb.min() == 0                                   # Telea marches outwards too, NS does not
+    assert np.array_equal(a[~inside], rgb[~inside]) and np.array_equal(b[~inside], rgb[~inside])
+    assert np.abs(a.astype(int) - b.astype(int))[inside].mean() < 12       # two colour rules, similar fills
+    c = np.full((30, 40, 3), 123, np.uint8)
+    m = np.zeros((30, 40), np.uint8)
+    m[8:14, 10:22] = 255
+    assert np.all(oracle.inpaint(c, m, 3.0, oracle.INPAINT_NS) == 123)
+    with pytest.raises(ValueError):
+        oracle.inpaint(c, m, 3.0, 5)
