@@ -388,6 +388,80 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(const uint8_t *__restr
     I[(size_t)dy * lw + dx] = out;
 }
 
+// Dword form of pyr_direct3_kernel for the two shapes the default pyramid has: k = 0 (same size) and k = 1 when the
+// level is exactly half the frame.  A byte load costs the texture addresser as much per lane as a dword load, and
+// the byte kernel issues 9 (k = 0) or 36 (k = 1) of them per output sample; here a lane reads three aligned dwords
+// per source row -- the four source columns it owns plus the neighbour byte on either side -- and produces four
+// (k = 0) or two (k = 1) horizontally adjacent samples from them: 2.25 / 6 loads per sample.  Lanes whose dwords
+// would cross the image edge take the byte path with reflected columns.  Arithmetic and order as in the byte kernel.
+template <int NTAP>
+__global__ __launch_bounds__(256) void pyr_direct3v_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh,
+                                                           float k0, float k1, float *__restrict__ I) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int c0 = (tbx * 64 + threadIdx.x) * 4;  // first source column of this lane
+    const int dy = tby * 4 + threadIdx.y;
+    if (c0 >= W || dy >= lh) return;
+    constexpr int NR = NTAP == 1 ? 3 : 4;          // source rows: sy-1 .. sy+1 (+ sy+2)
+    const int sy = NTAP == 1 ? dy : 2 * dy;
+    const bool fast = c0 >= 4 && c0 + 8 <= W;
+    float rf[NR][4];  // row-filtered samples at columns c0 .. c0+3
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const uint8_t *S = img + (size_t)reflect101(sy - 1 + r, H) * step;
+        float b[6];  // columns c0-1 .. c0+4
+        if (fast) {
+            const unsigned d0 = *(const unsigned *)(S + c0 - 4), d1 = *(const unsigned *)(S + c0), d2 = *(const unsigned *)(S + c0 + 4);
+            b[0] = (float)(d0 >> 24);
+            b[1] = (float)(d1 & 255u);
+            b[2] = (float)((d1 >> 8) & 255u);
+            b[3] = (float)((d1 >> 16) & 255u);
+            b[4] = (float)(d1 >> 24);
+            b[5] = (float)(d2 & 255u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) b[i] = (float)S[reflect101(min(c0 - 1 + i, W), W)];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) rf[r][j] = b[j + 1] * k0 + (b[j] + b[j + 2]) * k1;
+    }
+    // column filter at source row sy (+ sy+1):  (T[-1] + T[1])*k1 + T[0]*k0
+    if (NTAP == 1) {
+        float *out = I + (size_t)dy * lw + c0;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = (rf[0][j] + rf[2][j]) * k1 + rf[1][j] * k0;
+        if ((lw & 3) == 0 && (((uintptr_t)I) & 15) == 0) {  // c0 is a multiple of 4: one aligned 16-byte store
+            *(float4 *)out = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (c0 + j < lw) out[j] = v[j];
+        }
+    } else {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            t0[j] = (rf[0][j] + rf[2][j]) * k1 + rf[1][j] * k0;
+            t1[j] = (rf[1][j] + rf[3][j]) * k1 + rf[2][j] * k0;
+        }
+        float *out = I + (size_t)dy * lw + (c0 >> 1);
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float r0 = t0[2 * q] * 0.5f + t0[2 * q + 1] * 0.5f, r1 = t1[2 * q] * 0.5f + t1[2 * q + 1] * 0.5f;
+            v[q] = r0 * 0.5f + r1 * 0.5f;
+        }
+        if ((lw & 1) == 0 && (((uintptr_t)I) & 7) == 0) {
+            *(float2 *)out = make_float2(v[0], v[1]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if ((c0 >> 1) + q < lw) out[q] = v[q];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ F3 polynomial expansion
 //
 // One 64x16 output tile per 256-thread block.  The tile of I plus an n-pixel halo is staged in
@@ -1244,6 +1318,14 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     make_gauss_taps(ksize, sigma, gk);
     int ntap = (lw == W && lh == H) ? 1 : 2;
     const bool no_fused = ctx->fb_unfused_pyr;
+    const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && ((uintptr_t)d_img & 3) == 0 && (step & 3) == 0;
+    if (dword_ok && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
+        dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4)), block(64, 4);
+        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, d_img, step, W, H, lw, lh, gk.k[1], gk.k[2], d_I);
+        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, d_img, step, W, H, lw, lh, gk.k[1], gk.k[2], d_I);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3v_kernel");
+        return OFXCV_OK;
+    }
     if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
         hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_img, step, W, H, lw, lh, ntap,
                            gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I);
