@@ -93,7 +93,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
+                    "3840x2160 is configs[4] (64 pairs over 8 GPUs); the PMC traffic figure is only recorded for 1920x1080")
     args = ap.parse_args()
+    global W, H
+    W, H = (int(v) for v in args.size.lower().split("x"))
 
     import numpy as np
     import torch
@@ -196,7 +200,7 @@ def main():
         achieved = ITER_BYTES_PER_PX * W * H / avg_s / 1e9
         alg = algorithmic_bytes_per_pair(W, H)
         line = {
-            "metric": "frames/sec at 1920x1080 f32 (Farneback flow)",
+            "metric": "frames/sec at %dx%d f32 (Farneback flow)" % (W, H),
             "value": value,
             "unit": "frame-pairs/s",
             "n_gpus": world,
@@ -208,12 +212,13 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "VectorGenerator Farneback dense optical flow, 1920x1080 f32 RGBA frame pair resident in HBM "
-                                   "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[2])",
+            "config": {"workload": "VectorGenerator Farneback dense optical flow, %dx%d f32 RGBA frame pair resident in HBM "
+                                   "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[%d])"
+                                   % (W, H, 4 if (W, H) == (3840, 2160) else 2),
                        "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
                        "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(), "kernel": "iterate3x2_kernel<true> (two fused blur+solve+update iterations per launch; <true> = the pyramid level 0 launches, %dx%d)" % (W, H),
+                         "traffic": pmc_traffic() if (W, H) == (1920, 1080) else None, "kernel": "iterate3x2_kernel<true> (two fused blur+solve+update iterations per launch; <true> = the pyramid level 0 launches, %dx%d)" % (W, H),
                          "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n,
                          "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r01_bench_pairs1_kernel_stats.csv)",
                          "avg_launch_us_all_streams_in_flight": (conc_ms / conc_n * 1e3) if conc_n else None},
