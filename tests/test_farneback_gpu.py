@@ -251,3 +251,33 @@ def test_both_flags_and_rejected_flags(oracle, ofxcv, gpu_ctx):
     with pytest.raises(ofxcv.OfxcvError) as e:
         gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flags=1)
     assert e.value.status == -4  # OFXCV_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("kw", [
+    dict(pyr_scale=0.8, levels=4, iterations=3),          # non-dyadic pyramid: generic blur taps, fractional resize
+    dict(pyr_scale=0.6, levels=2, iterations=2, winsize=5),
+    dict(levels=1, iterations=1),                          # a single iteration: no updating pass at all
+    dict(levels=3, iterations=2),                          # one updating + the final pass (no fused pair)
+    dict(levels=3, iterations=6, winsize=7, poly_n=3, poly_sigma=0.9),
+    dict(levels=0, iterations=5),                          # no pyramid
+])
+def test_farneback_parameter_grid_bit_exact(oracle, ofxcv, gpu_ctx, kw):
+    ga, gb = _gray_pair(oracle, 217, 163, seed=7)
+    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT, **kw)
+    assert np.array_equal(got, ref)
+
+
+def test_farneback_unaligned_sources(oracle, ofxcv, gpu_ctx):
+    """Source pointers / strides that are not multiples of 4: the pyramid kernels must take their byte path."""
+    import torch
+    w, h = 320, 240   # level 1 is exactly half: the dword kernel would be eligible with aligned sources
+    ga, gb = _gray_pair(oracle, w, h)
+    buf_a = torch.zeros((h * 323 + 8,), dtype=torch.uint8, device="cuda")
+    buf_b = torch.zeros((h * 321 + 8,), dtype=torch.uint8, device="cuda")
+    pa = buf_a[1:1 + h * 323].view(h, 323)[:, :w]
+    pb = buf_b[3:3 + h * 321].view(h, 321)[:, :w]
+    pa.copy_(_dev(ga))
+    pb.copy_(_dev(gb))
+    got = gpu_ctx.calc_optical_flow_farneback(pa, pb).cpu().numpy()
+    assert np.array_equal(got, oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT))
