@@ -137,6 +137,8 @@ struct March {
     std::vector<int> lvl_ord;  // their order numbers
     std::vector<int> lvl_off;  // CSR offsets per (component, level) segment
     std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
+    // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
+    std::vector<int> cmp_pix, cmp_ord, cmp_off;
 };
 
 // cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
@@ -225,13 +227,13 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
 // colour p can read: window range, +1 for the image-gradient taps, +1 for the row/column-1 sample quirk).
 // Pixels further apart than 2*(range+2) never influence each other: connected groups of occupied coarse
 // cells are independent components, each walked by its own workgroup.
-void build_levels(March &m) {
+void build_levels(March &m, bool dataflow) {
     const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
     const int n = (int)m.pix.size();
     m.level.assign(n, 1);
     std::vector<int> lvl_map((size_t)ec * er, 0);
     const bool windowed = (long)(2 * R + 1) * (2 * R + 1) * n <= 400000000L;
-    for (int k = 0; k < n; k++) {
+    for (int k = 0; k < n && !dataflow; k++) {
         const int p = m.pix[k], i = p / ec, j = p % ec;
         int lv = 0;
         if (windowed) {
@@ -281,6 +283,20 @@ void build_levels(March &m) {
         comp[k] = cell[(size_t)(m.pix[k] / ec / cs) * gw + (m.pix[k] % ec) / cs];
         idx[k] = k;
     }
+    if (dataflow) {  // counting sort by component keeps the fill order inside each component
+        m.cmp_off.assign(ncomp + 1, 0);
+        for (int k = 0; k < n; k++) m.cmp_off[comp[k] + 1]++;
+        for (int c = 0; c < ncomp; c++) m.cmp_off[c + 1] += m.cmp_off[c];
+        std::vector<int> fillp(m.cmp_off.begin(), m.cmp_off.end() - 1);
+        m.cmp_pix.resize(n);
+        m.cmp_ord.resize(n);
+        for (int k = 0; k < n; k++) {
+            const int q = fillp[comp[k]]++;
+            m.cmp_pix[q] = m.pix[k];
+            m.cmp_ord[q] = k + 1;
+        }
+        return;
+    }
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return comp[a] != comp[b] ? comp[a] < comp[b] : m.level[a] < m.level[b]; });
     m.lvl_pix.resize(n);
     m.lvl_ord.resize(n);
@@ -314,7 +330,8 @@ struct FillArgs {
     const uint32_t *src;    // original image
     uint32_t *out;          // image being filled (initialised to src)
     int w, h, range;
-    const int *lvl_pix, *lvl_ord, *lvl_off, *comp_off;
+    const int *lvl_pix, *lvl_ord, *lvl_off, *comp_off;   // level schedule (large radius)
+    const int *cmp_pix, *cmp_ord, *cmp_off;              // dataflow schedule: the pixels of each component in fill order
 };
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between lanes of ONE wavefront
@@ -330,14 +347,14 @@ __global__ __launch_bounds__(256) void pack_rgbx_kernel(const uint8_t *__restric
     const uint8_t *p = src + (ptrdiff_t)y * step + (size_t)x * CN;
     uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (CN == 4 ? (uint32_t)p[3] << 24 : 0u);
     a[(size_t)y * w + x] = v;
-    b[(size_t)y * w + x] = v;
+    b[(size_t)y * w + x] = v & 0x00ffffffu;  // top byte of the working copy: "filled" tag
 }
 template <int CN>
-__global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__restrict__ src, int w, int h, uint8_t *__restrict__ dst,
-                                                          ptrdiff_t step) {
+__global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ alpha, int w, int h,
+                                                          uint8_t *__restrict__ dst, ptrdiff_t step) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
-    uint32_t v = src[(size_t)y * w + x];
+    uint32_t v = (src[(size_t)y * w + x] & 0x00ffffffu) | (alpha[(size_t)y * w + x] & 0xff000000u);
     uint8_t *p = dst + (ptrdiff_t)y * step + (size_t)x * CN;
     p[0] = (uint8_t)v;
     p[1] = (uint8_t)(v >> 8);
@@ -350,7 +367,18 @@ __global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__rest
 //
 // NS: the colour rule of icvNSInpaintFMM instead of icvTeleaInpaintFMM (weights from the isophote direction, built
 // from absolute byte differences, no level-set term): per channel the accumulators are Ia (lanes 0..2) and the weight
-// sum s (lanes 3..5); everything else -- fill order, dependency levels, staging, ordered accumulation -- is shared.
+// sum s (lanes 3..5); everything else -- fill order, staging, ordered accumulation -- is shared.
+//
+// Scheduling.  A filled pixel is written as R | G<<8 | B<<16 | 1<<24: the top byte of `out` is a "filled" tag (0 in the
+// initial copy), so one 4-byte load returns the colour together with the fact that it is final.
+//  * LDSWIN (dataflow): the 16 wavefronts of a workgroup take the pixels of their component round-robin in fill
+//    order.  While staging its neighbourhood a wavefront polls exactly those entries that the sequential algorithm
+//    would have filled before its own pixel (fill-order number smaller than its own) until their tag is set.  Every
+//    pixel a wavefront can wait for has a smaller number, and the smallest unfinished pixel is always being worked on
+//    by its owner without waiting: no deadlock, no barrier, and the cost of a dependency is one store -> load round
+//    trip through the L2 instead of a workgroup-wide level barrier.
+//  * otherwise (radius above kMaxLdsRange): the pixels of a component are grouped into dependency levels by the host
+//    and a workgroup barrier separates the levels.
 template <bool LDSWIN, bool NS>
 __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     __shared__ float s_terms[kFillWaves][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
@@ -361,7 +389,6 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     const int ec = a.w + 2, er = a.h + 2, range = a.range;
     const int side = 2 * range + 1, ntap = side * side, ws = side + 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg_beg = a.comp_off[blockIdx.x], seg_end = a.comp_off[blockIdx.x + 1];
 
     // colour of padded pixel (r,c) as the sequential algorithm sees it while pixel number `o` is filled: the
     // filled value if it was filled earlier (agent-scope load: written by another wave, must not come from a
@@ -373,13 +400,10 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
         return (q != 0 && q < o) ? cur : orig;
     };
 
-    int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
-    for (int seg = seg_beg; seg < seg_end; seg++) {
-        const int end = a.lvl_off[seg + 1];
-        for (int base = beg; base < end; base += kFillWaves) {
-            const int id = base + wave;
-            if (id < end) {  // wave-uniform
-                const int p = a.lvl_pix[id], o = a.lvl_ord[id];
+    // one pixel (padded index p, fill-order number o) by one wavefront
+    auto fill_pixel = [&](const int p, const int o) {
+            {
+                {
                 const int i = p / ec, j = p - i * ec;
                 const int wi0 = i - range - 1, wj0 = j - range - 1;  // padded coordinates of the staged window's corner
                 if (LDSWIN) {
@@ -388,10 +412,24 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                         int q = 0;
                         float tv = 0.f;
                         uint32_t rgb = 0;
+                        const uint32_t *wait_on = nullptr;  // filled before pixel o by the sequential algorithm
                         if (r >= 0 && c >= 0 && r < er && c < ec) {
                             q = a.ord[r * ec + c];
                             tv = a.t[r * ec + c];
-                            if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) rgb = resolve(r, c, q, o);
+                            if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) {
+                                const size_t at = (size_t)(r - 1) * a.w + (c - 1);
+                                if (q != 0 && q < o) wait_on = a.out + at;
+                                else rgb = a.src[at];
+                            }
+                        }
+                        while (wait_on) {  // agent-scope load: straight from the L2, never a stale L1 line
+                            const uint32_t v = __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (v >> 24) {
+                                rgb = v;
+                                wait_on = nullptr;
+                            } else {
+                                __builtin_amdgcn_s_sleep(1);
+                            }
                         }
                         s_word[wave][e] = q;
                         s_wt[wave][e] = tv;
@@ -514,15 +552,32 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 const uint32_t g = __shfl(byte, 1), bl = __shfl(byte, 2);
                 if (lane == 0) {
                     const size_t at = (size_t)(i - 1) * a.w + (j - 1);
-                    a.out[at] = byte | (g << 8) | (bl << 16) | (a.src[at] & 0xff000000u);
+                    __hip_atomic_store(a.out + at, byte | (g << 8) | (bl << 16) | 0x01000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 }
             }
+    };
+
+    if (LDSWIN) {
+        // wavefront v takes pixels v, v + 16, ... of its component's fill order: the smallest unfinished pixel is always the
+        // one its owner is working on (all smaller ones are finished), so the polls below cannot deadlock
+        const int cbeg = a.cmp_off[blockIdx.x], cend = a.cmp_off[blockIdx.x + 1];
+        for (int id = cbeg + wave; id < cend; id += kFillWaves) fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
+    } else {
+        const int seg_beg = a.comp_off[blockIdx.x], seg_end = a.comp_off[blockIdx.x + 1];
+        int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
+        for (int seg = seg_beg; seg < seg_end; seg++) {
+            const int end = a.lvl_off[seg + 1];
+            for (int base = beg; base < end; base += kFillWaves) {
+                const int id = base + wave;
+                if (id < end) fill_pixel(a.lvl_pix[id], a.lvl_ord[id]);  // wave-uniform
+            }
+            beg = end;
+            // every colour of this level is written (one workgroup = one CU; later reads are agent-scope loads that
+            // bypass the L1) before the next level of this component starts
+            __threadfence_block();
+            __syncthreads();
         }
-        beg = end;
-        // every colour of this level is written (one workgroup = one CU; later reads are agent-scope loads that
-        // bypass the L1) before the next level of this component starts
-        __threadfence_block();
-        __syncthreads();
     }
 }
 
@@ -586,8 +641,9 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
 
     March m;
+    const bool dataflow = range <= kMaxLdsRange;
     march_front(mask.data(), w, h, range, !ns, m);
-    build_levels(m);
+    build_levels(m, dataflow);
     const int n = (int)m.pix.size();
 
     if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, m.t.data(), en * sizeof(float), hipMemcpyHostToDevice, s));
@@ -602,19 +658,22 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `order` is a local
     }
     if (n > 0) {
-        const int nseg = (int)m.lvl_off.size(), ncomp = (int)m.comp_off.size() - 1;
+        // schedule arrays: (pixels, order numbers, offsets A, offsets B); dataflow uses only the first three
+        const std::vector<int> &sp = dataflow ? m.cmp_pix : m.lvl_pix, &so = dataflow ? m.cmp_ord : m.lvl_ord;
+        const std::vector<int> &sa = dataflow ? m.cmp_off : m.lvl_off, &sb = dataflow ? m.cmp_off : m.comp_off;
+        const int ncomp = (int)sb.size() - 1;
         const size_t off_t = 0, off_ord = align_up(off_t + en * 4, 256), off_pix = align_up(off_ord + en * 4, 256),
                      off_po = align_up(off_pix + (size_t)n * 4, 256), off_lo = align_up(off_po + (size_t)n * 4, 256),
-                     off_co = align_up(off_lo + (size_t)nseg * 4, 256), total = align_up(off_co + (size_t)(ncomp + 1) * 4, 256);
+                     off_co = align_up(off_lo + sa.size() * 4, 256), total = align_up(off_co + sb.size() * 4, 256);
         int rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
         if (rc) return rc;
         char *dp = (char *)ctx->ip_maps.ptr;
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_t, m.t.data(), en * 4, hipMemcpyHostToDevice, s));
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_ord, m.ord.data(), en * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.lvl_off.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_co, m.comp_off.data(), (size_t)(ncomp + 1) * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, sp.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, so.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_co, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, s));
         rc = ofxcv_reserve(ctx, ctx->ip_work, 2 * (size_t)w * h * 4);
         if (rc) return rc;
         uint32_t *work_src = (uint32_t *)ctx->ip_work.ptr, *work_out = work_src + (size_t)w * h;
@@ -632,9 +691,9 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         fa.w = w;
         fa.h = h;
         fa.range = range;
-        fa.lvl_pix = (const int *)(dp + off_pix);
-        fa.lvl_ord = (const int *)(dp + off_po);
-        fa.lvl_off = (const int *)(dp + off_lo);
+        fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);
+        fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
+        fa.lvl_off = fa.cmp_off = (const int *)(dp + off_lo);
         fa.comp_off = (const int *)(dp + off_co);
         if (range <= kMaxLdsRange) {
             if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
@@ -645,9 +704,9 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         }
         OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
         if (channels == 4)
-            hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);
+            hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
         else
-            hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, w, h, d_dst, dst_step);
+            hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
         OFXCV_LAUNCH_CHECK(ctx, "unpack_rgbx_kernel");
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host vectors above must outlive the copies
     }
