@@ -31,6 +31,7 @@
 namespace {
 
 enum : uint8_t { KNOWN = 0, BAND = 1, INSIDE = 2, CHANGE = 3 };
+constexpr int kFillWavesHost = 16;     // wavefronts per fill workgroup (kFillThreads / 64)
 constexpr int kNeverFilled = INT_MAX;  // hole pixel the march never reaches (image row / column 0)
 
 // ------------------------------------------------------------------ I0-I2 kernels
@@ -139,6 +140,7 @@ struct March {
     std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
     // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
     std::vector<int> cmp_pix, cmp_ord, cmp_off;
+    std::vector<int> cmp_wg;   // per workgroup: {first pixel, end, first wavefront slot, slots in total}
 };
 
 // cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
@@ -295,6 +297,17 @@ void build_levels(March &m, bool dataflow) {
             m.cmp_pix[q] = m.pix[k];
             m.cmp_ord[q] = k + 1;
         }
+        // workgroups per component: a wavefront spends a few microseconds per pixel even when it never waits, so a large
+        // component is spread over up to 8 workgroups (they poll each other's results through the L2)
+        m.cmp_wg.clear();
+        for (int c = 0; c < ncomp; c++) {
+            const int nc = m.cmp_off[c + 1] - m.cmp_off[c];
+            const int g = std::min(8, std::max(1, (nc + 1999) / 2000));
+            for (int r = 0; r < g; r++) {
+                const int rec[4] = {m.cmp_off[c], m.cmp_off[c + 1], r * kFillWavesHost, g * kFillWavesHost};
+                m.cmp_wg.insert(m.cmp_wg.end(), rec, rec + 4);
+            }
+        }
         return;
     }
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return comp[a] != comp[b] ? comp[a] < comp[b] : m.level[a] < m.level[b]; });
@@ -319,6 +332,7 @@ void build_levels(March &m, bool dataflow) {
 
 constexpr int kFillThreads = 1024;             // 16 wavefronts: 16 pixels of a level in flight per workgroup
 constexpr int kFillWaves = kFillThreads / 64;
+static_assert(kFillWaves == kFillWavesHost, "the host schedule assumes 16 wavefronts per workgroup");
 constexpr int kAcc = 10;                       // Ia[3], Jx[3], Jy[3], s
 constexpr int kMaxLdsRange = 5;                // (2r+3)^2 <= 169 neighbourhood entries staged in LDS
 constexpr int kWinMax = (2 * kMaxLdsRange + 3) * (2 * kMaxLdsRange + 3);
@@ -371,8 +385,8 @@ __global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__rest
 //
 // Scheduling.  A filled pixel is written as R | G<<8 | B<<16 | 1<<24: the top byte of `out` is a "filled" tag (0 in the
 // initial copy), so one 4-byte load returns the colour together with the fact that it is final.
-//  * LDSWIN (dataflow): the 16 wavefronts of a workgroup take the pixels of their component round-robin in fill
-//    order.  While staging its neighbourhood a wavefront polls exactly those entries that the sequential algorithm
+//  * LDSWIN (dataflow): a component gets 1..8 workgroups (16 wavefronts each) according to its size; their wavefronts
+//    take the component's pixels round-robin in fill order.  While staging its neighbourhood a wavefront polls exactly those entries that the sequential algorithm
 //    would have filled before its own pixel (fill-order number smaller than its own) until their tag is set.  Every
 //    pixel a wavefront can wait for has a smaller number, and the smallest unfinished pixel is always being worked on
 //    by its owner without waiting: no deadlock, no barrier, and the cost of a dependency is one store -> load round
@@ -407,33 +421,53 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 const int i = p / ec, j = p - i * ec;
                 const int wi0 = i - range - 1, wj0 = j - range - 1;  // padded coordinates of the staged window's corner
                 if (LDSWIN) {
-                    for (int e = lane; e < ws * ws; e += 64) {
-                        const int r = wi0 + e / ws, c = wj0 + e % ws;
-                        int q = 0;
-                        float tv = 0.f;
-                        uint32_t rgb = 0;
-                        const uint32_t *wait_on = nullptr;  // filled before pixel o by the sequential algorithm
-                        if (r >= 0 && c >= 0 && r < er && c < ec) {
-                            q = a.ord[r * ec + c];
-                            tv = a.t[r * ec + c];
-                            if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) {
-                                const size_t at = (size_t)(r - 1) * a.w + (c - 1);
-                                if (q != 0 && q < o) wait_on = a.out + at;
-                                else rgb = a.src[at];
+                    // all loads that do not depend on other pixels' results first (maps, original colours), then the
+                    // polls: the only thing on the dependency chain is the round trip of the awaited colours
+                    constexpr int kEl = (kWinMax + 63) / 64;
+                    int q[kEl];
+                    float tv[kEl];
+                    uint32_t rgb[kEl];
+                    const uint32_t *wait_on[kEl];  // entries the sequential algorithm fills before pixel o
+#pragma unroll
+                    for (int u = 0; u < kEl; u++) {
+                        const int e = lane + 64 * u;
+                        q[u] = 0;
+                        tv[u] = 0.f;
+                        rgb[u] = 0;
+                        wait_on[u] = nullptr;
+                        if (e < ws * ws) {
+                            const int r = wi0 + e / ws, c = wj0 + e % ws;
+                            if (r >= 0 && c >= 0 && r < er && c < ec) {
+                                q[u] = a.ord[r * ec + c];
+                                tv[u] = a.t[r * ec + c];
+                                if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) {
+                                    const size_t at = (size_t)(r - 1) * a.w + (c - 1);
+                                    if (q[u] != 0 && q[u] < o) wait_on[u] = a.out + at;
+                                    else rgb[u] = a.src[at];
+                                }
                             }
                         }
-                        while (wait_on) {  // agent-scope load: straight from the L2, never a stale L1 line
-                            const uint32_t v = __hip_atomic_load(wait_on, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kEl; u++) {
+                        while (wait_on[u]) {  // agent-scope load: straight from the L2, never a stale L1 line
+                            const uint32_t v = __hip_atomic_load(wait_on[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (v >> 24) {
-                                rgb = v;
-                                wait_on = nullptr;
+                                rgb[u] = v;
+                                wait_on[u] = nullptr;
                             } else {
                                 __builtin_amdgcn_s_sleep(1);
                             }
                         }
-                        s_word[wave][e] = q;
-                        s_wt[wave][e] = tv;
-                        s_wrgb[wave][e] = rgb;
+                    }
+#pragma unroll
+                    for (int u = 0; u < kEl; u++) {
+                        const int e = lane + 64 * u;
+                        if (e < ws * ws) {
+                            s_word[wave][e] = q[u];
+                            s_wt[wave][e] = tv[u];
+                            s_wrgb[wave][e] = rgb[u];
+                        }
                     }
                     wave_lds_sync();
                 }
@@ -559,10 +593,12 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     };
 
     if (LDSWIN) {
-        // wavefront v takes pixels v, v + 16, ... of its component's fill order: the smallest unfinished pixel is always the
-        // one its owner is working on (all smaller ones are finished), so the polls below cannot deadlock
-        const int cbeg = a.cmp_off[blockIdx.x], cend = a.cmp_off[blockIdx.x + 1];
-        for (int id = cbeg + wave; id < cend; id += kFillWaves) fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
+        // the wavefronts of all workgroups of a component take its pixels round-robin in fill order: the smallest unfinished
+        // pixel is always the one its owner is working on (all smaller ones are finished), so the polls cannot deadlock
+        // cmp_off holds one record per workgroup: {first pixel, end, this workgroup's first wavefront slot, slots in total}
+        const int cbeg = a.cmp_off[4 * blockIdx.x], cend = a.cmp_off[4 * blockIdx.x + 1];
+        const int first = a.cmp_off[4 * blockIdx.x + 2], stride = a.cmp_off[4 * blockIdx.x + 3];
+        for (int id = cbeg + first + wave; id < cend; id += stride) fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
     } else {
         const int seg_beg = a.comp_off[blockIdx.x], seg_end = a.comp_off[blockIdx.x + 1];
         int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
@@ -660,8 +696,8 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     if (n > 0) {
         // schedule arrays: (pixels, order numbers, offsets A, offsets B); dataflow uses only the first three
         const std::vector<int> &sp = dataflow ? m.cmp_pix : m.lvl_pix, &so = dataflow ? m.cmp_ord : m.lvl_ord;
-        const std::vector<int> &sa = dataflow ? m.cmp_off : m.lvl_off, &sb = dataflow ? m.cmp_off : m.comp_off;
-        const int ncomp = (int)sb.size() - 1;
+        const std::vector<int> &sa = dataflow ? m.cmp_wg : m.lvl_off, &sb = dataflow ? m.cmp_off : m.comp_off;
+        const int ncomp = dataflow ? (int)m.cmp_wg.size() / 4 : (int)sb.size() - 1;  // workgroups to launch
         const size_t off_t = 0, off_ord = align_up(off_t + en * 4, 256), off_pix = align_up(off_ord + en * 4, 256),
                      off_po = align_up(off_pix + (size_t)n * 4, 256), off_lo = align_up(off_po + (size_t)n * 4, 256),
                      off_co = align_up(off_lo + sa.size() * 4, 256), total = align_up(off_co + sb.size() * 4, 256);
