@@ -68,23 +68,25 @@ __global__ __launch_bounds__(256) void dilate_rect_kernel(const uint8_t *__restr
 
 // ------------------------------------------------------------------ I3/I4 front march (host)
 
-struct QElem {
-    float T;
-    unsigned seq;
-    int i, j;
-};
-struct QCmp {  // pop order of CvPriorityQueueFloat: smallest T first, equal T in push order
-    bool operator()(const QElem &a, const QElem &b) const { return a.T > b.T || (a.T == b.T && a.seq > b.seq); }
-};
+// Pop order of CvPriorityQueueFloat: smallest T first, equal T in push order.  T is never negative while it is queued,
+// so its bit pattern orders like its value: one 64-bit key (T bits << 32 | push number) replaces the two-field compare,
+// and the pixel is looked up by push number.
 struct FrontQueue {
-    std::priority_queue<QElem, std::vector<QElem>, QCmp> q;
-    unsigned seq = 0;
-    void push(int i, int j, float T) { q.push(QElem{T, seq++, i, j}); }
+    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> q;
+    std::vector<int> pi, pj;
+    void push(int i, int j, float T) {
+        uint32_t bits;
+        std::memcpy(&bits, &T, 4);
+        q.push(((uint64_t)bits << 32) | (uint32_t)pi.size());
+        pi.push_back(i);
+        pj.push_back(j);
+    }
     bool pop(int &i, int &j) {
         if (q.empty()) return false;
-        i = q.top().i;
-        j = q.top().j;
+        const uint32_t seq = (uint32_t)q.top();
         q.pop();
+        i = pi[seq];
+        j = pj[seq];
         return true;
     }
 };
@@ -140,6 +142,7 @@ struct March {
     std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
     // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
     std::vector<int> cmp_pix, cmp_ord, cmp_off;
+    std::vector<int> touched;  // scratch of march_front
     std::vector<int> cmp_wg;   // per workgroup: {first pixel, end, first wavefront slot, slots in total}
 };
 
@@ -150,41 +153,60 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
     m.w = w;
     m.h = h;
     m.range = range;
-    std::vector<uint8_t> mask(en, 0), band, ring;
-    for (int i = 0; i < h; i++)
+    // Everything below works from the list of hole pixels: the maps are only zero-filled, never scanned.
+    std::vector<uint8_t> mask(en, 0), band(en, 0);
+    std::vector<int> holes;
+    for (int i = 0; i < h; i++) {
+        const uint8_t *row = mask_in + (size_t)i * w;
         for (int j = 0; j < w; j++)
-            if (mask_in[(size_t)i * w + j]) mask[(i + 1) * ec + j + 1] = INSIDE;
+            if (row[j]) {
+                mask[(i + 1) * ec + j + 1] = INSIDE;
+                holes.push_back((i + 1) * ec + j + 1);
+            }
+    }
     m.t.assign(en, 1.0e6f);
     m.ord.assign(en, 0);
     m.pix.clear();
-    dilate_host(mask, band, er, ec, 1, true);
-    bool any = false;
-    for (size_t i = 0; i < en; i++) any |= band[i] != 0;
-    if (!any) return;
-    for (size_t i = 0; i < en; i++) band[i] = band[i] > mask[i] ? band[i] - mask[i] : 0;
-    zero_frame(band, er, ec);
-    FrontQueue heap, outq;
-    for (int i = 0; i < er; i++)
-        for (int j = 0; j < ec; j++)
-            if (band[i * ec + j]) {
-                heap.push(i, j, 0);
-                outq.push(i, j, 0);
-                m.t[i * ec + j] = 0;
+    if (holes.empty()) return;
+    // band = dilate(mask, 3x3 cross) - mask, frame zeroed; seeds in row-major order
+    std::vector<int> seeds;
+    const int d4[4] = {-ec, -1, 1, ec};
+    for (int p : holes)
+        for (int q = 0; q < 4; q++) {
+            const int n = p + d4[q];  // a hole pixel is never on the frame: its 4 neighbours are inside the map
+            const int ni = n / ec, nj = n - ni * ec;
+            if (!mask[n] && !band[n] && ni > 0 && nj > 0 && ni < er - 1 && nj < ec - 1) {
+                band[n] = INSIDE;
+                seeds.push_back(n);
             }
+        }
+    std::sort(seeds.begin(), seeds.end());
+    FrontQueue heap, outq;
+    for (int n : seeds) {
+        const int i = n / ec, j = n - i * ec;
+        heap.push(i, j, 0);
+        outq.push(i, j, 0);
+        m.t[n] = 0;
+    }
     int ii, jj;
     float *t = m.t.data();
     if (outside_ring) {  // CV_INPAINT_TELEA only; CV_INPAINT_NS leaves T = 1e6 off the band
-    // outward distances (negated) on the ring = dilate(mask, (2r+1)^2) - mask - band
-    dilate_host(mask, ring, er, ec, range, false);
-    bool any_ring = false;
-    for (size_t i = 0; i < en; i++) {
-        ring[i] = ring[i] > mask[i] ? ring[i] - mask[i] : 0;
-        any_ring |= ring[i] != 0;
-    }
-    if (!any_ring) return;  // Out->Init fails in the reference: cvInpaint returns without filling
-    for (size_t i = 0; i < en; i++) ring[i] = ring[i] > band[i] ? ring[i] - band[i] : 0;
-    zero_frame(ring, er, ec);
-    {
+        // ring = dilate(mask, (2r+1)^2 rect) - mask - band, frame zeroed.  A non-hole pixel within Chebyshev distance r of
+        // the hole is within r of a hole pixel that has a non-hole 8-neighbour, so only those spread the ring.
+        std::vector<uint8_t> ring(en, 0);
+        bool any_ring = false;
+        for (int p : holes) {
+            const int pi = p / ec, pj = p - pi * ec;
+            bool edge = false;
+            for (int di = -1; di <= 1 && !edge; di++)
+                for (int dj = -1; dj <= 1 && !edge; dj++) edge = !mask[(pi + di) * ec + pj + dj];
+            if (!edge) continue;
+            any_ring = true;
+            for (int a = std::max(pi - range, 1); a <= std::min(pi + range, er - 2); a++)
+                for (int c = std::max(pj - range, 1); c <= std::min(pj + range, ec - 2); c++)
+                    if (!mask[a * ec + c] && !band[a * ec + c]) ring[a * ec + c] = INSIDE;
+        }
+        if (!any_ring) return;  // Out->Init fails in the reference: cvInpaint returns without filling
         uint8_t *f = ring.data();
         while (outq.pop(ii, jj)) {
             f[ii * ec + jj] = CHANGE;
@@ -197,15 +219,17 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
                 t[i * ec + j] = dist;
                 f[i * ec + j] = BAND;
                 outq.push(i, j, dist);
+                m.touched.push_back(i * ec + j);
             }
         }
-        for (size_t i = 0; i < en; i++)
-            if (f[i] == CHANGE) t[i] = -t[i];
-    }
+        for (int n : seeds)
+            if (f[n] == CHANGE) t[n] = -t[n];
+        for (int n : m.touched)
+            if (f[n] == CHANGE) t[n] = -t[n];
+        m.touched.clear();
     }
     // inward front over the hole; the reference passes `mask` ({KNOWN, INSIDE}) as the flag map
-    for (size_t i = 0; i < en; i++)
-        if (mask[i]) m.ord[i] = kNeverFilled;
+    for (int p : holes) m.ord[p] = kNeverFilled;
     uint8_t *f = mask.data();
     int filled = 0;
     while (heap.pop(ii, jj)) {
