@@ -23,6 +23,8 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <queue>
 #include <vector>
 
@@ -641,6 +643,30 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     }
 }
 
+// The workgroups of a dataflow fill wait for each other's results, which only terminates if the workgroups they wait
+// for get to run.  One launch is at most a few dozen workgroups on a 256-CU device, but many concurrent launches (one
+// per rendering host thread) could fill the device with workgroups that all wait for partners still in the dispatch
+// queue.  At most kMaxConcurrentFills fills are therefore in flight per process; the slot is held until the call's
+// final stream synchronisation.
+constexpr int kMaxConcurrentFills = 4;
+class FillSlot {
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::condition_variable &cv() { static std::condition_variable c; return c; }
+    static int &in_flight() { static int n = 0; return n; }
+public:
+    FillSlot() {
+        std::unique_lock<std::mutex> lk(mu());
+        cv().wait(lk, [] { return in_flight() < kMaxConcurrentFills; });
+        ++in_flight();
+    }
+    ~FillSlot() {
+        { std::lock_guard<std::mutex> lk(mu()); --in_flight(); }
+        cv().notify_one();
+    }
+    FillSlot(const FillSlot &) = delete;
+    FillSlot &operator=(const FillSlot &) = delete;
+};
+
 int inpaint_mask_device(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_rgba, ptrdiff_t row_bytes, int w, int h, int iters,
                         uint8_t *d_mask, ptrdiff_t mask_step, uint8_t *d_tmp) {
     dim3 block(256), grid(ofxcv_div_up(w, 256), h);
@@ -755,6 +781,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
         fa.lvl_off = fa.cmp_off = (const int *)(dp + off_lo);
         fa.comp_off = (const int *)(dp + off_co);
+        FillSlot slot;  // released after the stream synchronisation below (or on an early return)
         if (range <= kMaxLdsRange) {
             if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
             else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);

@@ -132,3 +132,32 @@ def test_ns_constant_colour_and_bad_method(oracle, ofxcv, gpu_ctx):
     with pytest.raises(ofxcv.OfxcvError) as e:
         gpu_ctx.inpaint(_dev(c), _dev(m), 3.0, 7)
     assert e.value.status == -4
+
+
+@pytest.mark.timeout(180)
+def test_concurrent_inpaint_calls(oracle, ofxcv):
+    """Eight host threads, one context each, inpaint the same frame at once: the dataflow fill kernels of different
+    calls share the device (at most four are in flight), every result is the oracle's."""
+    import threading
+    import torch  # noqa: F401
+    fr = _frame(320, 240, holes=8)
+    ref = oracle.inpaint_render(fr, 3.0, 1.0)
+    results, errors = {}, []
+
+    def work(k):
+        try:
+            c = ofxcv.Context(0)
+            for _ in range(3):
+                results[k] = c.inpaint_render_host(fr, 3.0, 1.0)
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(8):
+        assert np.array_equal(results[k], ref), k
