@@ -9,10 +9,78 @@
 // host-owned destination are then filled from the pinned copy (unmapped channels stay untouched,
 // :507-516).
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 
 #include "common.h"
 
 namespace {
+
+// A few helper threads for the two host-side copies of this path (frames into the pinned ring, flow into the
+// destination image): one core moves ~25 GB/s, the PCIe link takes 55.  One job at a time; a caller that finds the pool
+// busy (several render threads at once already use several cores) simply does its copy itself.  The pool is created on
+// first use and never torn down (no static destructor joins threads while a host unloads the plugin).
+class HostPool {
+    std::mutex m_, user_;
+    std::condition_variable cv_job_, cv_done_;
+    const std::function<void(int)> *job_ = nullptr;
+    std::atomic<int> next_{0};
+    int ntasks_ = 0, active_ = 0, nworkers_ = 0;
+    unsigned long gen_ = 0;
+
+    void worker() {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_job_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                job = job_;
+                n = ntasks_;
+            }
+            for (int i; (i = next_.fetch_add(1)) < n;) (*job)(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) cv_done_.notify_one();
+            }
+        }
+    }
+    HostPool() {
+        const unsigned hc = std::thread::hardware_concurrency();
+        nworkers_ = hc >= 8 ? 3 : (hc >= 4 ? 1 : 0);
+        for (int i = 0; i < nworkers_; i++) std::thread([this] { worker(); }).detach();
+    }
+
+public:
+    static HostPool &get() {
+        static HostPool *p = new HostPool();  // intentionally leaked
+        return *p;
+    }
+    void run(int n, const std::function<void(int)> &fn) {
+        std::unique_lock<std::mutex> user(user_, std::try_to_lock);
+        if (!user.owns_lock() || nworkers_ == 0 || n <= 1) {
+            for (int i = 0; i < n; i++) fn(i);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            ntasks_ = n;
+            next_.store(0);
+            active_ = nworkers_;
+            ++gen_;
+        }
+        cv_job_.notify_all();
+        for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return active_ == 0; });
+        job_ = nullptr;
+    }
+};
 
 __global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ flow, size_t n, double rsx, double rsy) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -76,7 +144,11 @@ extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptr
     for (int f = 0; f < 2; f++) {
         for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
             int y1 = std::min(height, y0 + rows_per_chunk);
-            for (int y = y0; y < y1; y++) std::memcpy(h_frame[f] + (size_t)y * row, (const char *)src[f] + (ptrdiff_t)y * src_rb[f], row);
+            const int nblk = std::min(4, y1 - y0);
+            HostPool::get().run(nblk, [&](int b) {
+                const int ya = y0 + (int)((long)(y1 - y0) * b / nblk), yb = y0 + (int)((long)(y1 - y0) * (b + 1) / nblk);
+                for (int y = ya; y < yb; y++) std::memcpy(h_frame[f] + (size_t)y * row, (const char *)src[f] + (ptrdiff_t)y * src_rb[f], row);
+            });
             OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f] + (size_t)y0 * row, h_frame[f] + (size_t)y0 * row, (size_t)(y1 - y0) * row,
                                                 hipMemcpyHostToDevice, ctx->copy));
         }
@@ -106,7 +178,9 @@ extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptr
         if (mv & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 1; }
         else if (mu & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 0; }
     }
-    for (int y = 0; y < height && nmap; y++) {
+    const int nblk = nmap ? std::min(8, height) : 0;
+    HostPool::get().run(nblk, [&](int b) {
+    for (int y = (int)((long)height * b / nblk), ye = (int)((long)height * (b + 1) / nblk); y < ye; y++) {
         float *d = (float *)((char *)h_dst + (ptrdiff_t)y * dst_row_bytes);
         const float *sf = h_flow + (size_t)y * width * 2;
         if (nmap == 2) {
@@ -120,5 +194,6 @@ extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptr
                 for (int k = 0; k < nmap; k++) d[x * 4 + dst_c[k]] = sf[x * 2 + src_c[k]];
         }
     }
+    });
     return OFXCV_OK;
 }
