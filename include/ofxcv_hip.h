@@ -105,6 +105,19 @@ int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_
                               double render_scale_y, int levels, int iterations, int poly_n,
                               double poly_sigma);
 
+/* Both directions of a default VectorGenerator output frame in one call (the render() body of
+ * VectorGenerator/VectorGenerator.cpp:601-637: forward = frame t against t+1, backward = t against t-1): the reference
+ * frame is staged, uploaded and converted once, the second frame pair overlaps the first flow, and the destination is
+ * written in one pass.  Equivalent to ofxcv_vectorgen_flow_host(ref, fwd, ...) followed by (ref, bwd, ...); h_fwd or
+ * h_bwd may be NULL. */
+int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes,
+                               const float *h_fwd, ptrdiff_t fwd_row_bytes, const float *h_bwd,
+                               ptrdiff_t bwd_row_bytes, int ncomp, int width, int height, float *h_dst,
+                               ptrdiff_t dst_row_bytes, unsigned fwd_u_mask, unsigned fwd_v_mask,
+                               unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x,
+                               double render_scale_y, int levels, int iterations, int poly_n,
+                               double poly_sigma);
+
 /* ---- I0-I2: inpaint hole mask -------------------------------------------------------------
  * replaces cvCvtColor(imgSrc, mask, CV_RGBA2GRAY) + cvThreshold(mask, mask, 0, 255, CV_THRESH_BINARY_INV)
  * + cvDilate(mask, mask, NULL, (int)t2) at opencv2fx/inpaint/inpaint.cpp:305-309.

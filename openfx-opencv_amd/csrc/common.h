@@ -38,7 +38,7 @@ struct ofxcv_ctx {
     int device = 0;
     hipStream_t compute = nullptr;  // default stream for kernels when the caller passes NULL
     hipStream_t copy = nullptr;     // H2D / D2H staging stream of the host-buffer entry points
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_done = nullptr;
     hipStream_t prep = nullptr;     // Farneback: pyramid + polynomial expansion of all levels, ahead of the level walk
     hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {};

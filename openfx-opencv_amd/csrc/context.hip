@@ -106,7 +106,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
         OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
+        for (int i = 0; i < 3; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
         OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
         return OFXCV_OK;
     };
@@ -137,7 +137,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 3; i++)
         if (ctx->ev_h2d[i]) (void)hipEventDestroy(ctx->ev_h2d[i]);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->compute) (void)hipStreamDestroy(ctx->compute);

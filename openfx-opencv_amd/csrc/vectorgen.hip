@@ -110,38 +110,44 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
-extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_other,
-                                         ptrdiff_t other_row_bytes, int ncomp, int width, int height, float *h_dst,
-                                         ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask,
-                                         double render_scale_x, double render_scale_y, int levels, int iterations, int poly_n,
-                                         double poly_sigma) {
-    if (!ctx) return OFXCV_ERR_INVALID;
-    if (!h_ref || !h_other || !h_dst || width <= 0 || height <= 0 || render_scale_x == 0 || render_scale_y == 0)
-        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "vectorgen_flow_host: bad argument");
-    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "vectorgen_flow_host: RGB or RGBA sources only");
+// One reference frame against one or two other frames (forward: t+1, backward: t-1 -- the two directions a default
+// VectorGenerator output frame needs, VectorGenerator.cpp:739-779).  The reference is staged, uploaded and converted once;
+// the first flow is computed while the host still stages the third frame and is downloaded on the copy stream while
+// the second one runs; one pass over the destination image writes every mapped channel.
+static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, int n_other, const float *const h_other[2],
+                      const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
+                      const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
+                      int levels, int iterations, int poly_n, double poly_sigma) {
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-
+    const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float);
     const size_t frame = align_up(row * height, 256);
     const size_t gray_pitch = align_up((size_t)width, 256);
     const size_t gray = gray_pitch * height;
     const size_t flow_bytes = align_up((size_t)width * height * 8, 256);
-    int rc = reserve_pinned(ctx, 2 * frame + flow_bytes);
+    int rc = reserve_pinned(ctx, nf * frame + n_other * flow_bytes);
     if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->d_stage, 2 * frame + 2 * gray + flow_bytes);
+    rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes);
     if (rc) return rc;
     char *hp = (char *)ctx->h_pinned;
     char *dp = (char *)ctx->d_stage.ptr;
-    char *d_frame[2] = {dp, dp + frame};
-    uint8_t *d_gray[2] = {(uint8_t *)(dp + 2 * frame), (uint8_t *)(dp + 2 * frame + gray)};
-    float *d_flow = (float *)(dp + 2 * frame + 2 * gray);
-    char *h_frame[2] = {hp, hp + frame};
-    float *h_flow = (float *)(hp + 2 * frame);
+    char *d_frame[3], *h_frame[3];
+    uint8_t *d_gray[3];
+    float *d_flow[2], *h_flow[2];
+    for (int f = 0; f < nf; f++) {
+        d_frame[f] = dp + f * frame;
+        h_frame[f] = hp + f * frame;
+        d_gray[f] = (uint8_t *)(dp + nf * frame + f * gray);
+    }
+    for (int k = 0; k < n_other; k++) {
+        d_flow[k] = (float *)(dp + nf * (frame + gray) + k * flow_bytes);
+        h_flow[k] = (float *)(hp + nf * frame + k * flow_bytes);
+    }
 
-    const float *src[2] = {h_ref, h_other};
-    const ptrdiff_t src_rb[2] = {ref_row_bytes, other_row_bytes};
+    const float *src[3] = {h_ref, h_other[0], n_other > 1 ? h_other[1] : nullptr};
+    const ptrdiff_t src_rb[3] = {ref_row_bytes, other_row_bytes[0], n_other > 1 ? other_row_bytes[1] : 0};
     const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ~4 MiB per DMA
-    for (int f = 0; f < 2; f++) {
+    for (int f = 0; f < nf; f++) {
         for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
             int y1 = std::min(height, y0 + rows_per_chunk);
             const int nblk = std::min(4, y1 - y0);
@@ -156,44 +162,109 @@ extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptr
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
         rc = ofxcv_to_byte_grayscale(ctx, (const float *)d_frame[f], (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
         if (rc) return rc;
-    }
-    // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
-    rc = ofxcv_calc_optical_flow_farneback(ctx, d_gray[0], gray_pitch, d_gray[1], gray_pitch, d_flow, (size_t)width * 8, width, height, 0.5,
-                                           levels, 3, iterations, poly_n, poly_sigma, 0, ctx->compute);
-    if (rc) return rc;
-    if (render_scale_x != 1.0 || render_scale_y != 1.0) {
-        size_t n = (size_t)width * height;
-        hipLaunchKernelGGL(scale_flow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (float2 *)d_flow, n,
-                           render_scale_x, render_scale_y);
-        OFXCV_LAUNCH_CHECK(ctx, "scale_flow_kernel");
-    }
-    OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow, d_flow, (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
-    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
-
-    // write-back into the host-owned destination (:507-516): channel c receives flow.y if mapped to v, else flow.x if
-    // mapped to u, else stays untouched.  The channel -> coordinate table is resolved once, not per pixel.
-    const unsigned mu = chan_u_mask & 15u, mv = chan_v_mask & 15u;
-    int nmap = 0, dst_c[4], src_c[4];
-    for (int c = 0; c < 4; c++) {
-        if (mv & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 1; }
-        else if (mu & (1u << c)) { dst_c[nmap] = c; src_c[nmap++] = 0; }
-    }
-    const int nblk = nmap ? std::min(8, height) : 0;
-    HostPool::get().run(nblk, [&](int b) {
-    for (int y = (int)((long)height * b / nblk), ye = (int)((long)height * (b + 1) / nblk); y < ye; y++) {
-        float *d = (float *)((char *)h_dst + (ptrdiff_t)y * dst_row_bytes);
-        const float *sf = h_flow + (size_t)y * width * 2;
-        if (nmap == 2) {
-            const int d0 = dst_c[0], d1 = dst_c[1], s0 = src_c[0], s1 = src_c[1];
-            for (int x = 0; x < width; x++) {
-                d[x * 4 + d0] = sf[x * 2 + s0];
-                d[x * 4 + d1] = sf[x * 2 + s1];
-            }
+        if (f == 0) continue;
+        const int k = f - 1;
+        // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+        rc = ofxcv_calc_optical_flow_farneback(ctx, d_gray[0], gray_pitch, d_gray[f], gray_pitch, d_flow[k], (size_t)width * 8, width, height, 0.5,
+                                               levels, 3, iterations, poly_n, poly_sigma, 0, ctx->compute);
+        if (rc) return rc;
+        if (render_scale_x != 1.0 || render_scale_y != 1.0) {
+            size_t n = (size_t)width * height;
+            hipLaunchKernelGGL(scale_flow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (float2 *)d_flow[k], n,
+                               render_scale_x, render_scale_y);
+            OFXCV_LAUNCH_CHECK(ctx, "scale_flow_kernel");
+        }
+        if (k + 1 < n_other) {  // download on the copy stream (behind the last frame's upload) while the next flow runs
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));
         } else {
-            for (int x = 0; x < width; x++)
-                for (int k = 0; k < nmap; k++) d[x * 4 + dst_c[k]] = sf[x * 2 + src_c[k]];
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[k], d_flow[k], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
         }
     }
+    if (n_other > 1) {
+        OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy, ctx->ev_done, 0));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[0], d_flow[0], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->copy));
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy));
+    }
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+
+    // write-back into the host-owned destination (:507-516): per direction, channel c receives flow.y if mapped to v,
+    // else flow.x if mapped to u, else stays untouched; a later direction overwrites an earlier one.  The channel ->
+    // (flow, coordinate) table is resolved once, not per pixel.
+    int src_k[4] = {-1, -1, -1, -1}, src_c[4] = {0, 0, 0, 0};
+    for (int k = 0; k < n_other; k++) {
+        const unsigned mu = chan_u_mask[k] & 15u, mv = chan_v_mask[k] & 15u;
+        for (int c = 0; c < 4; c++) {
+            if (mv & (1u << c)) { src_k[c] = k; src_c[c] = 1; }
+            else if (mu & (1u << c)) { src_k[c] = k; src_c[c] = 0; }
+        }
+    }
+    int nmap = 0, dst_c[4];
+    const float *map_src[4];
+    for (int c = 0; c < 4; c++)
+        if (src_k[c] >= 0) {
+            dst_c[nmap] = c;
+            map_src[nmap++] = h_flow[src_k[c]] + src_c[c];
+        }
+    const int nblk = nmap ? std::min(8, height) : 0;
+    HostPool::get().run(nblk, [&](int b) {
+        for (int y = (int)((long)height * b / nblk), ye = (int)((long)height * (b + 1) / nblk); y < ye; y++) {
+            float *d = (float *)((char *)h_dst + (ptrdiff_t)y * dst_row_bytes);
+            const size_t ro = (size_t)y * width * 2;
+            if (nmap == 2) {
+                const float *s0 = map_src[0] + ro, *s1 = map_src[1] + ro;
+                const int d0 = dst_c[0], d1 = dst_c[1];
+                for (int x = 0; x < width; x++) {
+                    d[x * 4 + d0] = s0[x * 2];
+                    d[x * 4 + d1] = s1[x * 2];
+                }
+            } else if (nmap == 4) {
+                const float *s0 = map_src[0] + ro, *s1 = map_src[1] + ro, *s2 = map_src[2] + ro, *s3 = map_src[3] + ro;
+                for (int x = 0; x < width; x++) {
+                    d[x * 4 + 0] = s0[x * 2];
+                    d[x * 4 + 1] = s1[x * 2];
+                    d[x * 4 + 2] = s2[x * 2];
+                    d[x * 4 + 3] = s3[x * 2];
+                }
+            } else {
+                for (int x = 0; x < width; x++)
+                    for (int q = 0; q < nmap; q++) d[x * 4 + dst_c[q]] = map_src[q][ro + x * 2];
+            }
+        }
     });
     return OFXCV_OK;
+}
+
+extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_other,
+                                         ptrdiff_t other_row_bytes, int ncomp, int width, int height, float *h_dst,
+                                         ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask,
+                                         double render_scale_x, double render_scale_y, int levels, int iterations, int poly_n,
+                                         double poly_sigma) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!h_ref || !h_other || !h_dst || width <= 0 || height <= 0 || render_scale_x == 0 || render_scale_y == 0)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "vectorgen_flow_host: bad argument");
+    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "vectorgen_flow_host: RGB or RGBA sources only");
+    const float *others[2] = {h_other, nullptr};
+    const ptrdiff_t rbs[2] = {other_row_bytes, 0};
+    const unsigned mu[2] = {chan_u_mask, 0}, mv[2] = {chan_v_mask, 0};
+    return flows_host(ctx, h_ref, ref_row_bytes, 1, others, rbs, ncomp, width, height, h_dst, dst_row_bytes, mu, mv, render_scale_x,
+                      render_scale_y, levels, iterations, poly_n, poly_sigma);
+}
+
+extern "C" int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_fwd,
+                                          ptrdiff_t fwd_row_bytes, const float *h_bwd, ptrdiff_t bwd_row_bytes, int ncomp, int width,
+                                          int height, float *h_dst, ptrdiff_t dst_row_bytes, unsigned fwd_u_mask, unsigned fwd_v_mask,
+                                          unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x, double render_scale_y, int levels,
+                                          int iterations, int poly_n, double poly_sigma) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!h_ref || (!h_fwd && !h_bwd) || !h_dst || width <= 0 || height <= 0 || render_scale_x == 0 || render_scale_y == 0)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "vectorgen_flows_host: bad argument");
+    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "vectorgen_flows_host: RGB or RGBA sources only");
+    const float *others[2];
+    ptrdiff_t rbs[2];
+    unsigned mu[2], mv[2];
+    int n = 0;
+    if (h_fwd) { others[n] = h_fwd; rbs[n] = fwd_row_bytes; mu[n] = fwd_u_mask; mv[n++] = fwd_v_mask; }
+    if (h_bwd) { others[n] = h_bwd; rbs[n] = bwd_row_bytes; mu[n] = bwd_u_mask; mv[n++] = bwd_v_mask; }
+    return flows_host(ctx, h_ref, ref_row_bytes, n, others, rbs, ncomp, width, height, h_dst, dst_row_bytes, mu, mv, render_scale_x,
+                      render_scale_y, levels, iterations, poly_n, poly_sigma);
 }

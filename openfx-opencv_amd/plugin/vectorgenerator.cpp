@@ -273,6 +273,35 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
     const int levels = get_int(d->levels, time), iterations = get_int(d->iterations, time), poly_n = get_int(d->neighborhood, time);
     const double poly_sigma = get_double(d->sigma, time);
 
+    // both directions over the whole reference frame: one library call stages and converts the reference once and
+    // overlaps the second frame pair with the first flow
+    if (forward && backward) {
+        ImageGuard next(g, d->srcClip, time + 1), prev(g, d->srcClip, time - 1);
+        if (!next.img.data || !prev.img.data) throw SuiteError(kOfxStatFailed);
+        const Image &r = ref.img, &o = dst.img;
+        const bool whole = rw.x1 <= r.bounds.x1 && rw.y1 <= r.bounds.y1 && rw.x2 >= r.bounds.x2 && rw.y2 >= r.bounds.y2 &&
+                           o.bounds.x1 <= r.bounds.x1 && o.bounds.y1 <= r.bounds.y1 && o.bounds.x2 >= r.bounds.x2 && o.bounds.y2 >= r.bounds.y2;
+        const int ncomp = r.components == kOfxImageComponentRGBA ? 4 : (r.components == kOfxImageComponentRGB ? 3 : 0);
+        const bool same = ncomp && next.img.components == r.components && prev.img.components == r.components &&
+                          next.img.width() == r.width() && next.img.height() == r.height() && prev.img.width() == r.width() &&
+                          prev.img.height() == r.height() && r.depth == kOfxBitDepthFloat && next.img.depth == kOfxBitDepthFloat &&
+                          prev.img.depth == kOfxBitDepthFloat && o.depth == kOfxBitDepthFloat && o.components == kOfxImageComponentRGBA;
+        if (whole && same) {
+            unsigned fu = 0, fv = 0, bu = 0, bv = 0;
+            for (int i = 0; i < 4; i++) {
+                if (ch[i] == 1) fu |= 1u << i;
+                if (ch[i] == 2) fv |= 1u << i;
+                if (ch[i] == 3) bu |= 1u << i;
+                if (ch[i] == 4) bv |= 1u << i;
+            }
+            ofxcv_ctx *ctx = ThreadContext::get();
+            float *d0 = (float *)((char *)o.data + (ptrdiff_t)(r.bounds.y1 - o.bounds.y1) * o.row_bytes) + (size_t)(r.bounds.x1 - o.bounds.x1) * 4;
+            check_hip(ctx, ofxcv_vectorgen_flows_host(ctx, (const float *)r.data, r.row_bytes, (const float *)next.img.data, next.img.row_bytes,
+                                                      (const float *)prev.img.data, prev.img.row_bytes, ncomp, r.width(), r.height(), d0,
+                                                      o.row_bytes, fu, fv, bu, bv, rs[0], rs[1], levels, iterations, poly_n, poly_sigma));
+            return kOfxStatOK;
+        }
+    }
     if (forward) {
         ImageGuard other(g, d->srcClip, time + 1);
         if (!other.img.data) throw SuiteError(kOfxStatFailed);

@@ -135,3 +135,25 @@ def test_concurrent_renders_on_one_instance(oracle):
         assert np.array_equal(outs[t][..., :2], fwd) and np.array_equal(outs[t][..., 2:], bwd), t
     assert h.mh_clip_balance(inst, b"Source") == 0 and h.mh_clip_balance(inst, b"Output") == 0
     pl.destroy(inst)
+
+
+def test_two_direction_host_call_equals_two_single_calls(ofxcv, oracle):
+    """ofxcv_vectorgen_flows_host (forward + backward in one call, shared reference upload) == the two single calls."""
+    from openfx_opencv_amd import synth
+    w, h = 352, 264
+    prev, ref = synth.flow_pair(w, h, seed=11)
+    _, nxt = synth.flow_pair(w, h, seed=12)
+    c = ofxcv.Context(0)
+    a = np.full((h, w, 4), 7.0, np.float32)
+    c.vectorgen_flow_host(ref, nxt, a, 0b0001, 0b0010)
+    c.vectorgen_flow_host(ref, prev, a, 0b0100, 0b1000)
+    b = np.full((h, w, 4), 7.0, np.float32)
+    c.vectorgen_flows_host(ref, nxt, prev, b, 0b0001, 0b0010, 0b0100, 0b1000)
+    assert np.array_equal(a, b)
+    # one direction only, partial channel map, render scale
+    a2 = np.full((h, w, 4), 7.0, np.float32)
+    b2 = np.full((h, w, 4), 7.0, np.float32)
+    c.vectorgen_flow_host(ref, prev, a2, 0b0100, 0, 0.5, 0.5)
+    c.vectorgen_flows_host(ref, None, prev, b2, 0, 0, 0b0100, 0, 0.5, 0.5)
+    assert np.array_equal(a2, b2) and np.all(b2[..., [0, 1, 3]] == 7.0)
+    c.close()

@@ -21,3 +21,20 @@ def run(nthreads, n=8):
     return nthreads * n / el
 for nt in (1, 2, 4):
     print("host path, %d calling threads: %.1f pairs/s" % (nt, run(nt)))
+
+# a default VectorGenerator output frame: forward + backward flow of one reference frame
+prev, ref = synth.flow_pair(W, H, seed=11)
+_, nxt = synth.flow_pair(W, H, seed=12)
+c = ofxcv.Context(0)
+out = np.zeros((H, W, 4), np.float32)
+for combined in (False, True):
+    def frame():
+        if combined:
+            c.vectorgen_flows_host(ref, nxt, prev, out, 1, 2, 4, 8)
+        else:
+            c.vectorgen_flow_host(ref, nxt, out, 1, 2); c.vectorgen_flow_host(ref, prev, out, 4, 8)
+    frame(); frame()
+    t0 = time.perf_counter(); n = 10
+    for _ in range(n): frame()
+    el = (time.perf_counter() - t0) / n
+    print("default output frame (2 flows), %s: %.2f ms = %.0f frames/s" % ("one combined call" if combined else "two calls", el * 1e3, 1 / el))
