@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the inpaint render() body (host image in/out) and the oracle on the same frame."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth

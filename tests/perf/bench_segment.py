@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times pyramid mean-shift filtering at BASELINE config 4 (3840x2160, sp 10, sr 20, maxLevel 2) and the oracle on a crop."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth

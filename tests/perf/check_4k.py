@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 shape: 3840x2160 pairs, 8 in flight on one GPU; parity of one pair vs the oracle + throughput."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth
