@@ -32,13 +32,13 @@ __global__ __launch_bounds__(256) void ms_pack_kernel(const uint8_t *__restrict_
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const uint8_t *p = src + (ptrdiff_t)y * step + (size_t)x * CN;
-    dst[(size_t)y * w + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | (CN == 4 ? (uint32_t)p[3] << 24 : 0u);
+    dst[(size_t)y * w + x] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);  // top byte 0: the taps use 4-byte dot products
 }
 
 // result colours + (for 4-channel images) the alpha of the source pixel
 template <int CN>
-__global__ __launch_bounds__(256) void ms_unpack_kernel(const uint32_t *__restrict__ res, const uint32_t *__restrict__ src0, int w, int h,
-                                                        uint8_t *__restrict__ dst, ptrdiff_t step) {
+__global__ __launch_bounds__(256) void ms_unpack_kernel(const uint32_t *__restrict__ res, const uint8_t *__restrict__ src0, ptrdiff_t src0_step,
+                                                        int w, int h, uint8_t *__restrict__ dst, ptrdiff_t step) {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     uint32_t v = res[(size_t)y * w + x];
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ms_unpack_kernel(const uint32_t *__restri
     p[0] = (uint8_t)v;
     p[1] = (uint8_t)(v >> 8);
     p[2] = (uint8_t)(v >> 16);
-    if (CN == 4) p[3] = (uint8_t)(src0[(size_t)y * w + x] >> 24);
+    if (CN == 4) p[3] = src0[(ptrdiff_t)y * src0_step + (size_t)x * 4 + 3];
 }
 
 // pyrDown_ (8-bit): 5x5 [1 4 6 4 1]^2, BORDER_REFLECT_101, (sum + 128) >> 8
@@ -150,22 +150,49 @@ __global__ __launch_bounds__(256) void ms_iterate_kernel(const uint32_t *__restr
         int count = 0, s0 = 0, s1 = 0, s2 = 0, sx = 0, sy = 0;
         int minx = max((int)rint((double)((float)x0 - sp)), 0), miny = max((int)rint((double)((float)y0 - sp)), 0);
         int maxx = min((int)rint((double)((float)x0 + sp)), W - 1), maxy = min((int)rint((double)((float)y0 + sp)), H - 1);
+        // Window taps in integer dot products (the fourth byte of every packed pixel is 0):
+        //   |t - c|^2 <= isr2  <=>  t.t - thr <= 2 t.c   with thr = isr2 - c.c,
+        // and the three colour sums of the selected pixels are dot products with a one-hot byte vector, accumulated
+        // by the instruction itself.  11 vector instructions per tap instead of 28; all-integer, so the same result.
+        const uint32_t cpk = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
+        const uint32_t nthr = (uint32_t)(-(isr2 - (c0 * c0 + c1 * c1 + c2 * c2)));
+        uint32_t u0 = 0, u1 = 0, u2 = 0;
         for (int y = miny; y <= maxy; y++) {
             const uint32_t *row = src + (size_t)y * W;
             int row_count = 0;
-            for (int x = minx; x <= maxx; x++) {
-                uint32_t v = row[x];
-                int t0 = v & 255u, t1 = (v >> 8) & 255u, t2 = (v >> 16) & 255u;
-                int d0 = t0 - c0, d1 = t1 - c1, d2 = t2 - c2;
-                if (d0 * d0 + d1 * d1 + d2 * d2 <= isr2) {
-                    s0 += t0; s1 += t1; s2 += t2;
-                    sx += x;
-                    row_count++;
-                }
+            auto tap = [&](uint32_t v, int x) {
+                const int lhs = (int)__builtin_amdgcn_udot4(v, v, nthr, false);
+                const int tc = (int)__builtin_amdgcn_udot4(v, cpk, 0u, false);
+                const bool in = lhs <= 2 * tc;
+                const uint32_t sel = in ? v : 0u;
+                u0 = __builtin_amdgcn_udot4(sel, 0x00000001u, u0, false);
+                u1 = __builtin_amdgcn_udot4(sel, 0x00000100u, u1, false);
+                u2 = __builtin_amdgcn_udot4(sel, 0x00010000u, u2, false);
+                sx += in ? x : 0;
+                row_count += in ? 1 : 0;
+            };
+            int x = minx;
+            for (; x + 7 <= maxx; x += 8) {  // eight loads in flight per lane
+                uint32_t v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = row[x + q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) tap(v[q], x + q);
             }
+            for (; x + 3 <= maxx; x += 4) {
+                const uint32_t v0 = row[x], v1 = row[x + 1], v2 = row[x + 2], v3 = row[x + 3];
+                tap(v0, x);
+                tap(v1, x + 1);
+                tap(v2, x + 2);
+                tap(v3, x + 3);
+            }
+            for (; x <= maxx; x++) tap(row[x], x);
             count += row_count;
             sy += y * row_count;
         }
+        s0 = (int)u0;
+        s1 = (int)u1;
+        s2 = (int)u2;
         if (count == 0) break;
         double icount = 1. / count;
         int x1 = (int)rint(sx * icount), y1 = (int)rint(sy * icount);
@@ -248,9 +275,9 @@ int ofxcv_pyr_mean_shift_filtering(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff
         OFXCV_LAUNCH_CHECK(ctx, "ms_iterate_kernel");
     }
     if (channels == 4)
-        hipLaunchKernelGGL(ms_unpack_kernel<4>, pg, pb, 0, s, (const uint32_t *)D(0), (const uint32_t *)S(0), width, height, d_dst, dst_step);
+        hipLaunchKernelGGL(ms_unpack_kernel<4>, pg, pb, 0, s, (const uint32_t *)D(0), d_src, src_step, width, height, d_dst, dst_step);
     else
-        hipLaunchKernelGGL(ms_unpack_kernel<3>, pg, pb, 0, s, (const uint32_t *)D(0), (const uint32_t *)S(0), width, height, d_dst, dst_step);
+        hipLaunchKernelGGL(ms_unpack_kernel<3>, pg, pb, 0, s, (const uint32_t *)D(0), d_src, src_step, width, height, d_dst, dst_step);
     OFXCV_LAUNCH_CHECK(ctx, "ms_unpack_kernel");
     return OFXCV_OK;
 }
