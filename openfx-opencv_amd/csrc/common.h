@@ -112,6 +112,12 @@ int ofxcv_ctx_quiesce(ofxcv_ctx *ctx);
 
 static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Host image rows <-> a contiguous device image.  OFX row strides may be negative (bottom-up images) or carry
+// padding: a non-negative stride goes through hipMemcpy2DAsync, anything else through a contiguous host copy.
+// The download variant has finished (stream synchronised) when it returns only in the second case.
+int ofxcv_upload_rows(ofxcv_ctx *ctx, void *d_dst, size_t row, const void *h_src, ptrdiff_t src_row_bytes, int rows, hipStream_t s);
+int ofxcv_download_rows(ofxcv_ctx *ctx, void *h_dst, ptrdiff_t dst_row_bytes, const void *d_src, size_t row, int rows, hipStream_t s);
+
 int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation stream and the per-level events
 
 // measurement hook helpers (context.hip)

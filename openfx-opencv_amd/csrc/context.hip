@@ -41,6 +41,30 @@ int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     return OFXCV_OK;
 }
 
+int ofxcv_upload_rows(ofxcv_ctx *ctx, void *d_dst, size_t row, const void *h_src, ptrdiff_t src_row_bytes, int rows, hipStream_t s) {
+    if (src_row_bytes >= (ptrdiff_t)row) {
+        OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, row, h_src, (size_t)src_row_bytes, row, rows, hipMemcpyHostToDevice, s));
+        return OFXCV_OK;
+    }
+    std::vector<char> tmp(row * rows);
+    for (int y = 0; y < rows; y++) std::memcpy(tmp.data() + (size_t)y * row, (const char *)h_src + (ptrdiff_t)y * src_row_bytes, row);
+    OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_dst, tmp.data(), row * rows, hipMemcpyHostToDevice, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `tmp` dies with this scope
+    return OFXCV_OK;
+}
+
+int ofxcv_download_rows(ofxcv_ctx *ctx, void *h_dst, ptrdiff_t dst_row_bytes, const void *d_src, size_t row, int rows, hipStream_t s) {
+    if (dst_row_bytes >= (ptrdiff_t)row) {
+        OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, (size_t)dst_row_bytes, d_src, row, row, rows, hipMemcpyDeviceToHost, s));
+        return OFXCV_OK;
+    }
+    std::vector<char> tmp(row * rows);
+    OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), d_src, row * rows, hipMemcpyDeviceToHost, s));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    for (int y = 0; y < rows; y++) std::memcpy((char *)h_dst + (ptrdiff_t)y * dst_row_bytes, tmp.data() + (size_t)y * row, row);
+    return OFXCV_OK;
+}
+
 int ofxcv_prof_mark(ofxcv_ctx *ctx, hipStream_t s) {
     hipEvent_t e;
     OFXCV_HIP_CHECK(ctx, hipEventCreate(&e));

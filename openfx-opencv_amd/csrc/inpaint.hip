@@ -811,14 +811,16 @@ int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
     int rc = ofxcv_reserve(ctx, ctx->ip_img, 2 * img + msk);
     if (rc) return rc;
     uint8_t *d_src = (uint8_t *)ctx->ip_img.ptr, *d_dst = d_src + img, *d_mask = d_dst + img;
-    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_src, row, h_src, src_row_bytes, row, h, hipMemcpyHostToDevice, s));
+    rc = ofxcv_upload_rows(ctx, d_src, row, h_src, src_row_bytes, h, s);
+    if (rc) return rc;
     rc = ofxcv_inpaint_mask(ctx, d_src, (ptrdiff_t)row, w, h, dilation > 0 ? (int)dilation : 0, d_mask, w, s);
     if (rc) return rc;
     rc = ofxcv_inpaint_telea(ctx, d_src, (ptrdiff_t)row, 4, d_mask, w, w, h, radius, d_dst, (ptrdiff_t)row, nullptr, nullptr, s);
     if (rc) return rc;
     // write-back of inpaint.cpp:320-358 for noise == 0: RGB copied, alpha forced to 255 (the caller applies the
     // libc rand() noise of :336-347 itself when the noise parameter is non-zero, using h_mask_out)
-    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, dst_row_bytes, d_dst, row, row, h, hipMemcpyDeviceToHost, s));
+    rc = ofxcv_download_rows(ctx, h_dst, dst_row_bytes, d_dst, row, h, s);
+    if (rc) return rc;
     if (h_mask_out) OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_mask_out, w, d_mask, w, w, h, hipMemcpyDeviceToHost, s));
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
     for (int y = 0; y < h; y++) {

@@ -292,10 +292,12 @@ int ofxcv_segment_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
     int rc = ofxcv_reserve(ctx, ctx->ip_img, 2 * img);
     if (rc) return rc;
     uint8_t *d_src = (uint8_t *)ctx->ip_img.ptr, *d_dst = d_src + img;
-    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_src, row, h_src, src_row_bytes, row, height, hipMemcpyHostToDevice, s));
+    rc = ofxcv_upload_rows(ctx, d_src, row, h_src, src_row_bytes, height, s);
+    if (rc) return rc;
     rc = ofxcv_pyr_mean_shift_filtering(ctx, d_src, (ptrdiff_t)row, 4, width, height, sp, sr, max_level, 5, 1.0, d_dst, (ptrdiff_t)row, s);
     if (rc) return rc;
-    OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, dst_row_bytes, d_dst, row, row, height, hipMemcpyDeviceToHost, s));
+    rc = ofxcv_download_rows(ctx, h_dst, dst_row_bytes, d_dst, row, height, s);
+    if (rc) return rc;
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
     for (int y = 0; y < height; y++) {  // segment.cpp:315-319: alpha = 255
         uint8_t *d = h_dst + (ptrdiff_t)y * dst_row_bytes;

@@ -157,3 +157,35 @@ def test_two_direction_host_call_equals_two_single_calls(ofxcv, oracle):
     c.vectorgen_flows_host(ref, None, prev, b2, 0, 0, 0b0100, 0, 0.5, 0.5)
     assert np.array_equal(a2, b2) and np.all(b2[..., [0, 1, 3]] == 7.0)
     c.close()
+
+
+def test_bottom_up_host_images(ofxcv, oracle):
+    """OFX images may have negative row strides (bottom-up storage): all three host entry points accept them."""
+    from openfx_opencv_amd import synth
+    c = ofxcv.Context(0)
+    # inpaint / segment: uint8 RGBA, source and destination bottom-up
+    fr = synth.inpaint_frame(96, 72, n_holes=4)
+    phys = np.ascontiguousarray(fr[::-1])          # rows stored bottom-up ...
+    view = phys[::-1]                              # ... and addressed through a negative stride
+    assert view.strides[0] < 0 and np.array_equal(view, fr)
+    out_phys = np.zeros_like(phys)
+    out = out_phys[::-1]
+    lib = ofxcv.lib()
+    rc = lib.ofxcv_inpaint_render_host(c._h, C.c_void_p(view.ctypes.data), C.c_ssize_t(view.strides[0]), C.c_int(96), C.c_int(72),
+                                       C.c_double(3.0), C.c_double(1.0), C.c_void_p(out.ctypes.data), C.c_ssize_t(out.strides[0]), None)
+    assert rc == 0 and np.array_equal(out, oracle.inpaint_render(fr, 3.0, 1.0))
+    out_phys[:] = 0
+    rc = lib.ofxcv_segment_render_host(c._h, C.c_void_p(view.ctypes.data), C.c_ssize_t(view.strides[0]), C.c_int(96), C.c_int(72),
+                                       C.c_double(10.0), C.c_double(20.0), C.c_int(2), C.c_void_p(out.ctypes.data), C.c_ssize_t(out.strides[0]))
+    ref = oracle.pyr_mean_shift(np.ascontiguousarray(fr[..., :3]), 10.0, 20.0, 2)
+    assert rc == 0 and np.array_equal(out[..., :3], ref) and np.all(out[..., 3] == 255)
+    # VectorGenerator: float RGBA frames bottom-up
+    a, b = synth.flow_pair(128, 96)
+    ap, bp = np.ascontiguousarray(a[::-1])[::-1], np.ascontiguousarray(b[::-1])[::-1]
+    d1 = np.zeros((96, 128, 4), np.float32)
+    d2p = np.zeros((96, 128, 4), np.float32)
+    d2 = d2p[::-1]
+    c.vectorgen_flow_host(a, b, d1, 1, 2)
+    c.vectorgen_flow_host(ap, bp, d2, 1, 2)
+    assert np.array_equal(d1, d2)
+    c.close()
