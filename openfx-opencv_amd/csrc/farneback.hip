@@ -988,15 +988,16 @@ constexpr int kFtS0 = kFtW + 4;  // row stride of the staged M-in region (tile +
 constexpr int kFtS1 = kFtW + 2;  // row stride of the intermediate M region (tile + 1 ring): 64 = one wavefront
 static_assert(kFtS1 == 64 && kFtH + 2 == 2 * (kFtThreads / 64), "one wavefront per ring row, two rounds of eight rows");
 
-__device__ __forceinline__ void box_solve_lds(const float *__restrict__ sm, int stride, int plane_elems, int ly, int lx, double scale,
-                                              float &fxv, float &fyv) {
+// 3x3 window sum + 2x2 solve from LDS.  rowp(c, r) = address of column lx - 1 of window row r (0..2) of plane c.
+template <typename RowPtr>
+__device__ __forceinline__ void box_solve_rows(RowPtr rowp, double scale, float &fxv, float &fyv) {
     double acc[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        const float *p = sm + c * plane_elems + (ly - 1) * stride + (lx - 1);
-        double h0 = ((double)p[0] + (double)p[1]) + (double)p[2];
-        double h1 = ((double)p[stride] + (double)p[stride + 1]) + (double)p[stride + 2];
-        double h2 = ((double)p[2 * stride] + (double)p[2 * stride + 1]) + (double)p[2 * stride + 2];
+        const float *p0 = rowp(c, 0), *p1 = rowp(c, 1), *p2 = rowp(c, 2);
+        double h0 = ((double)p0[0] + (double)p0[1]) + (double)p0[2];
+        double h1 = ((double)p1[0] + (double)p1[1]) + (double)p1[2];
+        double h2 = ((double)p2[0] + (double)p2[1]) + (double)p2[2];
         acc[c] = (h0 + h1) + h2;
     }
     double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
@@ -1011,7 +1012,10 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
                                                                 const float *__restrict__ Min, float *__restrict__ Mout, int w, int h,
                                                                 int pitch, double scale) {
     __shared__ float s0[5 * (kFtH + 4) * kFtS0];  // M-in on tile + 2 ring
-    __shared__ float s1[5 * (kFtH + 2) * kFtS1];  // M after the first iteration on tile + 1 ring
+    // M after the first iteration on tile + 1 ring.  Only ring rows 0..7 have their own storage: rows 8..15 are written in the
+    // second half, when the first eight rows of s0 are dead (the first half read s0 rows 0..9, the second reads 8..17), and
+    // live there.  34 KB instead of 44 KB of LDS: four workgroups (8 waves per SIMD) per CU instead of three.
+    __shared__ float s1a[5 * 8 * kFtS1];
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int x0 = tbx * kFtW, y0 = tby * kFtH;
@@ -1020,7 +1024,11 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     const unsigned pb = (unsigned)(plane * 4);
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
               bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, 5 * plane * sizeof(float));
-    constexpr int n0 = (kFtH + 4) * kFtS0, n1 = (kFtH + 2) * kFtS1;
+    constexpr int n0 = (kFtH + 4) * kFtS0;
+    auto s1row = [&](int c, int r) -> float * { return r < 8 ? s1a + (c * 8 + r) * kFtS1 : s0 + c * n0 + (r - 8) * kFtS0; };
+    // ring rows whose pixel lies inside the image: rows beyond it are replicas (their first-iteration result may be computed
+    // from s0 rows that are already being overwritten and is never read: the second iteration clamps its window rows)
+    const int rlo = y0 == 0 ? 1 : 0, rhi = min(kFtH + 1, h - y0);
 
     // ring position (r, lane) <-> image pixel (clamp(y0 - 1 + r), clamp(x0 - 1 + lane)); wave `wave` owns ring rows
     // `wave` (first half) and 8 + `wave` (second half) and keeps their R0 values in registers for the second iteration
@@ -1035,14 +1043,15 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
         Px p;
         p.y = clampi(y0 - 1 + r, 0, h - 1);
         p.active = true;
-        box_solve_lds(s0, kFtS0, n0, p.y - (y0 - 2), x - (x0 - 2), scale, p.fxv, p.fyv);
+        const int qc = p.y - (y0 - 2), qx = x - (x0 - 2);
+        box_solve_rows([&](int c, int k) { return (const float *)(s0 + c * n0 + (qc - 1 + k) * kFtS0 + (qx - 1)); }, scale, p.fxv, p.fyv);
         p.tp = gather_taps(bR1, x, p.y, w, h, pitch, pb, p.fxv, p.fyv);
         return p;
     };
     auto first_finish = [&](int r, const Px &p, const float r0v[5]) {
         M5 mm = update_matrices_finish(r0v, p.tp, x, p.y, w, h, p.fxv, p.fyv);
 #pragma unroll
-        for (int c = 0; c < 5; c++) s1[c * n1 + r * kFtS1 + lane] = mm.v[c];
+        for (int c = 0; c < 5; c++) s1row(c, r)[lane] = mm.v[c];
     };
     auto second_prepare = [&](int r, bool wave_has_row) {  // ring row r = tile row r - 1
         Px p;
@@ -1050,7 +1059,8 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
         p.active = wave_has_row && lane >= 1 && lane <= kFtW && xr < w && p.y < h;  // not the ring itself, inside the image
         p.fxv = p.fyv = 0.f;
         if (p.active) {
-            box_solve_lds(s1, kFtS1, n1, r, lane, scale, p.fxv, p.fyv);
+            const int ra = clampi(r - 1, rlo, rhi), rc = clampi(r + 1, rlo, rhi);
+            box_solve_rows([&](int c, int k) { return (const float *)(s1row(c, k == 0 ? ra : (k == 1 ? r : rc)) + (lane - 1)); }, scale, p.fxv, p.fyv);
             p.tp = gather_taps(bR1, xr, p.y, w, h, pitch, pb, p.fxv, p.fyv);
         }
         return p;
