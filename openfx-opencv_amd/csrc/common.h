@@ -59,7 +59,8 @@ struct ofxcv_ctx {
     DevBuf fb_flow;    // two ping-pong coarse flow fields
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
-    bool fb_opencv_rounding = false;
+    int fb_opencv_rounding = 0;  // 0 direct window sums, 1 OpenCV's running-sum order (strip-parallel), 2 the same as a serial column scan
+    int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
 
     // inpaint scratch
     DevBuf ip_tmp;   // undilated mask

@@ -188,7 +188,11 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.opencv_rounding")) {
-        ctx->fb_opencv_rounding = value != 0;
+        ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.strict_rows")) {
+        ctx->fb_strict_rows = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.graph")) {

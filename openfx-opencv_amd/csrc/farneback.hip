@@ -1296,6 +1296,159 @@ __global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------ OpenCV-order box window, strip-parallel
+//
+// The running sum above is vsum(y) = c0 + sum_{t<=y} (double)d_t with d_t = (float)(M[min(t+1,h-1)] - M[max(t-2,0)]) and
+// c0 = (double)(3.f * M[0]): a column prefix of row differences that were rounded to f32.  Only the f64 additions are
+// re-associated here (errors of 1e-16 relative to the partial sums, nine orders of magnitude below the f32 rounding of
+// the d_t themselves, which is reproduced exactly):
+//   * vsum_carry_kernel (one per iteration, reads M once) sums d_t over strips of RW rows and leaves, per strip, column
+//     and channel, the f64 value of vsum just above the strip: `carry` (prefix inside a group of strips handled by one
+//     workgroup) + `gtot` (totals of the groups above).
+//   * iterate3s_kernel: one wavefront owns 62 columns (+ one halo lane each side) x RW rows.  It starts from the carry,
+//     adds its own row differences top to bottom exactly like the reference, takes the left/right column sums from the
+//     neighbouring lanes by DPP wave shifts (two dwords per f64), solves, gathers R1 and writes the next M.  The R1
+//     gather of a row is issued one row ahead of the arithmetic that consumes it.
+// No intermediate field in HBM: per iteration M is read (RW+3)/RW times plus 40 B of carries per column and strip.
+constexpr int kSsSPW = 4;   // strips per wavefront of the carry kernel (upper bound)
+
+template <int RW>
+__global__ __launch_bounds__(1024) void vsum_carry_kernel(const float *__restrict__ M, int w, int h, int pitch, double *__restrict__ carry,
+                                                          double *__restrict__ gtot, int nstrips, int spg, int spw) {
+    __shared__ double tot[16][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), c = blockIdx.y, g = blockIdx.z;
+    const int s_first = g * spg + wv * spw, s_end = min(s_first + spw, min((g + 1) * spg, nstrips));
+    const float *m = M + (size_t)c * pitch * h + x;
+    const int a = s_first * RW;
+    double pre[kSsSPW];  // sum of the strips of this wavefront before strip i
+    double acc = 0.;
+    if (s_first < s_end) {
+        // rows a-2 .. a + spw*RW of M (clamped): d_t = row[t+1] - row[t-2]
+        float row[kSsSPW * RW + 3];
+#pragma unroll
+        for (int r = 0; r < kSsSPW * RW + 3; r++) row[r] = r < spw * RW + 3 ? m[(size_t)clampi(a - 2 + r, 0, h - 1) * pitch] : 0.f;
+        if (a == 0) acc = (double)(row[2] * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product (row[2] = M[0])
+#pragma unroll
+        for (int i = 0; i < kSsSPW; i++) {
+            pre[i] = acc;
+            if (s_first + i < s_end) {
+#pragma unroll
+                for (int j = 0; j < RW; j++)
+                    if (a + i * RW + j < h) acc += (double)(row[i * RW + j + 3] - row[i * RW + j]);
+            }
+        }
+    }
+    tot[wv][lane] = acc;
+    __syncthreads();
+    double base = 0.;
+    for (int v = 0; v < wv; v++) base += tot[v][lane];
+    if (xr < w) {
+#pragma unroll
+        for (int i = 0; i < kSsSPW; i++)
+            if (s_first + i < s_end) carry[((size_t)(s_first + i) * 5 + c) * pitch + xr] = base + pre[i];
+        if (wv == 15) gtot[((size_t)g * 5 + c) * pitch + xr] = base + acc;
+    }
+}
+
+__device__ __forceinline__ double dpp64_from_left(double v) {  // lane i <- lane i-1
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp64_from_right(double v) {  // lane i <- lane i+1
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kSsW = 62;  // columns a wavefront of iterate3s_kernel owns (lanes 1..62; lanes 0 and 63 carry the halo columns)
+
+template <bool UPDATE, int RW>
+__global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                        const float *__restrict__ Min, float *__restrict__ Mout,
+                                                        float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
+                                                        const double *__restrict__ carry, const double *__restrict__ gtot, int spg) {
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x0 = (tbx * 2 + wave) * kSsW;
+    if (x0 >= w) return;  // wave-uniform
+    const int a = tby * RW;
+    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
+    const bool own = lane >= 1 && lane <= kSsW && xr < w;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
+    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+
+    // rows a-2 .. a+RW of M: index r <-> image row clamp(a - 2 + r)
+    float m[RW + 3][5];
+#pragma unroll
+    for (int r = 0; r < RW + 3; r++) {
+        const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
+#pragma unroll
+        for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
+    }
+    // vsum just above the strip
+    double D[5];
+    {
+        const int g = tby / spg;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double p = carry[((size_t)tby * 5 + c) * pitch + x];
+            if (g > 0) {
+                double s = gtot[(size_t)c * pitch + x];
+                for (int gg = 1; gg < g; gg++) s += gtot[((size_t)gg * 5 + c) * pitch + x];
+                p = s + p;
+            }
+            D[c] = p;
+        }
+    }
+    struct Px {
+        Taps tp;
+        float r0v[5];
+        float fxv, fyv;
+    };
+    Px prev;
+    auto finish = [&](const Px &p, int y) {
+        M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
+        if (own) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+        const int y = a + j;
+        if (y >= h) break;  // wave-uniform
+        double acc[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            D[c] += (double)(m[j + 3][c] - m[j][c]);  // the reference's vsum[x] += srow1[x] - srow0[x]
+            acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
+        }
+        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
+        if (UPDATE) {
+            Px cur;
+            cur.fxv = fxv;
+            cur.fyv = fyv;
+#pragma unroll
+            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
+            if (j > 0) finish(prev, y - 1);
+            prev = cur;
+        }
+    }
+    if (UPDATE) finish(prev, min(a + RW, h) - 1);
+}
+
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -1408,7 +1561,32 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
                      size_t flow_step, int w, int h, int winsize, bool update) {
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
-    if (ctx->fb_opencv_rounding && winsize == 3) {
+    if (ctx->fb_opencv_rounding == 1 && winsize == 3) {
+        // strip-parallel OpenCV-order window: carries of the column running sums, then the iteration itself
+        const int pitch = plane_pitch(w), tiles_x = ofxcv_div_up(w, kSsW);
+        int rw = ctx->fb_strict_rows;
+        if (rw != 2 && rw != 4 && rw != 8) rw = (long)tiles_x * ofxcv_div_up(h, 8) >= 4096 ? 8 : ((long)tiles_x * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
+        const int nstrips = ofxcv_div_up(h, rw), G = ofxcv_div_up(nstrips, 16 * kSsSPW), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
+        double *carry = (double *)ctx->fb_vsum.ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
+        dim3 cgrid(ofxcv_div_up(w, 64), 5, G), grid(ofxcv_div_up(tiles_x, 2), nstrips);
+#define OFXCV_LAUNCH_SS(RW)                                                                                                              \
+    do {                                                                                                                                 \
+        hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw);            \
+        if (update)                                                                                                                      \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg);                                                        \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((iterate3s_kernel<false, RW>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg);                                                        \
+    } while (0)
+        if (rw == 8) OFXCV_LAUNCH_SS(8);
+        else if (rw == 4) OFXCV_LAUNCH_SS(4);
+        else OFXCV_LAUNCH_SS(2);
+#undef OFXCV_LAUNCH_SS
+        OFXCV_LAUNCH_CHECK(ctx, "iterate3s_kernel");
+        return OFXCV_OK;
+    }
+    if (ctx->fb_opencv_rounding && winsize == 3) {  // 2: the serial column scan (cross-check of the strip-parallel form)
         const int pitch = plane_pitch(w);
         double *V = (double *)ctx->fb_vsum.ptr;  // reserved by the caller
         hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, Min, w, h, pitch, V);

@@ -9,6 +9,8 @@ from openfx_opencv_amd import synth
 
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 ctx = ofxcv.Context(0)
+for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 
 def timeit(fn, n=50, warm=5):
     for _ in range(warm): fn()
