@@ -46,19 +46,30 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 
 /* context options:
- *   "farneback.opencv_rounding" 0|1  evaluate the Farneback box window with OpenCV's own running sums (every row
- *                                    difference rounded to f32 before it is accumulated in f64) -- a validation mode,
- *                                    ~20x slower, that reproduces the reference's rounding noise sample for sample;
+ *   "farneback.opencv_rounding" 1|0|2 how the 3x3 box window of FarnebackUpdateFlow_Blur is evaluated.
+ *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical
+ *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel (a
+ *                                      carry pre-pass + a row-walking kernel per iteration).  Reproduces the reference's
+ *                                      rounding noise: every sample within 1e-4 (relative) of the CPU result.
+ *                                    0: direct sums (each window summed on its own in f64, two iterations fused per launch):
+ *                                      ~1.8x faster, but at ill-conditioned pixels (6e-5 of the samples at 1920x1080,
+ *                                      6e-4 at 3840x2160) the result leaves the 1e-4 band around the reference's.
+ *                                      Also selected by the environment variable OFXCV_FARNEBACK_WINDOW=direct.
+ *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
+ *                                    Window sizes other than the reference's 3 always use direct sums.
  *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1);
- *   "farneback.fuse_iterations" 0|1  run two iterations per launch through LDS (default 1; 0 = one launch each);
+ *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
- *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels). */
+ *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
+ *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
+ *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
- * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of its dominant kernel --
- * the fused blur+solve+update iteration at pyramid level 0 -- with a hipEvent pair on the stream it
- * is launched on.  ofxcv_profile_read synchronises, adds up the pairs and returns the total
+ * While enabled, ofxcv_calc_optical_flow_farneback brackets every updating iteration step at pyramid
+ * level 0 -- OpenCV-order mode: the carry pre-pass + the blur+solve+update kernel of one iteration;
+ * direct-window mode: the fused two-iteration kernel -- with a hipEvent pair on the stream it is
+ * launched on.  ofxcv_profile_read synchronises, adds up the pairs and returns the total
  * kernel time and the number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
 int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);

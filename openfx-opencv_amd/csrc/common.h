@@ -59,7 +59,8 @@ struct ofxcv_ctx {
     DevBuf fb_flow;    // two ping-pong coarse flow fields
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
-    int fb_opencv_rounding = 0;  // 0 direct window sums, 1 OpenCV's running-sum order (strip-parallel), 2 the same as a serial column scan
+    int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
+    int fb_strict_variant = 0, fb_carry_groups = 0;  // A/B knobs of the strip-parallel form
     int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
 
     // inpaint scratch

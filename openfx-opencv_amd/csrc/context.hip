@@ -1,5 +1,6 @@
 // context.hip -- device context, scratch management and error reporting of libofxcv_hip.so.
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 #include "common.h"
@@ -124,6 +125,10 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     ofxcv_ctx *ctx = new (std::nothrow) ofxcv_ctx();
     if (!ctx) return OFXCV_ERR_MEMORY;
     ctx->device = device;
+    if (const char *e = getenv("OFXCV_FARNEBACK_WINDOW")) {  // lets a plugin user pick the window evaluation without a new parameter
+        if (!std::strcmp(e, "direct")) ctx->fb_opencv_rounding = 0;
+        else if (!std::strcmp(e, "opencv")) ctx->fb_opencv_rounding = 1;
+    }
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
         OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
@@ -189,6 +194,14 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "farneback.opencv_rounding")) {
         ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.strict_variant")) {
+        ctx->fb_strict_variant = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.carry_groups")) {
+        ctx->fb_carry_groups = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.strict_rows")) {

@@ -1366,7 +1366,7 @@ __device__ __forceinline__ double dpp64_from_right(double v) {  // lane i <- lan
 
 constexpr int kSsW = 62;  // columns a wavefront of iterate3s_kernel owns (lanes 1..62; lanes 0 and 63 carry the halo columns)
 
-template <bool UPDATE, int RW>
+template <bool UPDATE, int RW, bool PIPE>
 __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                         const float *__restrict__ Min, float *__restrict__ Mout,
                                                         float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
@@ -1384,14 +1384,17 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
               bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
 
-    // rows a-2 .. a+RW of M: index r <-> image row clamp(a - 2 + r)
+    // rows a-2 .. a+RW of M: index r <-> image row clamp(a - 2 + r).  Row j needs indices j and j+3; the loads run PF rows
+    // ahead of their use instead of all up front (55 live registers for RW = 8 otherwise).
+    constexpr int PF = RW > 4 ? 3 : RW;
     float m[RW + 3][5];
-#pragma unroll
-    for (int r = 0; r < RW + 3; r++) {
+    auto load_m = [&](int r) {
         const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
         for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
-    }
+    };
+#pragma unroll
+    for (int r = 0; r < 3 + PF && r < RW + 3; r++) load_m(r);
     // vsum just above the strip
     double D[5];
     {
@@ -1424,6 +1427,7 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
     for (int j = 0; j < RW; j++) {
         const int y = a + j;
         if (y >= h) break;  // wave-uniform
+        if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1442,11 +1446,15 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
 #pragma unroll
             for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
             cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
-            if (j > 0) finish(prev, y - 1);
-            prev = cur;
+            if (PIPE) {
+                if (j > 0) finish(prev, y - 1);
+                prev = cur;
+            } else {
+                finish(cur, y);
+            }
         }
     }
-    if (UPDATE) finish(prev, min(a + RW, h) - 1);
+    if (UPDATE && PIPE) finish(prev, min(a + RW, h) - 1);
 }
 
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
@@ -1566,19 +1574,23 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         const int pitch = plane_pitch(w), tiles_x = ofxcv_div_up(w, kSsW);
         int rw = ctx->fb_strict_rows;
         if (rw != 2 && rw != 4 && rw != 8) rw = (long)tiles_x * ofxcv_div_up(h, 8) >= 4096 ? 8 : ((long)tiles_x * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
-        const int nstrips = ofxcv_div_up(h, rw), G = ofxcv_div_up(nstrips, 16 * kSsSPW), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
+        const int nstrips = ofxcv_div_up(h, rw), G = std::max(ofxcv_div_up(nstrips, 16 * kSsSPW), std::min(ctx->fb_carry_groups, 8)), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
         double *carry = (double *)ctx->fb_vsum.ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
         dim3 cgrid(ofxcv_div_up(w, 64), 5, G), grid(ofxcv_div_up(tiles_x, 2), nstrips);
 #define OFXCV_LAUNCH_SS(RW)                                                                                                              \
     do {                                                                                                                                 \
         hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw);            \
-        if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+        if (update && pipe)                                                                                                              \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, true>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg);                                                        \
+        else if (update)                                                                                                                 \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, false>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<false, RW>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+            hipLaunchKernelGGL((iterate3s_kernel<false, RW, false>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
     } while (0)
+        const bool pipe = !(ctx->fb_strict_variant & 1);
         if (rw == 8) OFXCV_LAUNCH_SS(8);
         else if (rw == 4) OFXCV_LAUNCH_SS(4);
         else OFXCV_LAUNCH_SS(2);

@@ -34,3 +34,16 @@ def gpu_ctx(ofxcv):
     ctx = ofxcv.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def direct_ctx(ofxcv):
+    """a context in the direct-window mode (each 3x3 box window summed on its own in f64: the fast opt-in path, bit-identical
+    to the oracle's DIRECT evaluation; the default mode reproduces OpenCV's running-sum order instead)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    ctx = ofxcv.Context(0)
+    ctx.set_option("farneback.opencv_rounding", 0)
+    yield ctx
+    ctx.close()

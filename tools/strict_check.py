@@ -25,6 +25,8 @@ for w, h in sizes:
         ctx = ofxcv.Context(0)
         ctx.set_option("farneback.opencv_rounding", mode)
         ctx.set_option("farneback.strict_rows", rows)
+        for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         got = ctx.calc_optical_flow_farneback(torch.from_numpy(ga).cuda(), torch.from_numpy(gb).cuda()).cpu().numpy()
         err = np.abs(ref - got)
         bad = err > 1e-4 * np.maximum(1, np.abs(ref))
