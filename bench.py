@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Farneback dense optical flow throughput at 1920x1080 (BASELINE.json metric).
 
-One step = one pass of the VectorGenerator hot path over one synthetic f32 RGBA frame pair that is
-already resident in HBM: sRGB-gray LUT x2 (F0) -> calcOpticalFlowFarneback (F1-F6) -> flow->RGBA
-write-back (F7), all through the C ABI of libofxcv_hip.so.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank runs its own independent pairs -- the path has no
-exchange step, so there is no data-path collective; only the timing barrier / max-reduce.
+One step = one pass of the VectorGenerator hot path over a batch of independent synthetic f32 RGBA frame pairs that
+are already resident in HBM: sRGB-gray LUT x2 (F0) -> calcOpticalFlowFarneback (F1-F6) -> flow->RGBA write-back (F7),
+all through the C ABI of libofxcv_hip.so.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
+rank runs its own independent pairs -- the path has no exchange step, so there is no data-path collective; only the
+timing barrier / max-reduce.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: the fused blur+solve+update
-iteration at pyramid level 0, timed live with HIP events on its own stream) and `cpu_baseline`
-(the CPU oracle -- a port of the reference's OpenCV algorithm -- timed on this host on a bounded sample).
+`value` is measured in the library's DEFAULT mode: the box window of FarnebackUpdateFlow_Blur evaluated in OpenCV's
+own order (every sample within 1e-4 of the reference arithmetic, see `parity`).  `value_direct_window` is the faster
+opt-in mode that sums each window directly and leaves the 1e-4 band at a few ill-conditioned pixels.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel of the timed mode: one blur+solve+update iteration at
+pyramid level 0, timed live with HIP events on its launch stream), `cpu_baseline` (the CPU oracle -- a port of the
+reference's OpenCV algorithm -- timed on this host on a bounded sample) and, at N = 1, one leg per other BASELINE
+config (end-to-end host path, Telea inpaint, mean-shift segment, 3840x2160 Farneback).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -23,10 +30,11 @@ if ROOT not in sys.path:
 
 W, H = 1920, 1080
 LEVELS, ITERS, POLY_N, POLY_SIGMA, WINSIZE, PYR_SCALE = 3, 15, 5, 1.1, 3, 0.5  # VectorGenerator.cpp:804-834, :391-395
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak
-# one fused iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel; the dominant
-# kernel (iterate3x2_kernel) runs TWO iterations per launch, i.e. 160 algorithmic bytes per pixel per launch
-ITER_BYTES_PER_PX = 160.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak (6.29 TB/s measured float4 copy)
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4.0  # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+# one iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
+ITER_BYTES_PER_PX = 80.0
+PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
 def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
@@ -40,39 +48,42 @@ def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
     return total
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (tools/pmc_bench.sh,
-    summary in profiles/): the counters need their own profiler runs, so the figure is measured offline and read here."""
+def pmc_kernels():
+    """HBM-side bytes / instruction counts per launch of the level-0 iteration kernels from the committed rocprofv3 --pmc
+    passes (tools/pmc_bench.sh + tools/pmc_traffic_json.py): counters need their own profiler runs, so these figures are
+    measured offline and read here (labelled as such in the line)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return float(json.load(f)["traffic_bytes_per_launch"])
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f)["kernels"]
     except Exception:
-        return None
+        return {}
 
 
-def cpu_baseline(ga, gb, budget_s=12.0):
+def stats(vals):
+    return {"median": statistics.median(vals), "min": min(vals), "max": max(vals), "repeats": len(vals)}
+
+
+def cpu_farneback(ga, gb, budget_s=12.0):
     """Time the CPU oracle (kind 'port': restatement of OpenCV's single-threaded CPU Farneback) on rank 0."""
     from oracle import binding as oracle
     oracle.lib()
     t0 = time.perf_counter()
     n = 0
     while True:
-        oracle.calc_optical_flow_farneback(ga, gb, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0, oracle.BLUR_FAITHFUL)
+        flow = oracle.calc_optical_flow_farneback(ga, gb, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0, oracle.BLUR_FAITHFUL)
         n += 1
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 8:
             break
     return {"value": n / el, "unit": "frame-pairs/s", "cores": 1, "kind": "port",
             "sample": "%d Farneback frame pairs at %dx%d (same synthetic frames, levels=3 iterations=15 poly_n=5), "
-                      "oracle/farneback.c single thread, %.1f s" % (n, W, H, el)}
+                      "oracle/farneback.c (OpenCV evaluation order) single thread, %.1f s" % (n, W, H, el)}, flow
 
 
-def cpu_baseline_all_cores(ga, gb, per_thread=4, max_threads=32):
-    """The same port, one independent frame pair per host thread (ctypes drops the GIL): what the host CPU of this box
-    delivers on the partitioned workload.  SURVEY.md 8(d) asks for the single-thread and the all-cores figure."""
+def cpu_farneback_all_cores(ga, gb, per_thread=4, max_threads=32):
+    """The same port, one independent frame pair per host thread (ctypes drops the GIL)."""
     import concurrent.futures as cf
     from oracle import binding as oracle
-    oracle.lib()
     n_thr = max(1, min(max_threads, os.cpu_count() or 1))
 
     def work(_):
@@ -86,15 +97,40 @@ def cpu_baseline_all_cores(ga, gb, per_thread=4, max_threads=32):
             "sample": "%d threads x %d Farneback frame pairs at %dx%d, one pair per thread at a time, %.1f s" % (n_thr, per_thread, W, H, el)}
 
 
+def cv2_probe(ga, gb, ref_flow):
+    """If the box has OpenCV's Python module, time the real thing and diff the oracle against it (SURVEY.md 8(c)/(d));
+    otherwise say so.  Never a requirement."""
+    try:
+        import cv2
+    except Exception as e:
+        return {"present": False, "note": "cv2 not importable on this box (%s): the oracle stays pinned by known-answer tests only" % type(e).__name__}
+    import numpy as np
+    out = {"present": True, "version": cv2.__version__}
+    for thr, key in ((1, "pairs_per_s_1_thread"), (0, "pairs_per_s_default_threads")):
+        cv2.setNumThreads(thr)
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < 5.0 and n < 8:
+            f = cv2.calcOpticalFlowFarneback(ga, gb, None, PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+            n += 1
+        out[key] = n / (time.perf_counter() - t0)
+    err = np.abs(f - ref_flow)
+    out["oracle_vs_cv2_max_abs_err"] = float(err.max())
+    out["oracle_vs_cv2_outside_1e-4"] = float((err > 1e-4 * np.maximum(1, np.abs(f))).mean())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
+    ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
     ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
-                    "3840x2160 is configs[4] (64 pairs over 8 GPUs); the PMC traffic figure is only recorded for 1920x1080")
+                    "3840x2160 is configs[4] (64 pairs over 8 GPUs)")
     args = ap.parse_args()
     global W, H
     W, H = (int(v) for v in args.size.lower().split("x"))
@@ -125,118 +161,310 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # One step = one batch of `pairs` independent frame pairs, each on its own context (own HIP stream and
-    # scratch): frame pairs never exchange data, so they shard across streams exactly as they shard across GPUs.
     P = max(1, args.pairs)
-    ctxs = [ofxcv.Context(local_rank) for _ in range(P)]
-    for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):  # A/B of kernel variants: name=value,...
-        for c in ctxs:
-            c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-    bufs = []
-    for i, c in enumerate(ctxs):
-        a, b = synth.flow_pair(W, H, seed=sharding.seed_for_pair(sharding.pairs_for_rank(world * P, rank, world)[i]))
-        with torch.cuda.stream(c.stream):
-            bufs.append(dict(a=torch.from_numpy(a).cuda(), b=torch.from_numpy(b).cuda(),
-                             ga=torch.empty((H, W), dtype=torch.uint8, device="cuda"),
-                             gb=torch.empty((H, W), dtype=torch.uint8, device="cuda"),
-                             flow=torch.empty((H, W, 2), dtype=torch.float32, device="cuda"),
-                             out=torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")))
+    extra_opts = [kv.split("=") for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(","))]  # A/B of kernel variants
 
-    def step():
-        for c, t in zip(ctxs, bufs):
+    def make_ctxs(n, direct):
+        cs = [ofxcv.Context(local_rank) for _ in range(n)]
+        for c in cs:
+            c.set_option("farneback.opencv_rounding", 0 if direct else 1)
+            for k, v in extra_opts:
+                c.set_option(k, int(v))
+        return cs
+
+    def make_bufs(cs, w, h):
+        bufs = []
+        for i, c in enumerate(cs):
+            a, b = synth.flow_pair(w, h, seed=sharding.seed_for_pair(sharding.pairs_for_rank(world * len(cs), rank, world)[i]))
+            with torch.cuda.stream(c.stream):
+                bufs.append(dict(a=torch.from_numpy(a).cuda(), b=torch.from_numpy(b).cuda(),
+                                 ga=torch.empty((h, w), dtype=torch.uint8, device="cuda"),
+                                 gb=torch.empty((h, w), dtype=torch.uint8, device="cuda"),
+                                 flow=torch.empty((h, w, 2), dtype=torch.float32, device="cuda"),
+                                 out=torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")))
+        return bufs
+
+    def step(cs, bufs):
+        # one batch of independent frame pairs, each on its own context (own HIP stream and scratch): frame pairs never
+        # exchange data, so they shard across streams exactly as they shard across GPUs
+        for c, t in zip(cs, bufs):
             with torch.cuda.stream(c.stream):
                 c.to_byte_grayscale(t["a"], t["ga"])
                 c.to_byte_grayscale(t["b"], t["gb"])
                 c.calc_optical_flow_farneback(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
                 c.flow_to_rgba(t["flow"], t["out"], 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    def timed_regions(cs, bufs, steps, warmup, repeats):
+        """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; elapsed = max over ranks"""
+        for _ in range(warmup):
+            step(cs, bufs)
+        out = []
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(cs, bufs)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            out.append(sharding.reduce_elapsed_max(time.perf_counter() - t0, dist, red_dev))
+        return out
 
-    # roofline leg: same process, same inputs -- HIP event pairs around every launch of the dominant kernel (the fused
-    # iteration at pyramid level 0), recorded on the stream the kernel is launched on.  One pair at a time here: with
-    # two streams in flight an event pair would also time the wait for the other stream's kernel.
-    c0, t0b = ctxs[0], bufs[0]
-    c0.profile_enable(True)
-    with torch.cuda.stream(c0.stream):
-        for _ in range(max(3, min(10, args.steps))):
-            c0.calc_optical_flow_farneback(t0b["ga"], t0b["gb"], t0b["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
-    torch.cuda.synchronize()
-    kern_ms, kern_n = c0.profile_read()
-    c0.profile_enable(False)
-    # for reference, the same event pairs with all `pairs` streams in flight (what a kernel trace of the timed region shows)
-    conc_ms, conc_n = 0.0, 0
-    if P > 1:
-        for c in ctxs:
-            c.profile_enable(True)
-        for _ in range(3):
-            step()
+    def kernel_leg(c, t, which):
+        """HIP event pairs around every level-0 launch of one kernel, on the stream it is launched on, one pair in flight"""
+        c.profile_enable(which)
+        with torch.cuda.stream(c.stream):
+            for _ in range(max(3, min(10, args.steps))):
+                c.calc_optical_flow_farneback(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
         torch.cuda.synchronize()
-        for c in ctxs:
-            ms, n = c.profile_read()
-            conc_ms += ms
-            conc_n += n
-            c.profile_enable(False)
-    g_a, g_b = bufs[0]["ga"], bufs[0]["gb"]
+        ms, n = c.profile_read()
+        c.profile_enable(0)
+        return (ms / 1e3 / max(1, n)), n
 
-    elapsed = sharding.reduce_elapsed_max(elapsed, dist, red_dev)        # MAX over ranks
-    pairs = sharding.reduce_count_sum(args.steps * P, dist, red_dev)       # units all ranks processed
-
-    if rank == 0:
-        value = pairs / elapsed
-        avg_s = kern_ms / 1e3 / max(1, kern_n)
-        achieved = ITER_BYTES_PER_PX * W * H / avg_s / 1e9
-        alg = algorithmic_bytes_per_pair(W, H)
-        line = {
-            "metric": "frames/sec at %dx%d f32 (Farneback flow)" % (W, H),
-            "value": value,
-            "unit": "frame-pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "VectorGenerator Farneback dense optical flow, %dx%d f32 RGBA frame pair resident in HBM "
-                                   "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[%d])"
-                                   % (W, H, 4 if (W, H) == (3840, 2160) else 2),
-                       "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
-                       "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P, "parallelism": "independent frame pairs per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic() if (W, H) == (1920, 1080) else None, "kernel": "iterate3x2_kernel<true> (two fused blur+solve+update iterations per launch; <true> = the pyramid level 0 launches, %dx%d)" % (W, H),
-                         "bytes_per_launch": ITER_BYTES_PER_PX * W * H, "avg_launch_us": avg_s * 1e6, "launches_timed": kern_n,
-                         "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r01_bench_pairs1_kernel_stats.csv)",
-                         "avg_launch_us_all_streams_in_flight": (conc_ms / conc_n * 1e3) if conc_n else None},
-            "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
-                           "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            ga = g_a.cpu().numpy()
-            gb = g_b.cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(ga, gb)
-            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(ga, gb)
-        elif world > 1:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+    # ---- headline: default mode (OpenCV-order window) ----
+    ctxs = make_ctxs(P, direct=False)
+    bufs = make_bufs(ctxs, W, H)
+    el = timed_regions(ctxs, bufs, args.steps, args.warmup, max(1, args.repeats))
+    pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
+    rates = [pairs_per_region / e for e in el]
+    main_s, main_n = kernel_leg(ctxs[0], bufs[0], 1)
+    carry_s, carry_n = kernel_leg(ctxs[0], bufs[0], 2)
+    one_in_flight = None
+    if world == 1:
+        e1 = timed_regions(ctxs[:1], bufs[:1], max(10, args.steps // 2), 3, 3)
+        one_in_flight = max(10, args.steps // 2) / statistics.median(e1)
+    strict_flow = bufs[0]["flow"].cpu().numpy()
+    g_a, g_b = bufs[0]["ga"].cpu().numpy(), bufs[0]["gb"].cpu().numpy()
     for c in ctxs:
         c.close()
+    del bufs
+
+    # ---- the opt-in direct-window mode, same workload ----
+    dctxs = make_ctxs(P, direct=True)
+    dbufs = make_bufs(dctxs, W, H)
+    del_ = timed_regions(dctxs, dbufs, args.steps, args.warmup, max(1, min(5, args.repeats)))
+    drates = [pairs_per_region / e for e in del_]
+    fused_s, fused_n = kernel_leg(dctxs[0], dbufs[0], 1)
+    direct_flow = dbufs[0]["flow"].cpu().numpy()
+    for c in dctxs:
+        c.close()
+    del dbufs
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = statistics.median(rates)
+    alg = algorithmic_bytes_per_pair(W, H)
+    pmc = pmc_kernels() if (W, H) == (1920, 1080) else {}
+    pm, pc, pf = pmc.get("opencv_order_iteration_level0", {}), pmc.get("opencv_order_carry_level0", {}), pmc.get("direct_window_fused_pair_level0", {})
+    iter_bytes = ITER_BYTES_PER_PX * W * H
+    achieved = iter_bytes / main_s / 1e9
+    traffic = pm.get("traffic_bytes_per_launch")
+    valu = pm.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
+    line = {
+        "metric": "frames/sec at %dx%d f32 (Farneback flow)" % (W, H),
+        "value": value,
+        "unit": "frame-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": statistics.median(el) / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "VectorGenerator Farneback dense optical flow, %dx%d f32 RGBA frame pair resident in HBM "
+                               "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[%d])"
+                               % (W, H, 4 if (W, H) == (3840, 2160) else 2),
+                   "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
+                   "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P,
+                   "box_window": "OpenCV order (library default): running f64 column sums of f32-rounded row differences, strip-parallel",
+                   "parallelism": "independent frame pairs per GPU, no collective"},
+        "value_stats": dict(stats(rates), note="each repeat = one timed region of `steps` steps bracketed by barrier + synchronize; value = median"),
+        "value_one_pair_in_flight": one_in_flight,
+        "value_direct_window": statistics.median(drates),
+        "value_direct_window_stats": dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
+                                          "fused per launch; does NOT meet 1e-4 at every sample (see parity)"),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic,
+                     "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
+                     "kernel": "iterate3s_kernel<true, 8, true> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)" % (W, H),
+                     "bytes_per_launch": iter_bytes, "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20)",
+                     "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
+                     "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r02_bench_pairs1_by_grid.txt)",
+                     "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
+                     "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "bound_actual": "hbm: the kernel moves more than its algorithmic bytes (halo rows of M, R1 gather lines, 40 B of carries per "
+                                     "column and strip) at about the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
+                     "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
+                     "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) / launch time",
+                     "carry_prepass": {"kernel": "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip; one launch per iteration)",
+                                       "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n, "algorithmic_bytes": 20.0 * W * H + 5.0 * W * H,
+                                       "traffic": pc.get("traffic_bytes_per_launch"),
+                                       "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None},
+                     "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
+                                              "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes,
+                                              "achieved": 2 * iter_bytes / fused_s / 1e9, "frac": 2 * iter_bytes / fused_s / 1e9 / HBM_PEAK_GBS,
+                                              "traffic": pf.get("traffic_bytes_per_launch"),
+                                              "traffic_GBps": (pf["traffic_bytes_per_launch"] / fused_s / 1e9) if pf.get("traffic_bytes_per_launch") else None}},
+        "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
+                       "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS,
+                       "direct_window_frac_of_hbm_peak": alg * statistics.median(drates) / world / 1e9 / HBM_PEAK_GBS},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        cb, ref_flow = cpu_farneback(g_a, g_b)
+        line["cpu_baseline"] = cb
+        line["cpu_baseline_all_cores"] = cpu_farneback_all_cores(g_a, g_b)
+        line["cv2"] = cv2_probe(g_a, g_b, ref_flow)
+
+        def par(got):
+            err = np.abs(got - ref_flow)
+            bad = err > 1e-4 * np.maximum(1, np.abs(ref_flow))
+            return {"outside_1e-4": float(bad.mean()), "max_abs_err": float(err.max()), "bit_identical": float((got == ref_flow).mean())}
+        line["parity"] = {"reference": "CPU oracle, OpenCV evaluation order (oracle/farneback.c, ORC_BLUR_FAITHFUL), same %dx%d pair; oracle itself is "
+                                       "pinned by known-answer tests only (no OpenCV in this image)" % (W, H),
+                          "tolerance": "|a-b| <= 1e-4 * max(1, |b|)",
+                          "timed_mode_opencv_order": par(strict_flow), "direct_window_mode": par(direct_flow)}
+    elif world > 1:
+        line["cpu_baseline"] = None
+    if world == 1 and not args.no_extra_legs and (W, H) == (1920, 1080):
+        try:
+            line.update(extra_legs(ofxcv, synth, torch, np, local_rank, not args.no_cpu_baseline))
+        except Exception as e:  # the headline must still be reported
+            line["extra_legs_error"] = "%s: %s" % (type(e).__name__, e)
+    print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
+    """One leg per remaining BASELINE config, rank 0 at N = 1 only; every figure is a median of a few runs."""
+    out = {}
+    med = statistics.median
+
+    # ---- end to end: f32 RGBA host frames -> flow written into a host RGBA image (PCIe inclusive) ----
+    a, b = synth.flow_pair(1920, 1080)
+    prev, _ = synth.flow_pair(1920, 1080, seed=11)
+
+    def host_rate(nthreads, n=6):
+        cs = [ofxcv.Context(dev) for _ in range(nthreads)]
+        outs = [np.zeros((1080, 1920, 4), np.float32) for _ in range(nthreads)]
+        for c, o in zip(cs, outs):
+            c.vectorgen_flows_host(a, b, prev, o, 1, 2, 4, 8)
+
+        def work(c, o):
+            for _ in range(n):
+                c.vectorgen_flows_host(a, b, prev, o, 1, 2, 4, 8)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(c, o)) for c, o in zip(cs, outs)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        el = time.perf_counter() - t0
+        for c in cs:
+            c.close()
+        return 2 * nthreads * n / el
+    out["end_to_end"] = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs), "
+                                     "three 1920x1080 f32 RGBA host frames in, one host RGBA frame out, PCIe inclusive",
+                         "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_4": host_rate(4)}
+
+    # ---- Telea inpaint (configs[0] size and configs[1]) ----
+    ctx = ofxcv.Context(dev)
+    for (w, h, key) in ((640, 480, "inpaint_640x480"), (1920, 1080, "inpaint_1080p")):
+        fr = synth.inpaint_frame(w, h)
+        ctx.inpaint_render_host(fr)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.inpaint_render_host(fr)
+            ts.append(time.perf_counter() - t0)
+        d = torch.from_numpy(fr).cuda()
+        m = ctx.inpaint_mask(d, 1)
+        torch.cuda.synchronize()
+        hole = int((m > 0).sum())
+        td = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ctx.inpaint_telea(d, m)
+            torch.cuda.synchronize()
+            td.append(time.perf_counter() - t0)
+        leg = {"workload": "opencv2fx/inpaint render body, %dx%d 8-bit RGBA, radius 3, dilation 1, %d hole pixels" % (w, h, hole),
+               "render_host_ms": med(ts) * 1e3, "telea_device_images_ms": med(td) * 1e3, "Mpx_hole_per_s": hole / med(td) / 1e6,
+               "bound": "dependency latency of the fast-marching order (host march + dataflow fill), not HBM"}
+        if with_cpu:
+            from oracle import binding as oracle
+            t0 = time.perf_counter()
+            oracle.inpaint_render(fr)
+            leg["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+        out[key] = leg
+
+    # ---- mean-shift segment, configs[3] ----
+    w, h = 3840, 2160
+    fr = np.ascontiguousarray(synth.inpaint_frame(w, h, n_holes=0)[..., :3])
+    d = torch.from_numpy(fr).cuda()
+    ctx.pyr_mean_shift_filtering(d)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ctx.pyr_mean_shift_filtering(d)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    leg = {"workload": "pyramid mean-shift filtering, 3840x2160 8-bit RGB resident in HBM, sp 10, sr 20, maxLevel 2", "ms": med(ts) * 1e3,
+           "Mpx_per_s": w * h / med(ts) / 1e6, "bound": "integer VALU issue (window taps), compulsory HBM traffic 6 B/px"}
+    if with_cpu:
+        from oracle import binding as oracle
+        crop = np.ascontiguousarray(fr[:540, :960])
+        t0 = time.perf_counter()
+        oracle.pyr_mean_shift(crop)
+        c = time.perf_counter() - t0
+        leg["cpu_oracle_Mpx_per_s"] = 960 * 540 / c / 1e6
+        leg["cpu_sample"] = "960x540 crop of the same frame, 1 thread, %.1f s" % c
+    out["segment_4k"] = leg
+    ctx.close()
+
+    # ---- 3840x2160 Farneback (configs[4] workload on one GPU) ----
+    w, h, p4 = 3840, 2160, 4
+    alg4 = algorithmic_bytes_per_pair(w, h)
+    leg = {"workload": "Farneback flow, 3840x2160 gray pairs resident in HBM, %d pairs in flight on one GPU (configs[4]: 8 per GPU)" % p4,
+           "unit": "frame-pairs/s"}
+    a4, b4 = synth.flow_pair(w, h)
+    for direct, key in ((False, "value"), (True, "value_direct_window")):
+        cs = [ofxcv.Context(dev) for _ in range(p4)]
+        bufs = []
+        for c in cs:
+            c.set_option("farneback.opencv_rounding", 0 if direct else 1)
+            with torch.cuda.stream(c.stream):
+                bufs.append((c.to_byte_grayscale(torch.from_numpy(a4).cuda()), c.to_byte_grayscale(torch.from_numpy(b4).cuda()),
+                             torch.empty((h, w, 2), device="cuda")))
+
+        def step4():
+            for c, (ga, gb, fl) in zip(cs, bufs):
+                with torch.cuda.stream(c.stream):
+                    c.calc_optical_flow_farneback(ga, gb, fl)
+        for _ in range(3):
+            step4()
+        rs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                step4()
+            torch.cuda.synchronize()
+            rs.append(8 * p4 / (time.perf_counter() - t0))
+        leg[key] = med(rs)
+        leg[key + "_frac_of_hbm_peak"] = alg4 * med(rs) / 1e9 / HBM_PEAK_GBS
+        for c in cs:
+            c.close()
+        del bufs
+    out["farneback_4k"] = leg
+    return out
 
 
 if __name__ == "__main__":

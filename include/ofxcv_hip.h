@@ -66,10 +66,10 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
- * While enabled, ofxcv_calc_optical_flow_farneback brackets every updating iteration step at pyramid
- * level 0 -- OpenCV-order mode: the carry pre-pass + the blur+solve+update kernel of one iteration;
- * direct-window mode: the fused two-iteration kernel -- with a hipEvent pair on the stream it is
- * launched on.  ofxcv_profile_read synchronises, adds up the pairs and returns the total
+ * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of one kernel at pyramid level 0
+ * with a hipEvent pair on the stream it is launched on.  enable = 1: the dominant kernel (OpenCV-order mode: the
+ * blur+solve+update kernel of one iteration, iterate3s_kernel; direct-window mode: the fused two-iteration
+ * kernel, iterate3x2_kernel); enable = 2: the carry pre-pass of the OpenCV-order mode (vsum_carry_kernel).  ofxcv_profile_read synchronises, adds up the pairs and returns the total
  * kernel time and the number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
 int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);

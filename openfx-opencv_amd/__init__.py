@@ -127,7 +127,8 @@ class Context:
         self._check(lib().ofxcv_ctx_set_option(self._h, name.encode(), C.c_int(int(value))))
 
     def profile_enable(self, on=True):
-        self._check(lib().ofxcv_profile_enable(self._h, C.c_int(1 if on else 0)))
+        """True/1: event pairs around the dominant kernel at level 0; 2: around the carry pre-pass (OpenCV-order mode); 0: off"""
+        self._check(lib().ofxcv_profile_enable(self._h, C.c_int(int(on))))
 
     def profile_read(self, reset=True):
         """(total_ms, launches) of the dominant kernel (level-0 fused iteration) since the last reset."""

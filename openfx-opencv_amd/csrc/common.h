@@ -71,7 +71,8 @@ struct ofxcv_ctx {
     DevBuf seg_work; // mean-shift pyramid (source + result per level) and mask
 
     // measurement hook: event pairs around the dominant kernel (see ofxcv_profile_enable)
-    bool prof_on = false;
+    int prof_on = 0;        // 0 off, 1 event pairs around the dominant kernel, 2 around the carry pre-pass of the OpenCV-order mode
+    bool prof_now = false;  // set by the level walk for the launches that are to be bracketed
     std::vector<hipEvent_t> prof_ev;  // start/stop pairs, recorded but not yet read
     double prof_ms = 0;
     long prof_launches = 0;

@@ -229,7 +229,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
 
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    ctx->prof_on = enable != 0;
+    ctx->prof_on = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return OFXCV_OK;
 }
 

@@ -1579,7 +1579,10 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         dim3 cgrid(ofxcv_div_up(w, 64), 5, G), grid(ofxcv_div_up(tiles_x, 2), nstrips);
 #define OFXCV_LAUNCH_SS(RW)                                                                                                              \
     do {                                                                                                                                 \
+        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
         hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw);            \
+        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
+        if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
         if (update && pipe)                                                                                                              \
             hipLaunchKernelGGL((iterate3s_kernel<true, RW, true>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
@@ -1589,7 +1592,10 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         else                                                                                                                             \
             hipLaunchKernelGGL((iterate3s_kernel<false, RW, false>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
+        if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
     } while (0)
+        const int mark = ctx->prof_now ? ctx->prof_on : 0;  // measurement hook: 1 = the iteration kernel, 2 = the carry pre-pass
+        int rc;
         const bool pipe = !(ctx->fb_strict_variant & 1);
         if (rw == 8) OFXCV_LAUNCH_SS(8);
         else if (rw == 4) OFXCV_LAUNCH_SS(4);
@@ -1821,7 +1827,9 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         for (int i = 0; i < iterations;) {
             const bool pair = fuse && i + 2 <= iterations - 1;
             const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
-            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+            const bool inner = prof && !pair && !gaussian && ctx->fb_opencv_rounding == 1 && winsize == 3;  // marks set around the kernels inside
+            ctx->prof_now = inner;
+            if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             if (pair) {  // two updating iterations in one launch
                 rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h, k == 0);
                 i += 2;
@@ -1833,8 +1841,9 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                     rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
                 i += 1;
             }
+            ctx->prof_now = false;
             if (rc) return rc;
-            if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+            if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             cur ^= 1;
         }
         prev_flow = out_flow;
@@ -1900,7 +1909,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     const bool use_graph = !ctx->prof_on && !ctx->fb_no_graph;
     if (!use_graph)
         return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations,
-                                 poly_n, poly_sigma, flags, ctx->prof_on);
+                                 poly_n, poly_sigma, flags, ctx->prof_on != 0);
     FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, flags, 0,
                       pyr_scale, poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr,
                       (ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) ? ctx->fb_vsum.ptr : nullptr};

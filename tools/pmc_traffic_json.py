@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_bench/summary.txt (tools/pmc_bench.sh) -> profiles/<tag>_pmc_traffic.json: HBM-side bytes per launch of
+the level-0 iteration kernels, read = sum of TCC_EA0_RDREQ_{32B,64B,128B} x size, write = WRREQ_64B x 64 + the rest x 32
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).  usage: pmc_traffic_json.py <summary.txt> <out.json>"""
+import collections
+import json
+import re
+import sys
+
+rows = collections.defaultdict(dict)
+for line in open(sys.argv[1]):
+    m = re.match(r"(.+?)\s+grid (\d+)\s+(\S+)\s+per-launch\s+([0-9.]+)", line)
+    if m:
+        rows[(m.group(1).strip(), int(m.group(2)))][m.group(3)] = float(m.group(4))
+
+
+def traffic(c):
+    rd = c.get("TCC_EA0_RDREQ_32B_sum", 0) * 32 + c.get("TCC_EA0_RDREQ_64B_sum", 0) * 64 + c.get("TCC_EA0_RDREQ_128B_sum", 0) * 128
+    w64 = c.get("TCC_EA0_WRREQ_64B_sum", 0)
+    wr = w64 * 64 + (c.get("TCC_EA0_WRREQ_sum", 0) - w64) * 32
+    return rd, wr
+
+
+out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --steps 2); per-launch averages per kernel and grid",
+       "kernels": {}}
+want = {"iterate3s_kernel<true, 8, true>": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0",
+        "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
+for (name, grid), c in rows.items():
+    for k, tag in want.items():
+        if name.startswith(k) and "TCC_EA0_RDREQ_sum" in c:
+            best = out["kernels"].get(tag)
+            if best and best["grid_threads"] >= grid:
+                continue
+            rd, wr = traffic(c)
+            out["kernels"][tag] = {"kernel": name, "grid_threads": grid, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+                                   "traffic_bytes_per_launch": rd + wr, "counters_per_launch": c}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+for k, v in out["kernels"].items():
+    print(k, v["kernel"], "%.1f MB" % (v["traffic_bytes_per_launch"] / 1e6))
