@@ -161,3 +161,45 @@ def test_concurrent_inpaint_calls(oracle, ofxcv):
     assert not errors, errors
     for k in range(8):
         assert np.array_equal(results[k], ref), k
+
+
+def test_index_map_known_answers_on_the_hip_path(gpu_ctx):
+    """The analytic known-answer tests that pin the oracle (tests/test_oracle_inpaint_segment.py) run against the maps
+    ofxcv_inpaint_telea itself returns, so the distance / fill-order parity is not only oracle-vs-product: straight-edge
+    hole -> T = 1, 2, 3, ... and a negated ring outside; row-major seeding + FIFO ties -> first hole column filled top to
+    bottom; symmetric hole -> every pixel filled exactly once, top-left corner first; constant colour comes back."""
+    h, w = 24, 40
+    rgb = np.full((h, w, 3), 100, np.uint8)
+    mask = np.zeros((h, w), np.uint8)
+    mask[:, 20:] = 255
+    dst, t, order = gpu_ctx.inpaint_telea(_dev(rgb), _dev(mask), 3.0, maps=True)
+    t, order = t.cpu().numpy(), order.cpu().numpy()
+    row = t[12, 1:-1]
+    assert row[19] == 0.0
+    assert np.allclose(row[20:30], np.arange(1, 11), atol=1e-5)
+    assert np.allclose(row[17:19], [-2, -1], atol=1e-5)
+    assert row[16] == 1.0e6 and row[10] == 1.0e6
+    col = order[:, 20]
+    assert col[0] == 0 and np.array_equal(col[1:], np.arange(1, h))
+    assert order[:, :20].max() == 0
+    c = np.full((40, 50, 3), (10, 120, 200), np.uint8)                         # constant image + bounded hole: comes back within
+    mc = np.zeros((40, 50), np.uint8)                                          # the reference's two roundings
+    mc[10:25, 15:30] = 255
+    oc = gpu_ctx.inpaint_telea(_dev(c), _dev(mc), 3.0).cpu().numpy()
+    assert np.abs(oc.astype(int) - c).max() <= 3 and np.array_equal(oc[mc == 0], c[mc == 0])
+    mask2 = np.zeros((21, 21), np.uint8)
+    mask2[6:15, 6:15] = 255
+    _, t2, o2 = gpu_ctx.inpaint_telea(_dev(np.full((21, 21, 3), 50, np.uint8)), _dev(mask2), 3.0, maps=True)
+    t2, o2 = t2.cpu().numpy(), o2.cpu().numpy()
+    assert o2[6, 6] == 1 and o2[6, 6] < o2[6, 14] < o2[14, 6] < o2[14, 14]
+    assert o2.max() == 81 and sorted(o2[o2 > 0].tolist()) == list(range(1, 82))
+    assert t2[1:-1, 1:-1][10, 10] > t2[1:-1, 1:-1][6, 6] > 0
+    # mask rule on the HIP path: (1,0,0) and (0,0,4) are holes, (0,1,0) and (0,0,5) are not
+    px = np.zeros((1, 6, 4), np.uint8)
+    px[0, :, 3] = 255
+    px[0, 1, :3] = (1, 0, 0)
+    px[0, 2, :3] = (0, 1, 0)
+    px[0, 3, :3] = (0, 0, 4)
+    px[0, 4, :3] = (0, 0, 5)
+    px[0, 5, :3] = (255, 255, 255)
+    assert gpu_ctx.inpaint_mask(_dev(px), 0).cpu().numpy()[0].tolist() == [255, 255, 0, 255, 0, 0]

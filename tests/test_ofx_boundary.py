@@ -234,6 +234,42 @@ def test_inpaint_render_through_ofx(host, oracle):
 
 
 @pytest.mark.gpu
+def test_inpaint_noise_through_ofx(host, oracle):
+    """inpaintnoise > 0: the plugin's write-back adds libc rand() noise on masked pixels (inpaint.cpp:320-358).  Replayed
+    here with the same libc: srand(rs) for every x of every 4th row, a draw on every 4th x of a masked pixel, rs chained
+    on the red value; noise_div = (int)(1/noise)."""
+    from openfx_opencv_amd import synth
+    libc = C.CDLL(None)
+    w, h = 160, 120
+    fr = synth.inpaint_frame(w, h)
+    for noise in (0.5, 0.2):
+        pl = Plugin(host, "inpaint")
+        inst = pl.instance()
+        out = np.zeros_like(fr)
+        pl.set_image(inst, "Source", 1.0, fr, "OfxBitDepthByte")
+        pl.set_image(inst, "Output", 1.0, out, "OfxBitDepthByte")
+        host.mh_set_param_double(inst, b"inpaintnoise", C.c_double(noise))
+        assert pl.render(inst, 1.0, w, h) == STAT_OK
+        clean = oracle.inpaint_render(fr, 3.0, 1.0)
+        mask = oracle.inpaint_mask(fr, 1)
+        noise_div = int(1 / noise) or 1
+        ref = clean.copy()
+        rs = 0
+        for y in range(h):
+            for x in range(w):
+                if y % 4 == 0:
+                    libc.srand(rs)
+                a = 0
+                if mask[y, x] > 0 and x % 4 == 0:
+                    a = int((libc.rand() % 10 - 5) / noise_div)          # C division truncates towards zero
+                    rs = (rs + int(clean[y, x, 0])) % 256
+                ref[y, x, :3] = np.clip(clean[y, x, :3].astype(int) + a, 0, 255)
+        assert np.array_equal(out, ref)
+        assert (out != clean).any()                                          # the noise really was applied
+        pl.destroy(inst)
+
+
+@pytest.mark.gpu
 def test_segment_render_through_ofx(host, oracle):
     from openfx_opencv_amd import synth
     fr = synth.inpaint_frame(322, 243, n_holes=0)                            # not a multiple of 4: the plugin rounds down

@@ -65,3 +65,12 @@ def test_mean_shift_4k_properties(oracle, gpu_ctx):
     got = full[y0:y0 + 256, x0:x0 + 256].cpu().numpy()
     same = (got[64:-64, 64:-64] == ref[64:-64, 64:-64]).all(axis=2)
     assert same.mean() > 0.999, same.mean()
+
+
+def test_mean_shift_4k_max_level_2_full_frame(oracle, gpu_ctx):
+    """BASELINE config 4 exactly: 3840x2160, sp 10, sr 20, maxLevel 2 -- the whole frame against the oracle (about 10 s of CPU),
+    every pixel identical (all-integer arithmetic)."""
+    fr = np.ascontiguousarray(_img(3840, 2160)[..., :3])
+    got = gpu_ctx.pyr_mean_shift_filtering(_dev(fr), 10, 20, 2).cpu().numpy()
+    ref = oracle.pyr_mean_shift(fr, 10, 20, 2)
+    assert np.array_equal(got, ref), "differing pixels: %d" % (got != ref).any(axis=2).sum()

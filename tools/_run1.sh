@@ -1,9 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2e
-( time python bench.py ) > gpurun_out/r2e/bench.json 2> gpurun_out/r2e/bench.err
-tail -5 gpurun_out/r2e/bench.err
-python - <<'PY'
-import json
-l = json.loads(open("gpurun_out/r2e/bench.json").read().strip().splitlines()[-1])
-print(json.dumps(l, indent=1)[:6000])
-PY
+python -m pytest tests/test_cv2_crosscheck.py tests/test_inpaint_gpu.py tests/test_segment_gpu.py tests/test_ofx_boundary.py -m gpu -q -s -rs 2>&1 | grep -v amdgpu.ids | tail -25
