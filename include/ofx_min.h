@@ -93,6 +93,7 @@ OfxExport int OfxGetNumberOfPlugins(void);
 #define kOfxMemorySuite "OfxMemorySuite"
 #define kOfxMultiThreadSuite "OfxMultiThreadSuite"
 #define kOfxMessageSuite "OfxMessageSuite"
+#define kOfxParamPropChoiceLabelOption "OfxParamPropChoiceLabelOption" /* per-option help text (host extension used by the Support library) */
 #define kOfxInteractSuite "OfxInteractSuite"
 
 /* ---- generic properties ---- */
@@ -257,6 +258,8 @@ typedef struct OfxMultiThreadSuiteV1 {
 } OfxMultiThreadSuiteV1;
 
 #define kOfxMessageError "OfxMessageError"
+#define kOfxMessageLog "OfxMessageLog"
+#define kOfxMessageMessage "OfxMessageMessage"
 typedef struct OfxMessageSuiteV1 {
     OfxStatus (*message)(void *handle, const char *messageType, const char *messageId, const char *format, ...);
 } OfxMessageSuiteV1;

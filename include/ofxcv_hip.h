@@ -61,6 +61,7 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
  *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
+ *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
  *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
  *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
@@ -155,6 +156,10 @@ int ofxcv_inpaint_telea(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step
 int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int channels,
                   const uint8_t *d_mask, ptrdiff_t mask_step, int width, int height, double radius, int method,
                   uint8_t *d_dst, ptrdiff_t dst_step, float *d_t_map, int *d_order_map, void *stream);
+/* The colour fill is a dataflow kernel whose wavefronts poll each other's results with a bounded number of polls
+ * (context option "inpaint.spin_limit", default 2^21); a fill whose poll gave up is repeated with a barrier-scheduled
+ * kernel (identical colours).  Number of such repeats on this context so far: */
+long ofxcv_inpaint_fallback_count(const ofxcv_ctx *ctx);
 
 /* ---- whole inpaint render() body for host-resident OFX images (noise == 0 path) --------------
  * replaces opencv2fx/inpaint/inpaint.cpp:286-358: RGBA in -> RGBA out, alpha forced to 255.  h_mask_out

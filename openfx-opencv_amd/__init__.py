@@ -62,7 +62,7 @@ EXPORTS = [
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
-    "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_render_host",
+    "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_fallback_count", "ofxcv_inpaint_render_host",
     "ofxcv_pyr_mean_shift_filtering", "ofxcv_segment_render_host",
 ]
 
@@ -230,6 +230,10 @@ class Context:
                    C.c_int(w), C.c_int(h), C.c_double(radius), C.c_int(method), _ptr(dst), C.c_ssize_t(dst.stride(0)),
                    _ptr(t) if maps else None, _ptr(order) if maps else None)
         return (dst, t, order) if maps else dst
+
+    def inpaint_fallback_count(self):
+        lib().ofxcv_inpaint_fallback_count.restype = C.c_long
+        return int(lib().ofxcv_inpaint_fallback_count(self._h))
 
     def inpaint_telea(self, src, mask, radius=3.0, maps=False):
         return self.inpaint(src, mask, radius, INPAINT_TELEA, maps)

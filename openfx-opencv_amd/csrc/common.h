@@ -68,6 +68,10 @@ struct ofxcv_ctx {
     DevBuf ip_maps;  // distance / order maps and the per-level pixel lists of the colour fill
     DevBuf ip_img;   // device copies of the host images (render_host)
     DevBuf ip_work;  // 4-byte-per-pixel working images of the colour fill
+    DevBuf ip_flag;  // error flag of the dataflow fill (a poll gave up)
+    DevBuf ip_sched2; // level schedule of the fall-back fill
+    int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)
+    long ip_fallbacks = 0;   // fills that were repeated with the barrier-scheduled kernel
     DevBuf seg_work; // mean-shift pyramid (source + result per level) and mask
 
     // measurement hook: event pairs around the dominant kernel (see ofxcv_profile_enable)

@@ -161,7 +161,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_level)
         if (e) (void)hipEventDestroy(e);
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
@@ -173,6 +173,8 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (ctx->copy) (void)hipStreamDestroy(ctx->copy);
     delete ctx;
 }
+
+long ofxcv_inpaint_fallback_count(const ofxcv_ctx *ctx) { return ctx ? ctx->ip_fallbacks : -1; }
 
 const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
@@ -194,6 +196,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "farneback.opencv_rounding")) {
         ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "inpaint.spin_limit")) {
+        ctx->ip_spin_limit = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.strict_variant")) {

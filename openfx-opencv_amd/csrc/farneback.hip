@@ -1706,6 +1706,7 @@ int ofxcv_farneback_level_geom(int width, int height, double pyr_scale, int k, i
 int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step, int width, int height, int lw, int lh,
                               double sigma, int ksize, float *d_I, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_img || !d_I || width <= 0 || height <= 0 || lw <= 0 || lh <= 0 || ksize < 1 || !(ksize & 1) || step < (size_t)width)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_pyr_image: bad argument");
     int rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(2 * lw + 2) * height));
@@ -1716,6 +1717,7 @@ int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step,
 int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n, double poly_sigma,
                             void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_I || !d_R || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_polyexp: bad argument");
     return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma);
 }
@@ -1723,6 +1725,7 @@ int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int hei
 int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow, size_t flow_step,
                                     int width, int height, float *d_M, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_R0 || !d_R1 || !d_flow || !d_M || width <= 0 || height <= 0 || (flow_step & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
     hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
@@ -1734,6 +1737,7 @@ int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const flo
 int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_M_in, float *d_M_out,
                                      float *d_flow, size_t flow_step, int width, int height, int winsize, int update, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_M_in || width <= 0 || height <= 0 || winsize < 1 || !(winsize & 1) || (d_flow && (flow_step & 7)) ||
         (update && (!d_R0 || !d_R1 || !d_M_out || d_M_out == d_M_in)) || (!update && !d_flow))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_flow_blur: bad argument");
@@ -1858,6 +1862,7 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
                                       size_t next_step, float *d_flow, size_t flow_step, int width, int height, double pyr_scale,
                                       int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_prev || !d_next || !d_flow || width <= 0 || height <= 0 || prev_step < (size_t)width || next_step < (size_t)width ||
         flow_step < (size_t)width * 8 || (flow_step & 7) || (((uintptr_t)d_flow) & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument");
@@ -1865,8 +1870,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: flags 0x%x not supported (USE_INITIAL_FLOW, FARNEBACK_GAUSSIAN)", flags);
     if (!(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || iterations < 1 || winsize < 1 || !(winsize & 1))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad parameter");
-    if ((size_t)plane_pitch(width) * height >= (1u << 28))
-        return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: frames above 2^28 pixels exceed the 32-bit buffer offsets");
+    // a 5-plane field is addressed through one buffer resource with 32-bit byte offsets: 5 * pitch * height * 4 < 2^31
+    if ((size_t)plane_pitch(width) * height * 20 >= (size_t)1 << 31)
+        return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: frames above %d pixels exceed the 32-bit buffer offsets",
+                          (int)(((size_t)1 << 31) / 20));
     hipStream_t s = ofxcv_stream(ctx, stream);
     const uint8_t *img[2] = {d_prev, d_next};
     const size_t step[2] = {prev_step, next_step};

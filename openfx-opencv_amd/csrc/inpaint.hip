@@ -372,6 +372,8 @@ struct FillArgs {
     int w, h, range;
     const int *lvl_pix, *lvl_ord, *lvl_off, *comp_off;   // level schedule (large radius)
     const int *cmp_pix, *cmp_ord, *cmp_off;              // dataflow schedule: the pixels of each component in fill order
+    int *err;                                            // dataflow: set when a poll gave up (see the poll loop)
+    int spin_limit;                                      // polls a wavefront spends on one awaited colour before it gives up
 };
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between lanes of ONE wavefront
@@ -476,10 +478,18 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     }
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
+                        int spins = 0;
                         while (wait_on[u]) {  // agent-scope load: straight from the L2, never a stale L1 line
                             const uint32_t v = __hip_atomic_load(wait_on[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (v >> 24) {
                                 rgb[u] = v;
+                                wait_on[u] = nullptr;
+                            } else if (++spins > a.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                                // Bounded wait.  The owner of the awaited pixel is a wavefront of this component's workgroups; should
+                                // it not be running (a partner workgroup that never became resident), give up instead of
+                                // spinning for ever inside the host's render thread: flag the launch, let every wavefront
+                                // drain, and the host repeats the fill with the barrier-scheduled kernel.
+                                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 wait_on[u] = nullptr;
                             } else {
                                 __builtin_amdgcn_s_sleep(1);
@@ -643,12 +653,20 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     }
 }
 
-// The workgroups of a dataflow fill wait for each other's results, which only terminates if the workgroups they wait
-// for get to run.  One launch is at most a few dozen workgroups on a 256-CU device, but many concurrent launches (one
-// per rendering host thread) could fill the device with workgroups that all wait for partners still in the dispatch
-// queue.  At most kMaxConcurrentFills fills are therefore in flight per process; the slot is held until the call's
-// final stream synchronisation.
+// Termination of the dataflow fill.  A wavefront only ever waits for pixels of its own component with a smaller order
+// number.  Components with ONE workgroup (up to 2000 pixels -- all of them for dust-like masks, however many
+// components there are) therefore wait only inside their workgroup, whose wavefronts are co-resident by construction:
+// the size of the grid does not matter for them.  A larger component is spread over 2..8 workgroups with consecutive
+// ids; those do wait for each other, so a workgroup can spin while a partner is still in the dispatch queue.
+// Workgroups are dispatched in id order, so per launch at most 7 resident workgroups can be in that state (the ones
+// at the dispatch frontier); all others have every partner resident, run to completion and free their slots.  A
+// device-wide stall would need every resident slot held by such frontier waiters, i.e. ~70 concurrent fills on 512
+// slots; kMaxConcurrentFills bounds the fills of this process, and for everything that reasoning does not cover
+// (other processes sharing the GPU, a dispatcher that does not go in order) the polls are BOUNDED: a wavefront that
+// has spun kSpinLimit times raises FillArgs::err, every wavefront drains, and the host repeats the fill with the
+// barrier-scheduled kernel (one workgroup per component, no cross-workgroup waits).
 constexpr int kMaxConcurrentFills = 4;
+constexpr int kSpinLimit = 1 << 21;  // ~2 s of polling one colour (a dependency normally resolves in microseconds)
 class FillSlot {
     static std::mutex &mu() { static std::mutex m; return m; }
     static std::condition_variable &cv() { static std::condition_variable c; return c; }
@@ -690,6 +708,7 @@ extern "C" {
 int ofxcv_inpaint_mask(ofxcv_ctx *ctx, const uint8_t *d_rgba, ptrdiff_t row_bytes, int width, int height, int dilate_iters,
                        uint8_t *d_mask, ptrdiff_t mask_step, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_rgba || !d_mask || width <= 0 || height <= 0 || dilate_iters < 0 || mask_step < width || (((uintptr_t)d_rgba | (uintptr_t)row_bytes) & 3))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_mask: bad argument");
     int rc = ofxcv_reserve(ctx, ctx->ip_tmp, (size_t)width * height);
@@ -709,6 +728,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
                   ptrdiff_t mask_step, int width, int height, double radius, int method, uint8_t *d_dst, ptrdiff_t dst_step,
                   float *d_t_map, int *d_order_map, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_src || !d_mask || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || d_src == d_dst)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint: bad argument");
     if (method != OFXCV_INPAINT_NS && method != OFXCV_INPAINT_TELEA)
@@ -783,9 +803,48 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         fa.comp_off = (const int *)(dp + off_co);
         FillSlot slot;  // released after the stream synchronisation below (or on an early return)
         if (range <= kMaxLdsRange) {
+            // dataflow kernel with bounded polls; its error flag lives behind the schedule arrays
+            rc = ofxcv_reserve(ctx, ctx->ip_flag, 256);
+            if (rc) return rc;
+            fa.err = (int *)ctx->ip_flag.ptr;
+            fa.spin_limit = ctx->ip_spin_limit >= 0 ? ctx->ip_spin_limit : kSpinLimit;
+            OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fa.err, 0, sizeof(int), s));
             if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
             else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+            OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
+            int timed_out = 0;
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(&timed_out, fa.err, sizeof(int), hipMemcpyDeviceToHost, s));
+            OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+            if (timed_out) {
+                // a poll gave up: repeat with the level schedule (workgroup barriers between dependency levels, nothing
+                // waits across workgroups).  Same arithmetic, same order: identical colours.
+                ctx->ip_fallbacks++;
+                build_levels(m, false);
+                const size_t o_pix = 0, o_po = align_up((size_t)n * 4, 256), o_lo = align_up(o_po + (size_t)n * 4, 256),
+                             o_co = align_up(o_lo + m.lvl_off.size() * 4, 256), tot = align_up(o_co + m.comp_off.size() * 4, 256);
+                rc = ofxcv_reserve(ctx, ctx->ip_sched2, tot);
+                if (rc) return rc;
+                char *d2 = (char *)ctx->ip_sched2.ptr;
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_lo, m.lvl_off.data(), m.lvl_off.size() * 4, hipMemcpyHostToDevice, s));
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_co, m.comp_off.data(), m.comp_off.size() * 4, hipMemcpyHostToDevice, s));
+                fa.lvl_pix = fa.cmp_pix = (const int *)(d2 + o_pix);
+                fa.lvl_ord = fa.cmp_ord = (const int *)(d2 + o_po);
+                fa.lvl_off = fa.cmp_off = (const int *)(d2 + o_lo);
+                fa.comp_off = (const int *)(d2 + o_co);
+                // working copy back to "nothing filled yet"
+                if (channels == 4)
+                    hipLaunchKernelGGL(pack_rgbx_kernel<4>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+                else
+                    hipLaunchKernelGGL(pack_rgbx_kernel<3>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+                const int nwg = (int)m.comp_off.size() - 1;
+                if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+                else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+            }
         } else {
+            fa.err = nullptr;
+            fa.spin_limit = 0;
             if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
             else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
         }

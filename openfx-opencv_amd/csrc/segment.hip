@@ -218,6 +218,7 @@ int ofxcv_pyr_mean_shift_filtering(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff
                                    double sp, double sr, int max_level, int max_iter, double eps, uint8_t *d_dst, ptrdiff_t dst_step,
                                    void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_src || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "pyr_mean_shift_filtering: bad argument");
     if (max_level < 0 || max_level > 8) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "pyr_mean_shift_filtering: max_level outside 0..8");

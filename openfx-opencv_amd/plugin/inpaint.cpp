@@ -16,9 +16,8 @@ using namespace ofxcv_plugin;
 #define INPAINT_NOISE "inpaintnoise"
 #define PLUGIN_GROUPING "Draw"  // opencv2fx.h:10
 
-static const char *kDescription =
-    "Telea inpainting of the black (integer luma 0) regions of the source, "
-    "from the OpenCV inpaint example of the opencv2fx plugin set; computed on AMD Instinct GPUs.";
+// the reference's property value (inpaint.cpp:40-67): one credit line, then the licence notice
+static const char *kDescription = "OpenCV inpaint. Wrapper provided by Bernd Porr -- http://www.berndporr.me.uk\n\n" OFXCV_OFX_LICENCE_NOTICE;
 
 namespace {
 
@@ -171,6 +170,10 @@ OfxStatus plugin_main(const char *action, const void *handle, OfxPropertySetHand
     return guarded([&]() -> OfxStatus {
         OfxImageEffectHandle effect = (OfxImageEffectHandle)handle;
         if (!std::strcmp(action, kOfxActionLoad)) return g.fetch_basic();
+        if (!std::strcmp(action, "OfxActionUnload")) {  // not handled by the reference (reply default); device contexts are released
+            ThreadContext::release_all();
+            return kOfxStatReplyDefault;
+        }
         if (!std::strcmp(action, kOfxActionDescribe)) return describe(effect);
         if (!std::strcmp(action, kOfxImageEffectActionDescribeInContext)) return describe_in_context(effect, inArgs);
         if (!std::strcmp(action, kOfxImageEffectActionRender)) return render(effect, inArgs, outArgs);

@@ -23,6 +23,28 @@ struct SuiteError : std::exception {
 };
 
 // opencv2fx.cpp:8-25: OK / Reply* pass, ErrMemory -> bad_alloc, anything else -> Suite exception
+// kOfxPropPluginDescription of the two opencv2fx plugins is the Open Effects Association's BSD licence notice
+// (segment.cpp:41-66; inpaint.cpp:40-67 puts one credit line in front).  The property value is part of the drop-in
+// contract, so it is reproduced character for character -- including the reference's missing line breaks in the
+// disclaimer paragraph.
+#define OFXCV_OFX_LICENCE_NOTICE                                                                                          \
+    "Copyright (c) 2003, The Open Effects Association Ltd. All rights reserved.\n\n"                                        \
+    "Redistribution and use in source and binary forms, with or without\nmodification, are permitted provided that the "  \
+    "following conditions are met:\n\n"                                                                                   \
+    "    * Redistributions of source code must retain the above copyright notice,\n      this list of conditions and "    \
+    "the following disclaimer.\n"                                                                                         \
+    "    * Redistributions in binary form must reproduce the above copyright notice,\n      this list of conditions "     \
+    "and the following disclaimer in the documentation\n      and/or other materials provided with the distribution.\n"  \
+    "    * Neither the name The Open Effects Association Ltd, nor the names of its\n      contributors may be used to "   \
+    "endorse or promote products derived from this\n      software without specific prior written permission.\n\n"       \
+    "THIS SOFTWARE IS PROVIDED BY THE COPYRIGHT HOLDERS AND CONTRIBUTORS \"AS IS\" AND" "ANY EXPRESS OR IMPLIED "          \
+    "WARRANTIES, INCLUDING, BUT NOT LIMITED TO, THE IMPLIED" "WARRANTIES OF MERCHANTABILITY AND FITNESS FOR A "           \
+    "PARTICULAR PURPOSE ARE" "DISCLAIMED. IN NO EVENT SHALL THE COPYRIGHT OWNER OR CONTRIBUTORS BE LIABLE FOR" "ANY "     \
+    "DIRECT, INDIRECT, INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES" "(INCLUDING, BUT NOT LIMITED TO, "       \
+    "PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES;" "LOSS OF USE, DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER "    \
+    "CAUSED AND ON" "ANY THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT" "(INCLUDING NEGLIGENCE OR " \
+    "OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF THIS" "SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE."
+
 inline void check(OfxStatus stat) {
     switch (stat) {
         case kOfxStatOK:
@@ -148,6 +170,7 @@ class ThreadContext {
   public:
     static ofxcv_ctx *get() {
         thread_local Holder h;
+        std::lock_guard<std::mutex> lock(h.mu);  // uncontended except against release_all()
         if (!h.ctx) {
             static std::atomic<int> next{0};
             int n = ofxcv_device_count();
@@ -158,14 +181,40 @@ class ThreadContext {
         }
         return h.ctx;
     }
+    // OfxActionUnload: the host guarantees no render is in flight; every context this plugin binary created on any
+    // thread is destroyed (streams, scratch, pinned staging, registrations), threads that render again re-create theirs
+    static void release_all() {
+        std::lock_guard<std::mutex> lock(registry_mu());
+        for (Holder *h : registry()) {
+            std::lock_guard<std::mutex> hl(h->mu);
+            if (h->ctx) ofxcv_ctx_destroy(h->ctx);
+            h->ctx = nullptr;
+        }
+    }
 
   private:
     struct Holder {
         ofxcv_ctx *ctx = nullptr;
+        std::mutex mu;
+        Holder() {
+            std::lock_guard<std::mutex> lock(registry_mu());
+            registry().push_back(this);
+        }
         ~Holder() {
+            {
+                std::lock_guard<std::mutex> lock(registry_mu());
+                auto &r = registry();
+                for (size_t i = 0; i < r.size(); i++)
+                    if (r[i] == this) {
+                        r.erase(r.begin() + i);
+                        break;
+                    }
+            }
             if (ctx) ofxcv_ctx_destroy(ctx);
         }
     };
+    static std::mutex &registry_mu() { static std::mutex m; return m; }
+    static std::vector<Holder *> &registry() { static std::vector<Holder *> r; return r; }
 };
 
 inline void check_hip(ofxcv_ctx *ctx, int rc) {

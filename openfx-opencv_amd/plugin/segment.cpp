@@ -4,8 +4,11 @@
 // and parameters (:344-414), action dispatch (:483-522).  The reference's cvPyrSegmentation call (:296-302,
 // OpenCV <= 2.4 legacy pyramid linking, source not in the reference tree) is served by the mean-shift
 // segmentation BASELINE.json defines for this workload: pyramid level 2 as in the reference (:280),
-// spatial radius 10, and `threshold 2` (the reference's cluster-merge colour threshold) as the colour radius.
-// `threshold 1` is declared for parameter-set identity and not used by mean-shift.
+// `threshold 2` (the reference's cluster-merge colour threshold) as the colour radius and `threshold 1` (the
+// reference's link threshold, 1..255, default 250) as the spatial radius, scaled so that the default gives the
+// spatial radius 10 of BASELINE.json: sp = threshold1 / 25.  The substitution is announced to the host through the
+// message suite (log message, once per instance) -- the plugin identifier and parameter set are the reference's, the
+// pixels are mean-shift's.
 #include <vector>
 
 #include "ofxcv_plugin.h"
@@ -16,9 +19,7 @@ using namespace ofxcv_plugin;
 #define THRESHOLD2 "threshold2"
 #define PLUGIN_GROUPING "Draw"
 
-static const char *kDescription =
-    "Colour segmentation of the source image (pyramid mean-shift filtering), "
-    "from the OpenCV segmentation example of the opencv2fx plugin set; computed on AMD Instinct GPUs.";
+static const char *kDescription = OFXCV_OFX_LICENCE_NOTICE;  // the reference's property value (segment.cpp:41-66)
 
 namespace {
 
@@ -27,6 +28,7 @@ Suites g;
 struct InstanceData {  // segment.cpp:100-105 (the CvMemStorage / CvSeq members have no counterpart here)
     OfxParamHandle threshold1 = nullptr, threshold2 = nullptr;
     int isGeneralEffect = 0;
+    bool announced = false;  // the substitution notice has been logged
 };
 
 InstanceData *instance_data(OfxImageEffectHandle effect) {
@@ -78,7 +80,13 @@ OfxStatus render(OfxImageEffectHandle instance, OfxPropertySetHandle inArgs, Ofx
     double t1, t2;
     check(g.param->paramGetValueAtTime(d->threshold1, time, &t1));
     check(g.param->paramGetValueAtTime(d->threshold2, time, &t2));
-    (void)t1;
+    if (!d->announced && g.message) {
+        d->announced = true;
+        g.message->message(instance, kOfxMessageLog, "ofxcv.segment.substitution",
+                           "cvPyrSegmentation(level 2, threshold 1, threshold 2) is rendered as pyramid mean-shift filtering on the GPU: "
+                           "spatial radius = threshold 1 / 25 (= %g), colour radius = threshold 2 (= %d), pyramid level 2",
+                           t1 / 25.0, (int)t2 > 0 ? (int)t2 : 1);
+    }
 
     const int level = 2;                                   // :280
     const int w = src.img.width() & -(1 << level);         // :283-284: the processed rectangle is rounded down
@@ -87,7 +95,8 @@ OfxStatus render(OfxImageEffectHandle instance, OfxPropertySetHandle inArgs, Ofx
     std::vector<unsigned char> image1((size_t)w * h * 4);
     ofxcv_ctx *ctx = ThreadContext::get();
     const double sr = (int)t2 > 0 ? (double)(int)t2 : 1.0;
-    check_hip(ctx, ofxcv_segment_render_host(ctx, (const uint8_t *)src.img.data, src.img.row_bytes, w, h, 10.0, sr, level, image1.data(),
+    const double sp = t1 / 25.0 >= 1.0 ? t1 / 25.0 : 1.0;   // threshold 1 (1..255, default 250) -> spatial radius (default 10)
+    check_hip(ctx, ofxcv_segment_render_host(ctx, (const uint8_t *)src.img.data, src.img.row_bytes, w, h, sp, sr, level, image1.data(),
                                              (ptrdiff_t)w * 4));
     // write-back of the reduced rectangle, alpha 255 (:307-323)
     for (int y = rw.y1; y < rw.y1 + h; y++) {
@@ -148,6 +157,10 @@ OfxStatus plugin_main(const char *action, const void *handle, OfxPropertySetHand
     return guarded([&]() -> OfxStatus {
         OfxImageEffectHandle effect = (OfxImageEffectHandle)handle;
         if (!std::strcmp(action, kOfxActionLoad)) return g.fetch_basic();
+        if (!std::strcmp(action, "OfxActionUnload")) {  // not handled by the reference (reply default); device contexts are released
+            ThreadContext::release_all();
+            return kOfxStatReplyDefault;
+        }
         if (!std::strcmp(action, kOfxActionDescribe)) return describe(effect);
         if (!std::strcmp(action, kOfxImageEffectActionDescribeInContext)) return describe_in_context(effect, inArgs);
         if (!std::strcmp(action, kOfxImageEffectActionRender)) return render(effect, inArgs, outArgs);

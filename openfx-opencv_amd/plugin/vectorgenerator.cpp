@@ -13,6 +13,8 @@
 #include <cmath>
 #include <vector>
 
+#include <string>
+
 #include "ofxcv_plugin.h"
 
 using namespace ofxcv_plugin;
@@ -33,6 +35,9 @@ const ChoiceDef kChannels[4] = {
     {"bChannel", "B channel", "Selects which component of the motion vectors to set in the blue channel of the output image", 3},
     {"aChannel", "A channel", "Selects which component of the motion vectors to set in the alpha channel of the output image", 4}};
 const char *kChannelOptions[5] = {"0", "forward.u", "forward.v", "backward.u", "backward.v"};
+// per-option help texts of appendOption(name, hint), VectorGenerator.cpp:126-137 (the last one says "x flow" in the reference too)
+const char *kChannelOptionHints[5] = {"0 constant channel", "x flow (in pixels) to the next frame.", "y flow (in pixels) to the next frame.",
+                                      "x flow (in pixels) to the previous frame.", "x flow (in pixels) to the previous frame."};
 
 enum Method { eFarneback = 0, eSimpleFlow = 1, eDualTVL1 = 2 };  // VectorGenerator.cpp:219-224
 
@@ -120,8 +125,15 @@ OfxStatus describe_in_context(OfxImageEffectHandle effect, OfxPropertySetHandle)
     for (const ChoiceDef &c : kChannels) {
         check(g.param->paramDefine(params, kOfxParamTypeChoice, c.name, &p));
         set_labels(p, c.label);
-        check(g.prop->propSetString(p, kOfxParamPropHint, 0, c.hint));
-        for (int i = 0; i < 5; i++) check(g.prop->propSetString(p, kOfxParamPropChoiceOption, i, kChannelOptions[i]));
+        // ChoiceParamDescriptor::appendOption(name, hint): the option help goes into the host's per-option label property
+        // and, on hosts without it, is appended to the parameter hint as "name: hint" lines
+        std::string hint = c.hint;
+        for (int i = 0; i < 5; i++) {
+            check(g.prop->propSetString(p, kOfxParamPropChoiceOption, i, kChannelOptions[i]));
+            if (g.prop->propSetString(p, kOfxParamPropChoiceLabelOption, i, kChannelOptionHints[i]) != kOfxStatOK)
+                hint += std::string("\n") + kChannelOptions[i] + ": " + kChannelOptionHints[i];
+        }
+        check(g.prop->propSetString(p, kOfxParamPropHint, 0, hint.c_str()));
         check(g.prop->propSetInt(p, kOfxParamPropDefault, 0, c.def));
         check(g.prop->propSetInt(p, kOfxParamPropAnimates, 0, 1));
         check(g.prop->propSetString(page, kOfxParamPropPageChild, child++, c.name));
@@ -360,7 +372,10 @@ OfxStatus plugin_main(const char *action, const void *handle, OfxPropertySetHand
     return guarded([&]() -> OfxStatus {
         OfxImageEffectHandle effect = (OfxImageEffectHandle)handle;
         if (!std::strcmp(action, kOfxActionLoad)) return g.fetch_basic();
-        if (!std::strcmp(action, kOfxActionUnload)) return kOfxStatOK;  // the reference frees its LUT manager here (:697)
+        if (!std::strcmp(action, kOfxActionUnload)) {  // the reference frees its LUT manager here (:697); this one its device contexts
+            ThreadContext::release_all();
+            return kOfxStatOK;
+        }
         if (!std::strcmp(action, kOfxActionDescribe)) return describe(effect);
         if (!std::strcmp(action, kOfxImageEffectActionDescribeInContext)) return describe_in_context(effect, inArgs);
         if (!std::strcmp(action, kOfxActionCreateInstance)) return create_instance(effect);

@@ -203,3 +203,21 @@ def test_index_map_known_answers_on_the_hip_path(gpu_ctx):
     px[0, 4, :3] = (0, 0, 5)
     px[0, 5, :3] = (255, 255, 255)
     assert gpu_ctx.inpaint_mask(_dev(px), 0).cpu().numpy()[0].tolist() == [255, 255, 0, 255, 0, 0]
+
+
+def test_dataflow_fill_bounded_polls_fall_back_to_the_barrier_kernel(oracle, ofxcv):
+    """the polls of the dataflow fill are bounded; with the bound forced to 0 every awaited colour 'times out', the launch
+    raises its error flag and the fill is repeated with the barrier-scheduled kernel: same colours, and the context
+    counts the fall-back.  With the default bound there is no fall-back."""
+    fr = _frame(333, 257, holes=8)
+    mask = oracle.inpaint_mask(fr, 1)
+    rgb = np.ascontiguousarray(fr[..., :3])
+    ref = oracle.inpaint_telea(rgb, mask, 3.0)
+    c = ofxcv.Context(0)
+    assert np.array_equal(c.inpaint_telea(_dev(rgb), _dev(mask), 3.0).cpu().numpy(), ref) and c.inpaint_fallback_count() == 0
+    c.set_option("inpaint.spin_limit", 0)
+    assert np.array_equal(c.inpaint_telea(_dev(rgb), _dev(mask), 3.0).cpu().numpy(), ref)
+    assert c.inpaint_fallback_count() == 1
+    assert np.array_equal(c.inpaint(_dev(rgb), _dev(mask), 3.0, ofxcv.INPAINT_NS).cpu().numpy(), oracle.inpaint(rgb, mask, 3.0, oracle.INPAINT_NS))
+    assert c.inpaint_fallback_count() == 2
+    c.close()

@@ -114,6 +114,11 @@ def test_error_convention(host, name):
     pl.destroy(inst)
 
 
+def _same_text(text, length, sha256):
+    import hashlib
+    assert len(text) == length and hashlib.sha256(text.encode()).hexdigest() == sha256
+
+
 def test_describe_inpaint(host):
     d = Plugin(host, "inpaint").dump()
     p = _props(d["props"])
@@ -134,6 +139,10 @@ def test_describe_inpaint(host):
         assert (q["OfxPropLabel"], q["OfxParamPropDisplayMin"], q["OfxParamPropDisplayMax"], q["OfxParamPropDefault"], q["OfxParamPropMin"]) == (label, dmin, dmax, default, 0)
         assert q["OfxParamPropScriptName"] == name
     assert params["Main"][0] == "OfxParamTypePage" and params["Main"][1]["OfxParamPropPageChild"] == ["threshold1", "threshold2"]
+    # kOfxPropPluginDescription is the reference's value (inpaint.cpp:40-67: credit line + the OFX Association licence notice,
+    # incl. its missing line breaks): length and SHA-256 of the reference's string literal
+    _same_text(p["OfxPropPluginDescription"], 1618, "5d613ff3611447ff99c450a0c2cad42cc9cb3b7b316112509c478c783310a53c")
+    assert p["OfxPropPluginDescription"].startswith("OpenCV inpaint. Wrapper provided by Bernd Porr")
 
 
 def test_describe_segment(host):
@@ -146,6 +155,8 @@ def test_describe_segment(host):
     assert (params["threshold1"]["OfxPropLabel"], params["threshold1"]["OfxParamPropDefault"], params["threshold1"]["OfxParamPropDisplayMax"]) == ("threshold 1", 250, 255)
     assert (params["threshold2"]["OfxPropLabel"], params["threshold2"]["OfxParamPropDefault"], params["threshold2"]["OfxParamPropDisplayMin"]) == ("threshold 2", 30, 1)
     assert params["Main"]["OfxParamPropPageChild"] == ["threshold1", "threshold2"]
+    _same_text(p["OfxPropPluginDescription"], 1540, "f9fe0293138e7f67a2bd39cf812ed1e507848271978c8efd5f3fe2a8e8d1458d")   # segment.cpp:41-66
+    assert '"AS IS" ANDANY EXPRESS' in p["OfxPropPluginDescription"]                    # the reference's missing line break
 
 
 def test_describe_vectorgenerator(host):
@@ -174,6 +185,9 @@ def test_describe_vectorgenerator(host):
             t, q = params[n]
             assert t == "OfxParamTypeChoice" and q["OfxParamPropDefault"] == i + 1 and q["OfxParamPropAnimates"] == 1
             assert q["OfxParamPropChoiceOption"] == ["0", "forward.u", "forward.v", "backward.u", "backward.v"]
+            # appendOption(name, hint), VectorGenerator.cpp:126-137,734-738
+            assert q["OfxParamPropChoiceLabelOption"] == ["0 constant channel", "x flow (in pixels) to the next frame.", "y flow (in pixels) to the next frame.",
+                                                          "x flow (in pixels) to the previous frame.", "x flow (in pixels) to the previous frame."]
         assert params["method"][1]["OfxParamPropChoiceOption"] == ["Farneback", "Dual TV L1"] and params["method"][1]["OfxParamPropAnimates"] == 0
         for n, t, dflt in [("levels", "OfxParamTypeInteger", 3), ("iterations", "OfxParamTypeInteger", 15), ("neighborhood", "OfxParamTypeInteger", 5),
                            ("sigma", "OfxParamTypeDouble", 1.1), ("tau", "OfxParamTypeDouble", 0.25), ("lambda", "OfxParamTypeDouble", 0.15),
@@ -281,9 +295,20 @@ def test_segment_render_through_ofx(host, oracle):
     assert pl.render(inst, 1.0, 322, 243) == STAT_OK
     w, h = 320, 240
     src = np.ascontiguousarray(fr[:h, :w, :3])
-    ref = oracle.pyr_mean_shift(src, 10.0, 30.0, 2)                           # threshold2 default 30 -> colour radius
+    ref = oracle.pyr_mean_shift(src, 10.0, 30.0, 2)                           # threshold1 250 / 25 -> spatial radius 10, threshold2 30 -> colour radius
     assert np.array_equal(out[:h, :w, :3], ref) and (out[:h, :w, 3] == 255).all()
     assert (out[h:] == 7).all() and (out[:, w:] == 7).all()                   # outside the reduced rectangle: untouched
+    # the substitution of cvPyrSegmentation is announced through the message suite
+    assert b"pyramid mean-shift filtering" in host.mh_last_message(inst)
+    # threshold 1 is a live control: 125 -> spatial radius 5
+    host.mh_set_param_double(inst, b"threshold1", C.c_double(125.0))
+    host.mh_set_param_double(inst, b"threshold2", C.c_double(20.0))
+    assert pl.render(inst, 1.0, 322, 243) == STAT_OK
+    assert np.array_equal(out[:h, :w, :3], oracle.pyr_mean_shift(src, 5.0, 20.0, 2))
+    # OfxActionUnload releases the device contexts; a later render re-creates them
+    assert host.mh_action_raw(pl.p, b"OfxActionUnload") == STAT_REPLY_DEFAULT       # as in the reference (:483-522 has no Unload case)
+    assert pl.render(inst, 1.0, 322, 243) == STAT_OK
+    assert np.array_equal(out[:h, :w, :3], oracle.pyr_mean_shift(src, 5.0, 20.0, 2))
     pl.destroy(inst)
 
 
