@@ -61,6 +61,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
  *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
+ *   "host.register"             0|1  host-image entry points address the host's own (registered) buffers (default 1) or
+ *                                    always stage through the pinned ring (0);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
  *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
  *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
@@ -129,6 +131,10 @@ int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref
                                unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x,
                                double render_scale_y, int levels, int iterations, int poly_n,
                                double poly_sigma);
+
+/* number of host-image calls on this context that ran zero-copy (the host's buffers registered with hipHostRegister and
+ * addressed directly by the kernels) instead of staging through the pinned ring; option "host.register" 0 forces the ring */
+long ofxcv_host_zero_copy_calls(const ofxcv_ctx *ctx);
 
 /* ---- I0-I2: inpaint hole mask -------------------------------------------------------------
  * replaces cvCvtColor(imgSrc, mask, CV_RGBA2GRAY) + cvThreshold(mask, mask, 0, 255, CV_THRESH_BINARY_INV)

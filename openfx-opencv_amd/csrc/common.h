@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "ofxcv_hip.h"
@@ -81,6 +82,10 @@ struct ofxcv_ctx {
     double prof_ms = 0;
     long prof_launches = 0;
 
+    ofxcv_ctx *sibling = nullptr;  // second context of the host path: the backward flow runs beside the forward one
+    bool host_register = true;     // option "host.register": 0 = always stage through the pinned ring
+    long host_zero_copy_calls = 0, host_staged_calls = 0;
+
     // host-path staging
     DevBuf d_stage;            // device side: 2 f32 frames, 2 gray frames, flow, rgba
     void *h_pinned = nullptr;  // pinned host ring
@@ -110,9 +115,13 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
     return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->compute;
 }
 
-// Process-wide lock around the operations that must not overlap another thread's stream capture on ROCm 7.2 (the
-// capture itself, device allocations and frees): a capture in flight was seen to be invalidated by them.
-std::mutex &ofxcv_capture_mutex();
+// Process-wide reader/writer lock for the HIP runtime operations that are not safe against each other across host
+// threads on ROCm 7.2.  EXCLUSIVE: stream capture + graph instantiation, device allocations / frees / host registration,
+// graph-exec destruction and context teardown (a capture in flight was seen to be invalidated by an allocation, and
+// hipGraphExecDestroy tears down the exec's internal streams while another thread's hipGraphLaunch walks the runtime's
+// stream list -- a segfault in hip::Graph::UpdateStreams, caught once in ~10 runs of four concurrent render threads).
+// SHARED: hipGraphLaunch (launches of different threads stay concurrent with each other).
+std::shared_mutex &ofxcv_capture_mutex();
 // Waits for everything this context has in flight (its own streams and the last caller-supplied one); never a
 // device-wide synchronisation, which would stall -- and invalidate the captures of -- other contexts' threads.
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx);

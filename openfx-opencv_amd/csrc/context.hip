@@ -15,8 +15,8 @@ int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
-std::mutex &ofxcv_capture_mutex() {
-    static std::mutex m;
+std::shared_mutex &ofxcv_capture_mutex() {
+    static std::shared_mutex m;
     return m;
 }
 
@@ -29,7 +29,7 @@ int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
 
 int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes) return OFXCV_OK;
-    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
     if (b.ptr) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
@@ -151,8 +151,12 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
 
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
+    if (ctx->sibling) {
+        ofxcv_ctx_destroy(ctx->sibling);
+        ctx->sibling = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
-    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
     (void)ofxcv_ctx_quiesce(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (FbGraph &g : ctx->fb_graphs)
@@ -174,6 +178,8 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     delete ctx;
 }
 
+long ofxcv_host_zero_copy_calls(const ofxcv_ctx *ctx) { return ctx ? ctx->host_zero_copy_calls : -1; }
+
 long ofxcv_inpaint_fallback_count(const ofxcv_ctx *ctx) { return ctx ? ctx->ip_fallbacks : -1; }
 
 const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "null context"; }
@@ -184,7 +190,9 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute
 
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return OFXCV_ERR_INVALID;
+    if (ctx->sibling) (void)ofxcv_ctx_set_option(ctx->sibling, name, value);
     // captured launch sequences bake the kernel choice in: drop them whenever an option changes
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
     for (FbGraph &g : ctx->fb_graphs)
         if (g.exec) {
             (void)hipGraphExecDestroy(g.exec);
@@ -196,6 +204,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "farneback.opencv_rounding")) {
         ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "host.register")) {
+        ctx->host_register = value != 0;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "inpaint.spin_limit")) {

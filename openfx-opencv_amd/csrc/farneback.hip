@@ -1925,10 +1925,6 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
     if (!g) {
         FbGraph *slot = &ctx->fb_graphs[ctx->fb_graph_next++ % kFbGraphSlots];
-        if (slot->exec) {
-            (void)hipGraphExecDestroy(slot->exec);
-            slot->exec = nullptr;
-        }
         // Relaxed mode: the captured region itself makes no capture-unsafe call, and other host threads (each with
         // its own context: allocations, synchronising copies) must not be able to invalidate this capture.  If the
         // capture cannot be completed anyway, the call falls back to plain launches and stops using graphs.
@@ -1936,7 +1932,11 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         // one capture at a time per process, and no device allocation / free / context teardown of another host thread
         // during it (ofxcv_capture_mutex): either was seen to invalidate a capture on ROCm 7.2.  Launches, copies
         // and graph replays of other threads stay concurrent.
-        std::unique_lock<std::mutex> capture_lock(ofxcv_capture_mutex());
+        std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex());
+        if (slot->exec) {  // evicted entry: destroyed under the exclusive lock (see common.h)
+            (void)hipGraphExecDestroy(slot->exec);
+            slot->exec = nullptr;
+        }
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
             rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
@@ -1961,7 +1961,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         slot->key = key;
         g = slot;
     }
-    OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
+    {
+        std::shared_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex());
+        OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
+    }
     return OFXCV_OK;
 }
 

@@ -2,14 +2,22 @@
 // Farneback branch) for host-resident OFX images.
 //
 // The reference marshals each OFX image into a cv::Mat through CVImageWrapper / OFX::ImageMemory
-// (OpenCV/GenericOpenCVPlugin.cpp:58-165, 223-265).  Here the two f32 frames are copied in row
-// blocks into a pinned ring and sent to HBM with hipMemcpyAsync on the context's copy stream; the
-// compute stream waits on a per-frame event, so the sRGB-gray kernel of frame 0 runs while frame
-// 1 is still on the wire.  Only the flow (8 B/px) comes back; the mapped RGBA channels of the
-// host-owned destination are then filled from the pinned copy (unmapped channels stay untouched,
-// :507-516).
+// (OpenCV/GenericOpenCVPlugin.cpp:58-165, 223-265).  Two ways here:
+//  * registered buffers (default for the usual case: top-down images, all four destination channels mapped): the
+//    host's own buffers are registered with the driver for the duration of the call (hipHostRegister: 0.2 ms per 1080p
+//    frame, no cache -- a registration does not survive the host freeing and re-allocating the addresses), the copy
+//    engine reads the f32 frames in place (no staging memcpy), and one kernel stores the four flow channels of both
+//    directions straight into the host's destination image.  The backward flow runs on a sibling context beside the
+//    forward one.
+//  * pinned ring (everything else: bottom-up / oddly strided images, partial channel maps, registration refused,
+//    option "host.register" 0): the frames are copied in row blocks into a pinned ring and sent to HBM with
+//    hipMemcpyAsync on the copy stream while the compute stream converts the previous frame; only the flow (8 B/px)
+//    comes back and the mapped channels of the destination are filled from the pinned copy (unmapped channels stay
+//    untouched, :507-516).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <functional>
 #include <thread>
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ fl
 
 int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_pinned_bytes) return OFXCV_OK;
-    std::lock_guard<std::mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
     if (ctx->h_pinned) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
@@ -110,6 +118,158 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+// ---- registered host buffers ----
+// Registered for the duration of ONE call: a registration pins the pages behind an address range at that moment; a host
+// that frees a frame buffer and gets the same addresses back from its allocator would leave a cached registration
+// pointing at the old pages (measured: a pointer-keyed cache produced wrong frames with numpy-allocated buffers).
+// Register / unregister take the exclusive runtime lock like every other memory operation.
+struct HostRegistrations {
+    void *p[4];
+    int n = 0;
+    bool add(const void *ptr, size_t bytes) {
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();  // e.g. already registered by the host application itself (or by another render thread
+            return false;             // reading the same source frame): this call stages through the ring
+        }
+        p[n++] = const_cast<void *>(ptr);
+        return true;
+    }
+    ~HostRegistrations() {
+        if (!n) return;
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        for (int i = 0; i < n; i++) (void)hipHostUnregister(p[i]);
+        (void)hipGetLastError();
+    }
+};
+
+// the four RGBA channels of the destination from the two flow fields, one 16-byte store per pixel:
+// channel c <- flow[k[c]].{x|y} / render scale
+struct ChanMap {
+    int k[4], comp[4];
+};
+__global__ __launch_bounds__(256) void flows_to_rgba_kernel(const float2 *__restrict__ f0, const float2 *__restrict__ f1, int width, int height,
+                                                            float *__restrict__ dst, ptrdiff_t dst_row_bytes, ChanMap m, double rsx, double rsy) {
+    const int y = blockIdx.y, x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= width) return;
+    const size_t i = (size_t)y * width + x;
+    float2 a = f0[i], b = f1 ? f1[i] : make_float2(0.f, 0.f);
+    a.x = (float)(a.x / rsx); a.y = (float)(a.y / rsy);
+    b.x = (float)(b.x / rsx); b.y = (float)(b.y / rsy);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float2 f = m.k[c] == 1 ? b : a;
+        v[c] = m.comp[c] ? f.y : f.x;
+    }
+    *(float4 *)((char *)dst + (ptrdiff_t)y * dst_row_bytes + (size_t)x * 16) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+constexpr int kNotRegistered = 12345;  // internal: the registered-buffer path does not apply, stage through the pinned ring
+
+static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, int n_other, const float *const h_other[2],
+                                 const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
+                                 const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
+                                 int levels, int iterations, int poly_n, double poly_sigma) {
+    if (!ctx->host_register) return kNotRegistered;
+    const int nf = 1 + n_other;
+    const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
+    const float *src[3] = {h_ref, h_other[0], n_other > 1 ? h_other[1] : nullptr};
+    const ptrdiff_t src_rb[3] = {ref_row_bytes, other_row_bytes[0], n_other > 1 ? other_row_bytes[1] : 0};
+    for (int f = 0; f < nf; f++)
+        if (src_rb[f] < (ptrdiff_t)row) return kNotRegistered;  // bottom-up images: ring
+    // channel -> (flow, coordinate): per direction v wins over u, a later direction overwrites an earlier one (:507-516)
+    ChanMap cm = {{-1, -1, -1, -1}, {0, 0, 0, 0}};
+    for (int k = 0; k < n_other; k++) {
+        const unsigned mu = chan_u_mask[k] & 15u, mv = chan_v_mask[k] & 15u;
+        for (int c = 0; c < 4; c++) {
+            if (mv & (1u << c)) { cm.k[c] = k; cm.comp[c] = 1; }
+            else if (mu & (1u << c)) { cm.k[c] = k; cm.comp[c] = 0; }
+        }
+    }
+    // Only whole pixels are stored into host memory by the kernel (the default mapping: forward.u/v, backward.u/v): 4-byte
+    // partial stores over PCIe were measured at a third of the rate (2.1 ms instead of 0.63 ms per 1080p frame), slower
+    // than the ring's flow download + host scatter.
+    if (cm.k[0] < 0 || cm.k[1] < 0 || cm.k[2] < 0 || cm.k[3] < 0 || dst_row_bytes < (ptrdiff_t)drow || ((uintptr_t)h_dst & 15) || (dst_row_bytes & 15))
+        return kNotRegistered;
+    HostRegistrations regs;
+    for (int f = 0; f < nf; f++)
+        if (!regs.add(src[f], (size_t)(height - 1) * src_rb[f] + row)) return kNotRegistered;
+    if (!regs.add(h_dst, (size_t)(height - 1) * dst_row_bytes + drow)) return kNotRegistered;
+    void *d_dst = nullptr;
+    if (hipHostGetDevicePointer(&d_dst, h_dst, 0) != hipSuccess || !d_dst) {
+        (void)hipGetLastError();
+        return kNotRegistered;
+    }
+
+    const size_t frame = align_up(row * height, 256), gray_pitch = align_up((size_t)width, 256), gray = gray_pitch * height,
+                 flow_bytes = align_up((size_t)width * height * 8, 256);
+    int rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes);
+    if (rc) return rc;
+    char *dp = (char *)ctx->d_stage.ptr;
+    uint8_t *d_gray[3];
+    float *d_flow[2] = {nullptr, nullptr};
+    for (int f = 0; f < nf; f++) d_gray[f] = (uint8_t *)(dp + nf * frame + f * gray);
+    for (int k = 0; k < n_other; k++) d_flow[k] = (float *)(dp + nf * (frame + gray) + k * flow_bytes);
+
+    // uploads straight from the host's buffers on the copy stream; the compute stream converts frame f as soon as it has
+    // arrived, so the next frame is on the wire meanwhile
+    for (int f = 0; f < nf; f++) {
+        if ((size_t)src_rb[f] == row)  // contiguous rows: one linear DMA
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + f * frame, src[f], row * height, hipMemcpyHostToDevice, ctx->copy));
+        else
+            OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(dp + f * frame, row, src[f], (size_t)src_rb[f], row, height, hipMemcpyHostToDevice, ctx->copy));
+        OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
+    }
+    // The two flows of an output frame are independent: the second one runs on a sibling context (its own Farneback
+    // scratch and streams) concurrently with the first -- one flow alone does not fill the device.
+    ofxcv_ctx *c2 = nullptr;
+    if (n_other > 1) {
+        if (!ctx->sibling && ofxcv_ctx_create(ctx->device, &ctx->sibling) != OFXCV_OK) ctx->sibling = nullptr;
+        c2 = ctx->sibling;
+        if (c2 && (c2->fb_opencv_rounding != ctx->fb_opencv_rounding || c2->fb_no_graph != ctx->fb_no_graph)) {
+            (void)ofxcv_ctx_set_option(c2, "farneback.opencv_rounding", ctx->fb_opencv_rounding);
+            (void)ofxcv_ctx_set_option(c2, "farneback.graph", ctx->fb_no_graph ? 0 : 1);
+        }
+    }
+    auto sync_all = [&]() {
+        (void)hipStreamSynchronize(ctx->copy);
+        (void)hipStreamSynchronize(ctx->compute);
+        if (c2) (void)hipStreamSynchronize(c2->compute);
+    };
+    for (int f = 0; f < nf; f++) {
+        OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
+        rc = ofxcv_to_byte_grayscale(ctx, (const float *)(dp + f * frame), (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
+        if (rc) { sync_all(); return rc; }
+        if (f == 0) continue;
+        ofxcv_ctx *fc = (f == 2 && c2) ? c2 : ctx;
+        if (fc != ctx) {  // hand gray[0] / gray[2] over to the sibling's stream
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));
+            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(fc->compute, ctx->ev_done, 0));
+        }
+        // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+        rc = ofxcv_calc_optical_flow_farneback(fc, d_gray[0], gray_pitch, d_gray[f], gray_pitch, d_flow[f - 1], (size_t)width * 8, width, height,
+                                               0.5, levels, 3, iterations, poly_n, poly_sigma, 0, fc->compute);
+        if (rc) {
+            if (fc != ctx) std::snprintf(ctx->err, sizeof(ctx->err), "%s", fc->err);
+            sync_all();
+            return rc;
+        }
+        if (fc != ctx) {  // join: the write-back on the main stream waits for the sibling's flow
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(fc->ev_done, fc->compute));
+            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, fc->ev_done, 0));
+        }
+    }
+    hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
+                       (const float2 *)d_flow[1], width, height, (float *)d_dst, dst_row_bytes, cm, render_scale_x, render_scale_y);
+    OFXCV_LAUNCH_CHECK(ctx, "flows_to_rgba_kernel");
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy));
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+    if (c2) OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(c2->compute));
+    ctx->host_zero_copy_calls++;
+    return OFXCV_OK;  // `regs` unregisters the host ranges here: nothing of this call is in flight any more
+}
+
 // One reference frame against one or two other frames (forward: t+1, backward: t-1 -- the two directions a default
 // VectorGenerator output frame needs, VectorGenerator.cpp:739-779).  The reference is staged, uploaded and converted once;
 // the first flow is computed while the host still stages the third frame and is downloaded on the copy stream while
@@ -121,6 +281,12 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float);
+    {
+        int rc0 = flows_host_registered(ctx, h_ref, ref_row_bytes, n_other, h_other, other_row_bytes, ncomp, width, height, h_dst, dst_row_bytes,
+                                        chan_u_mask, chan_v_mask, render_scale_x, render_scale_y, levels, iterations, poly_n, poly_sigma);
+        if (rc0 != kNotRegistered) return rc0;
+    }
+    ctx->host_staged_calls++;
     const size_t frame = align_up(row * height, 256);
     const size_t gray_pitch = align_up((size_t)width, 256);
     const size_t gray = gray_pitch * height;

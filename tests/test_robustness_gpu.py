@@ -193,3 +193,44 @@ def test_bottom_up_host_images(ofxcv, oracle):
     c.vectorgen_flow_host(ap, bp, d2, 1, 2)
     assert np.array_equal(d1, d2)
     c.close()
+
+
+def test_registered_host_path_equals_the_pinned_ring(ofxcv):
+    """ofxcv_vectorgen_flows_host registers the host's own buffers for the call when all four destination channels are mapped
+    (the copy engine reads the frames in place, a kernel stores whole pixels into the host image, the backward flow runs on a
+    sibling context); with option host.register = 0, for partial channel maps and for bottom-up images the frames are staged
+    through the pinned ring.  Same pixels either way; buffers that the host frees and re-allocates between calls are fine."""
+    from openfx_opencv_amd import synth
+    w, h = 200, 120
+    zc, ring = ofxcv.Context(0), ofxcv.Context(0)
+    ring.set_option("host.register", 0)
+    n_reg = 0
+    for rep in range(3):                       # fresh numpy buffers every time: the allocator hands the same addresses again
+        ref, nxt = synth.flow_pair(w, h, seed=5 + rep)
+        prev, _ = synth.flow_pair(w, h, seed=16 + rep)
+        for fu, fv, bu, bv, rx, ry, registered in [(1, 2, 4, 8, 1.0, 1.0, True), (4, 8, 1, 2, 0.5, 0.25, True), (3, 12, 0, 0, 1.0, 2.0, True),
+                                                   (1, 0, 0, 8, 1.0, 1.0, False), (1, 2, 2, 4, 1.0, 1.0, False)]:
+            a = np.full((h, w, 4), -3.0, np.float32)
+            b = np.full((h, w, 4), -3.0, np.float32)
+            zc.vectorgen_flows_host(ref, nxt, prev, a, fu, fv, bu, bv, rx, ry)
+            ring.vectorgen_flows_host(ref, nxt, prev, b, fu, fv, bu, bv, rx, ry)
+            assert np.array_equal(a, b), (rep, fu, fv, bu, bv)
+            n_reg += registered
+            assert zc.host_zero_copy_calls() == n_reg, (rep, fu, fv, bu, bv)
+    assert ring.host_zero_copy_calls() == 0
+    # padded destination / source rows and RGB sources, one direction mapped to all four channels
+    pad = np.full((h, w + 12, 4), 5.0, np.float32)
+    a, b = pad.copy(), pad.copy()
+    ref3, nxt3 = np.ascontiguousarray(ref[..., :3]), np.ascontiguousarray(nxt[..., :3])
+    zc.vectorgen_flow_host(ref3, nxt3, a[:, :w], 0b0101, 0b1010)
+    ring.vectorgen_flow_host(ref3, nxt3, b[:, :w], 0b0101, 0b1010)
+    assert np.array_equal(a, b) and (a[:, w:] == 5.0).all() and zc.host_zero_copy_calls() == n_reg + 1
+    # bottom-up images cannot be addressed as one ascending range: the ring serves them
+    refp, nxtp = np.ascontiguousarray(ref[::-1])[::-1], np.ascontiguousarray(nxt[::-1])[::-1]    # same images, stored bottom-up
+    cp = np.zeros((h, w, 4), np.float32)
+    zc.vectorgen_flow_host(refp, nxtp, cp[::-1], 0b0101, 0b1010)
+    d = np.zeros((h, w, 4), np.float32)
+    ring.vectorgen_flow_host(ref, nxt, d, 0b0101, 0b1010)
+    assert np.array_equal(cp[::-1], d) and zc.host_zero_copy_calls() == n_reg + 1
+    zc.close()
+    ring.close()
