@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_bench; rm -rf $OUT; mkdir -p $OUT
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-legs > $OUT/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
 done
 python - <<'PY'
 import csv, glob, collections, os, re
