@@ -262,7 +262,9 @@ def main():
     value = statistics.median(rates)
     alg = algorithmic_bytes_per_pair(W, H)
     pmc = pmc_kernels() if (W, H) == (1920, 1080) else {}
-    pm, pc, pf = pmc.get("opencv_order_iteration_level0", {}), pmc.get("opencv_order_carry_level0", {}), pmc.get("direct_window_fused_pair_level0", {})
+    folded = carry_n == 0
+    pm = pmc.get("opencv_order_folded_iteration_level0" if folded else "opencv_order_iteration_level0", {})
+    pc, pf = pmc.get("opencv_order_carry_level0", {}), pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes = ITER_BYTES_PER_PX * W * H
     achieved = iter_bytes / main_s / 1e9
     traffic = pm.get("traffic_bytes_per_launch")
@@ -295,7 +297,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
-                     "kernel": "iterate3s_kernel<true, 8, true> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)" % (W, H),
+                     "kernel": ("iterate3f_kernel<true, 8, 8> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
+                                "of its own output; pyramid level 0, %dx%d)" if folded else
+                                "iterate3s_kernel<true, 8, true> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
                      "bytes_per_launch": iter_bytes, "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20)",
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r02_bench_pairs1_by_grid.txt)",
@@ -305,10 +309,11 @@ def main():
                                      "column and strip) at about the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
                      "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) / launch time",
-                     "carry_prepass": {"kernel": "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip; one launch per iteration)",
-                                       "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n, "algorithmic_bytes": 20.0 * W * H + 5.0 * W * H,
-                                       "traffic": pc.get("traffic_bytes_per_launch"),
-                                       "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None},
+                     "carry_prepass": ({"kernel": "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip; one launch per iteration; option farneback.fold_carries=0)",
+                                        "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n, "algorithmic_bytes": 20.0 * W * H + 5.0 * W * H,
+                                        "traffic": pc.get("traffic_bytes_per_launch"),
+                                        "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None}
+                                       if carry_n else "none: the carries of the f64 column sums are produced by the iteration kernel itself (folded form)"),
                      "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
                                               "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes,
                                               "achieved": 2 * iter_bytes / fused_s / 1e9, "frac": 2 * iter_bytes / fused_s / 1e9 / HBM_PEAK_GBS,

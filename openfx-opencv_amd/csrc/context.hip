@@ -214,6 +214,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_spin_limit = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.fold_carries")) {
+        ctx->fb_fold_carries = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.strict_variant")) {
         ctx->fb_strict_variant = value;
         return OFXCV_OK;

@@ -1457,6 +1457,285 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
     if (UPDATE && PIPE) finish(prev, min(a + RW, h) - 1);
 }
 
+// ------------------------------------------------------------------ OpenCV-order window, carries folded into the iteration
+//
+// iterate3s_kernel needs vsum just above every strip, and vsum_carry_kernel re-reads all of M once per iteration to
+// provide it.  Here the iteration kernel produces the carries of ITS OUTPUT for the next launch:
+//   * a workgroup = NW wavefronts stacked over the same 62 columns, RW rows each (a strip of NW*RW rows).  One f64 per
+//     strip, column and channel comes in (`Kin`: vsum just above the strip); the wavefronts pass the sums of their own
+//     row differences through LDS, so each starts its column chain at the right value.
+//   * while the rows of the new M are produced, every wavefront adds up the row differences of the new M that lie inside
+//     its own rows (d_t = (float)(M'[t+1] - M'[t-2]) needs rows three apart); its last three rows go to LDS so that the
+//     wavefront below can add the three differences that straddle the wavefront boundary.  The strip's sum goes to
+//     `Spart`.
+//   * the three differences that straddle a STRIP boundary need rows of two workgroups.  The last workgroup of a tile
+//     column to finish (one atomic counter per tile column; nobody spins) reads those boundary rows and the strip sums
+//     of its tile column back, runs the prefix over the strips and leaves `Kout` for the next launch.
+// Everything is summed in ascending row order; only f64 additions are re-associated (strip and wavefront partial sums),
+// as in the two-kernel form.  vsum_seed_kernel provides the carries of the first M of a pyramid level the same way.
+struct FoldArgs {
+    const double *Kin;    // [nstrips][5][pitch]  vsum of Min at the row above each strip
+    double *Kout;         // [nstrips][5][pitch]  the same for Mout (complete when the launch has finished)
+    double *Spart;        // [nstrips][5][pitch]  sum of the row differences of Mout with both rows inside the strip
+    unsigned *counters;   // [tile columns]       workgroups of the tile column that have finished (0 on entry and on exit)
+    int nstrips;
+    int scan_in_kernel;   // 1: the last workgroup of a tile column runs the prefix over the strips itself; 0: fold_scan_kernel does
+};
+
+// Data that one workgroup hands to another inside a launch (the boundary rows of the new M, the strip sums) goes through
+// device-scope accesses: stores that write through the XCD's L2 and loads that do not hit in a non-coherent cache.  A
+// device-wide fence would have every workgroup write back its whole L2 (measured: 199 instead of 40 us per launch).
+__device__ __forceinline__ float ld_dev(const float *p) {
+    return __builtin_bit_cast(float, __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ double ld_dev(const double *p) {
+    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_dev(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// buffer store with the sc0 | sc1 cache policy (write-through to memory)
+__device__ __forceinline__ void buf_st_dev(const Buf &b, float v, unsigned voff_bytes, unsigned soff_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, 17);
+}
+
+// Last workgroup of tile column: prefix over the strips.  M = the field the carries are for, rows of `sh` per strip.
+template <int NW, bool DEV>
+__device__ __forceinline__ void fold_scan(const float *__restrict__ M, const FoldArgs &fa, int sh, int xr, int w, int h, int pitch,
+                                          int wave, bool own) {
+    auto ldf = [](const float *p) { return DEV ? ld_dev(p) : *p; };
+    auto ldd = [](const double *p) { return DEV ? ld_dev(p) : *p; };
+    const size_t plane = (size_t)pitch * h;
+    const int x = clampi(xr, 0, w - 1);
+    for (int c = wave; c < 5; c += NW) {  // one channel per wavefront (wavefront 0 also takes what is left over)
+        const float *m = M + c * plane + x;
+        const size_t kst = (size_t)5 * pitch, kof = (size_t)c * pitch + x;
+        double run = (double)(ldf(m) * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
+        if (own) fa.Kout[kof] = run;
+        constexpr int CH = 8;  // strip boundaries per batch of loads
+        for (int s0 = 1; s0 < fa.nstrips; s0 += CH) {
+            float r[CH][6];
+            double sp[CH];
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int s = s0 + i;
+                if (s < fa.nstrips) {
+                    const int A = s * sh;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) r[i][k] = ldf(m + (size_t)min(A - 3 + k, h - 1) * pitch);
+                    sp[i] = ldd(fa.Spart + (size_t)(s - 1) * kst + kof);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+                const int s = s0 + i;
+                if (s < fa.nstrips) {
+                    run += sp[i];                          // differences inside strip s-1
+                    run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
+                    if (own) fa.Kout[(size_t)s * kst + kof] = run;
+                    run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
+                    run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
+                }
+            }
+        }
+    }
+}
+
+// strip sum from the wavefront sums (s_w), then the hand-over to the last workgroup of the tile column
+template <int NW>
+__device__ __forceinline__ void fold_finish(const float *__restrict__ M, const FoldArgs &fa, double (*s_w)[5][64], unsigned *s_flag, int sh,
+                                            int tbx, int tby, int xr, int w, int h, int pitch, int wave, int lane, bool own) {
+    __syncthreads();
+    if (wave == 0 && own) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double sum = s_w[0][c][lane];
+            for (int u = 1; u < NW; u++) sum += s_w[u][c][lane];
+            st_dev(fa.Spart + ((size_t)tby * 5 + c) * pitch + xr, sum);
+        }
+    }
+    if (!fa.scan_in_kernel) return;  // fold_scan_kernel follows as its own launch
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wavefront's write-through stores (rows of M, strip sum) have completed
+    __syncthreads();
+    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(fa.counters + tbx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_flag != (unsigned)(fa.nstrips - 1)) return;
+    fold_scan<NW, true>(M, fa, sh, xr, w, h, pitch, wave, own);
+    if (threadIdx.x == 0) __hip_atomic_store(fa.counters + tbx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the prefix over the strips as its own (small) launch: one workgroup per tile column, one wavefront per channel
+__global__ __launch_bounds__(320) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int xr = blockIdx.x * kSsW - 1 + lane;
+    const bool own = lane >= 1 && lane <= kSsW && xr < w;
+    fold_scan<5, false>(M, fa, sh, xr, w, h, pitch, wave, own);
+}
+
+// carries of a field that already lies in memory (the first M of a pyramid level)
+template <int RW, int NW>
+__global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, FoldArgs fa) {
+    __shared__ double s_w[NW][5][64];
+    __shared__ unsigned s_flag;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
+    const bool own = lane >= 1 && lane <= kSsW && xr < w;
+    constexpr int SH = RW * NW;
+    const int A = tby * SH, a = A + wave * RW;
+    const size_t plane = (size_t)pitch * h;
+    // rows a-3 .. a+RW-1: the differences with the later row inside this wavefront's rows
+    float m[RW + 3][5];
+#pragma unroll
+    for (int r = 0; r < RW + 3; r++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) m[r][c] = M[c * plane + (size_t)clampi(a - 3 + r, 0, h - 1) * pitch + x];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        double sum = 0.;
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            // t = a+j-1: rows a+j and a+j-3.  The first three of a strip belong to the strip boundary (fold_scan), except
+            // at the top of the image, where rows above 0 are row 0: t = 0, 1 are (row 1 - row 0), (row 2 - row 0).
+            const int row = a + j;
+            if (row >= h || row - 1 < 0) continue;                   // t = row - 1 >= 0
+            if (wave == 0 && j < 3 && A > 0) continue;
+            sum += (double)(m[j + 3][c] - m[j][c]);
+        }
+        s_w[wave][c][lane] = sum;
+    }
+    fold_finish<NW>(M, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
+}
+
+template <bool UPDATE, int RW, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                           const float *__restrict__ Min, float *__restrict__ Mout,
+                                                           float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
+                                                           FoldArgs fa) {
+    constexpr bool PIPE = RW < 8;  // with 8 rows per wavefront the second in-flight pixel record does not fit 128 registers
+    static_assert(RW >= 3, "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
+    __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
+    __shared__ float s_last[NW][3][5][64];   // the last three rows of Mout of every wavefront
+    __shared__ unsigned s_flag;
+    int tbx, tby;
+    xcd_tile(tbx, tby);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x0 = tbx * kSsW;
+    constexpr int SH = RW * NW;
+    const int A = tby * SH, a = A + wave * RW;
+    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
+    const bool own = lane >= 1 && lane <= kSsW && xr < w;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
+    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+
+    // rows a-2 .. a+RW of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
+    float m[RW + 3][5];
+#pragma unroll
+    for (int r = 0; r < RW + 3; r++) {
+        const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
+#pragma unroll
+        for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
+    }
+    double D[5];
+#pragma unroll
+    for (int c = 0; c < 5; c++) D[c] = fa.Kin[((size_t)tby * 5 + c) * pitch + x];
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        double t = 0.;
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+            if (a + j < h) t += (double)(m[j + 3][c] - m[j][c]);
+        s_w[wave][c][lane] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 5; c++)
+        for (int u = 0; u < wave; u++) D[c] += s_w[u][c][lane];  // vsum just above this wavefront's first row
+    __syncthreads();  // s_w is reused for the sums of Mout
+
+    struct Px {
+        Taps tp;
+        float r0v[5];
+        float fxv, fyv;
+    };
+    Px prev;
+    float mo[RW][5];   // rows of Mout as they are produced (only 0..2 and the last three finished ones stay live)
+    double I[5] = {0., 0., 0., 0., 0.};
+    auto finish = [&](const Px &p, int j) {
+        const int y = a + j;
+        M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            mo[j][c] = mm.v[c];
+            if (own) {
+                if (fa.scan_in_kernel) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+                else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+            }
+            if (j >= 3) I[c] += (double)(mm.v[c] - mo[j - 3][c]);   // t = y-1: rows y, y-3, both in this wavefront
+            if (j >= RW - 3) s_last[wave][j - (RW - 3)][c][lane] = mm.v[c];
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+        const int y = a + j;
+        if (y >= h) break;  // wave-uniform
+        double acc[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            D[c] += (double)(m[j + 3][c] - m[j][c]);  // the reference's vsum[x] += srow1[x] - srow0[x]
+            acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
+        }
+        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
+        if (UPDATE) {
+            Px cur;
+            cur.fxv = fxv;
+            cur.fyv = fyv;
+#pragma unroll
+            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
+            if (PIPE) {  // the gather of row j is in flight while row j-1 is finished
+                if (j > 0) finish(prev, j - 1);
+                prev = cur;
+            } else {
+                finish(cur, j);
+            }
+        }
+    }
+    if (!UPDATE) return;
+    if (PIPE) {
+        const int nr = min(RW, h - a);  // rows of this wavefront inside the image (<= 0: none, bottom strip only)
+        if (nr > 0) {
+#pragma unroll
+            for (int j = 0; j < RW; j++)
+                if (j == nr - 1) finish(prev, j);
+        }
+    }
+    __syncthreads();  // every wavefront's last three rows are in LDS
+    // the three differences across the boundary to the wavefront above (t = a-1, a, a+1); at the top of the image rows above
+    // row 0 are row 0 (t = 0, 1); the ones across the strip boundary are left to fold_scan
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        double sum = 0.;
+        if (wave > 0) {
+            sum = (double)(mo[0][c] - s_last[wave - 1][0][c][lane]);
+            sum += (double)(mo[1][c] - s_last[wave - 1][1][c][lane]);
+            sum += (double)(mo[2][c] - s_last[wave - 1][2][c][lane]);
+        } else if (A == 0) {
+            sum = (double)(mo[1][c] - mo[0][c]);
+            sum += (double)(mo[2][c] - mo[0][c]);
+        }
+        s_w[wave][c][lane] = sum + I[c];
+    }
+    fold_finish<NW>(Mout, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
+}
+
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -1573,7 +1852,7 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         // strip-parallel OpenCV-order window: carries of the column running sums, then the iteration itself
         const int pitch = plane_pitch(w), tiles_x = ofxcv_div_up(w, kSsW);
         int rw = ctx->fb_strict_rows;
-        if (rw != 2 && rw != 4 && rw != 8) rw = (long)tiles_x * ofxcv_div_up(h, 8) >= 4096 ? 8 : ((long)tiles_x * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
+        if (rw != 2 && rw != 4 && rw != 8 && rw != 16) rw = (long)tiles_x * ofxcv_div_up(h, 8) >= 4096 ? 8 : ((long)tiles_x * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
         const int nstrips = ofxcv_div_up(h, rw), G = std::max(ofxcv_div_up(nstrips, 16 * kSsSPW), std::min(ctx->fb_carry_groups, 8)), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
         double *carry = (double *)ctx->fb_vsum.ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
         dim3 cgrid(ofxcv_div_up(w, 64), 5, G), grid(ofxcv_div_up(tiles_x, 2), nstrips);
@@ -1597,7 +1876,8 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         const int mark = ctx->prof_now ? ctx->prof_on : 0;  // measurement hook: 1 = the iteration kernel, 2 = the carry pre-pass
         int rc;
         const bool pipe = !(ctx->fb_strict_variant & 1);
-        if (rw == 8) OFXCV_LAUNCH_SS(8);
+        if (rw == 16) OFXCV_LAUNCH_SS(16);
+        else if (rw == 8) OFXCV_LAUNCH_SS(8);
         else if (rw == 4) OFXCV_LAUNCH_SS(4);
         else OFXCV_LAUNCH_SS(2);
 #undef OFXCV_LAUNCH_SS
@@ -1672,6 +1952,81 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
     else
         hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, R0, R1, (const float *)V, Mout, flow, flow_step, w, h, pitch, t);
     OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
+    return OFXCV_OK;
+}
+
+// OpenCV-order window with the carries folded into the iteration kernel (winsize 3).  Strip geometry by level size.
+struct FoldGeom {
+    int rw, nw, tiles_x, nstrips;
+};
+FoldGeom fold_geom(int w, int h) {
+    FoldGeom g;
+    g.tiles_x = ofxcv_div_up(w, kSsW);
+    g.nw = 8;
+    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 64) >= 256 ? 8 : ((long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3);
+    g.nstrips = ofxcv_div_up(h, g.rw * g.nw);
+    return g;
+}
+struct FoldScratch {  // carved from ctx->fb_vsum by the caller
+    double *K[2], *Spart;
+    unsigned *counters;
+};
+FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0) {  // sized for the level-0 geometry (the largest)
+    const FoldGeom g = fold_geom(w0, h0);
+    const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 8) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 24 rows)
+    (void)g;
+    FoldScratch fs;
+    double *base = (double *)ctx->fb_vsum.ptr;
+    fs.K[0] = base;
+    fs.K[1] = base + n;
+    fs.Spart = base + 2 * n;
+    fs.counters = (unsigned *)(base + 3 * n);
+    return fs;
+}
+int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot) {
+    const FoldGeom g = fold_geom(w, h);
+    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1};
+    dim3 grid(g.tiles_x, g.nstrips);
+    const int pitch = plane_pitch(w);
+    if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+    else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+    else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+    OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
+    if (!fa.scan_in_kernel) {
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x), dim3(320), 0, s, M, w, h, pitch, g.rw * g.nw, fa);
+        OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
+    }
+    return OFXCV_OK;
+}
+int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
+                          size_t flow_step, int w, int h, bool update, const FoldScratch &fs, int kslot) {
+    const FoldGeom g = fold_geom(w, h);
+    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1};
+    dim3 grid(g.tiles_x, g.nstrips);
+    const int pitch = plane_pitch(w);
+    const double scale = 1. / 9.;
+    int rc;
+    const int mark = ctx->prof_now ? ctx->prof_on : 0;
+    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+#define OFXCV_LAUNCH_FOLD(RW)                                                                                                            \
+    do {                                                                                                                                 \
+        if (update)                                                                                                                      \
+            hipLaunchKernelGGL((iterate3f_kernel<true, RW, 8>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((iterate3f_kernel<false, RW, 8>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+    } while (0)
+    if (g.rw == 8) OFXCV_LAUNCH_FOLD(8);
+    else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4);
+    else OFXCV_LAUNCH_FOLD(3);
+#undef OFXCV_LAUNCH_FOLD
+    OFXCV_LAUNCH_CHECK(ctx, "iterate3f_kernel");
+    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+    if (update && !fa.scan_in_kernel) {
+        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x), dim3(320), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa);
+        OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
+        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+    }
     return OFXCV_OK;
 }
 
@@ -1828,6 +2183,15 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         int cur = 0;
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
+        // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
+        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && !ctx->fb_strict_rows;
+        FoldScratch fs = {};
+        if (fold) {
+            fs = fold_scratch(ctx, width, height);
+            if (k == levels) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fs.counters, 0, sizeof(unsigned) * (ofxcv_div_up(width, kSsW) + 1), s));
+            rc = launch_fold_seed(ctx, s, Mbuf[0], w, h, fs, 0);
+            if (rc) return rc;
+        }
         for (int i = 0; i < iterations;) {
             const bool pair = fuse && i + 2 <= iterations - 1;
             const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
@@ -1841,6 +2205,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                 bool update = i < iterations - 1;
                 if (gaussian)
                     rc = launch_gauss_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                else if (fold)
+                    rc = launch_fold_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, update, fs, cur);
                 else
                     rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
                 i += 1;

@@ -244,6 +244,25 @@ def test_opencv_order_mode_strip_heights_and_serial_scan_agree(oracle, ofxcv, ro
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("w,h", [(125, 70), (333, 257), (640, 480)])
+def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
+    """the carries of the f64 column sums from a pre-pass over M (default) or produced by the iteration kernel itself
+    (farneback.fold_carries 1: prefix over the strips by the last workgroup of a tile column, an atomic counter, device-scope
+    loads; 2: by a small launch of its own): the same flow, within tolerance of the faithful oracle at every sample"""
+    ga, gb = _gray_pair(oracle, w, h)
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    outs = []
+    for fold in (0, 1, 2):
+        ctx = ofxcv.Context(0)
+        ctx.set_option("farneback.fold_carries", fold)
+        for _ in range(2):   # twice: the tile-column counters must be back at zero after a call
+            got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+        ctx.close()
+        assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), fold
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
     rng = np.random.default_rng(13)
     h, w = 119, 161
