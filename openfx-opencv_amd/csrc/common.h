@@ -63,7 +63,7 @@ struct ofxcv_ctx {
     int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
     int fb_fold_carries = 0;  // OpenCV-order mode: 0 (default, fastest measured) carry pre-pass over all of M per iteration; 1 carries folded into the iteration kernel,
                               // prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
-    int fb_strict_variant = 0, fb_carry_groups = 0;  // A/B knobs of the strip-parallel form
+    int fb_strict_variant = 0, fb_carry_groups = 0, fb_lds_pad = 0;  // A/B knobs of the strip-parallel form
     int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
 
     // inpaint scratch

@@ -218,6 +218,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->fb_fold_carries = value < 0 ? 0 : (value > 2 ? 2 : value);
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.lds_pad")) {
+        ctx->fb_lds_pad = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.strict_variant")) {
         ctx->fb_strict_variant = value;
         return OFXCV_OK;

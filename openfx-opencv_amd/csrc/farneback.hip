@@ -1366,7 +1366,9 @@ __device__ __forceinline__ double dpp64_from_right(double v) {  // lane i <- lan
 
 constexpr int kSsW = 62;  // columns a wavefront of iterate3s_kernel owns (lanes 1..62; lanes 0 and 63 carry the halo columns)
 
-template <bool UPDATE, int RW, bool PIPE>
+// MODE 0: the R1 gather of a row is consumed right away; 1: issued one row ahead of the arithmetic that consumes it; 2: rows in
+// pairs -- both gathers are issued back to back (the bottom R1 row of one is the top row of the other), then both finished
+template <bool UPDATE, int RW, int MODE>
 __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                         const float *__restrict__ Min, float *__restrict__ Mout,
                                                         float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
@@ -1423,11 +1425,7 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
             for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
         }
     };
-#pragma unroll
-    for (int j = 0; j < RW; j++) {
-        const int y = a + j;
-        if (y >= h) break;  // wave-uniform
-        if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
+    auto solve_row = [&](int j, float &fxv, float &fyv) {
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1436,17 +1434,46 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
         }
         double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
         double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    };
+    auto request = [&](Px &p, int y) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) p.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+        p.tp = gather_taps(bR1, x, y, w, h, pitch, pb, p.fxv, p.fyv);
+    };
+    if (MODE == 2 && UPDATE) {
+#pragma unroll
+        for (int j = 0; j < RW; j += 2) {
+            const int y = a + j;
+            if (y >= h) break;  // wave-uniform
+            const bool two = j + 1 < RW && y + 1 < h;
+            if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
+            if (j + 4 + PF < RW + 3) load_m(j + 4 + PF);
+            Px p0, p1;
+            solve_row(j, p0.fxv, p0.fyv);
+            if (two) solve_row(j + 1, p1.fxv, p1.fyv);
+            request(p0, y);
+            if (two) request(p1, y + 1);
+            finish(p0, y);
+            if (two) finish(p1, y + 1);
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+        const int y = a + j;
+        if (y >= h) break;  // wave-uniform
+        if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
+        float fxv, fyv;
+        solve_row(j, fxv, fyv);
         if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
         if (UPDATE) {
             Px cur;
             cur.fxv = fxv;
             cur.fyv = fyv;
-#pragma unroll
-            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
-            if (PIPE) {
+            request(cur, y);
+            if (MODE == 1) {
                 if (j > 0) finish(prev, y - 1);
                 prev = cur;
             } else {
@@ -1454,7 +1481,7 @@ __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict_
             }
         }
     }
-    if (UPDATE && PIPE) finish(prev, min(a + RW, h) - 1);
+    if (UPDATE && MODE == 1) finish(prev, min(a + RW, h) - 1);
 }
 
 // ------------------------------------------------------------------ OpenCV-order window, carries folded into the iteration
@@ -1862,20 +1889,24 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw);            \
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
         if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-        if (update && pipe)                                                                                                              \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, true>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+        if (update && pairs)                                                                                                             \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 2>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg);                                                        \
+        else if (update && pipe)                                                                                                         \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 1>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
         else if (update)                                                                                                                 \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, false>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<false, RW, false>), grid, dim3(128), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
+            hipLaunchKernelGGL((iterate3s_kernel<false, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
                                (const double *)carry, (const double *)gtot, spg);                                                        \
         if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
     } while (0)
         const int mark = ctx->prof_now ? ctx->prof_on : 0;  // measurement hook: 1 = the iteration kernel, 2 = the carry pre-pass
+        const size_t lds_pad = (size_t)ctx->fb_lds_pad;     // A/B: unused dynamic LDS that limits the resident workgroups per CU
         int rc;
-        const bool pipe = !(ctx->fb_strict_variant & 1);
+        const bool pipe = !(ctx->fb_strict_variant & 1), pairs = (ctx->fb_strict_variant & 2) != 0;
         if (rw == 16) OFXCV_LAUNCH_SS(16);
         else if (rw == 8) OFXCV_LAUNCH_SS(8);
         else if (rw == 4) OFXCV_LAUNCH_SS(4);

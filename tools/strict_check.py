@@ -18,7 +18,7 @@ for w, h in sizes:
     a, b = synth.flow_pair(w, h)
     ga, gb = oracle.to_byte_grayscale(a), oracle.to_byte_grayscale(b)
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
-    for name, opts in [("serial", {"farneback.opencv_rounding": 2}), ("two-kernel", {"farneback.fold_carries": 0}), ("folded-1", {"farneback.fold_carries": 1}), ("folded-2", {"farneback.fold_carries": 2})]:
+    for name, opts in [("serial", {"farneback.opencv_rounding": 2}), ("two-kernel", {"farneback.fold_carries": 0}), ("folded-1", {"farneback.fold_carries": 1}), ("folded-2", {"farneback.fold_carries": 2}), ("row pairs", {"farneback.strict_variant": 2})]:
         ctx = ofxcv.Context(0)
         for k, v in opts.items():
             ctx.set_option(k, v)
