@@ -72,6 +72,14 @@ struct ofxcv_ctx {
     DevBuf ip_img;   // device copies of the host images (render_host)
     DevBuf ip_work;  // 4-byte-per-pixel working images of the colour fill
     DevBuf ip_flag;  // error flag of the dataflow fill (a poll gave up)
+    DevBuf ip_tmap, ip_omap;  // persistent padded distance / order maps (defaults everywhere between calls)
+    int ip_map_w = 0, ip_map_h = 0;
+    void *ip_host_state = nullptr;           // host state of the front march (inpaint.hip: March)
+    void (*ip_host_state_free)(void *) = nullptr;
+    void *ip_pinned = nullptr;   // pinned mirror of the per-pixel upload arrays of the pipelined fill
+    size_t ip_pinned_bytes = 0;
+    int ip_per_wg = 0;       // option "inpaint.pixels_per_workgroup" (A/B)
+    int ip_portion = 0;      // option "inpaint.portion": fill-order pixels per portion of the pipelined fill (0 = default)
     DevBuf ip_sched2; // level schedule of the fall-back fill
     int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)
     long ip_fallbacks = 0;   // fills that were repeated with the barrier-scheduled kernel

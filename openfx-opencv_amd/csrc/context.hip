@@ -165,11 +165,13 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_level)
         if (e) (void)hipEventDestroy(e);
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
+    if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->ip_pinned) (void)hipHostFree(ctx->ip_pinned);
     for (int i = 0; i < 3; i++)
         if (ctx->ev_h2d[i]) (void)hipEventDestroy(ctx->ev_h2d[i]);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
@@ -208,6 +210,14 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "host.register")) {
         ctx->host_register = value != 0;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "inpaint.pixels_per_workgroup")) {
+        ctx->ip_per_wg = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "inpaint.portion")) {
+        ctx->ip_portion = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "inpaint.spin_limit")) {

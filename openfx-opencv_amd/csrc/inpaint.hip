@@ -28,6 +28,9 @@
 #include <queue>
 #include <vector>
 
+#include <chrono>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -132,10 +135,15 @@ void zero_frame(std::vector<uint8_t> &m, int rows, int cols) {
     for (int i = 0; i < rows; i++) m[i * cols] = m[i * cols + cols - 1] = 0;
 }
 
+// Host state of the front march.  The maps are as large as the padded frame but only ever touched at hole pixels, their
+// band and the outward ring: they persist with the context and are reset sparsely (the lists of touched indices), so a call
+// costs time proportional to the hole, not to the frame (22 MB of fills per 1080p call otherwise).
 struct March {
     int w = 0, h = 0, range = 1;
-    std::vector<float> t;      // (h+2)*(w+2) final distance map (negative outside the hole within `range`)
-    std::vector<int> ord;      // (h+2)*(w+2): 0 = not a hole pixel, k >= 1 = filled k-th, kNeverFilled = hole never reached
+    std::vector<float> t;      // (h+2)*(w+2) final distance map (negative outside the hole within `range`); default 1e6
+    std::vector<int> ord;      // (h+2)*(w+2): 0 = not a hole pixel, k >= 1 = filled k-th, kNeverFilled = hole not (yet) reached
+    std::vector<uint8_t> mask, band, ring;  // flag maps of the reference's set-up; default 0
+    std::vector<int> holes, seeds, ring_px; // indices set in mask / band / ring
     std::vector<int> pix;      // fill order: padded linear index of the k-th filled pixel
     std::vector<int> level;    // dependency level (>= 1) of the k-th filled pixel
     std::vector<int> lvl_pix;  // pixels (padded linear index) sorted by (level, order)
@@ -144,20 +152,46 @@ struct March {
     std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
     // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
     std::vector<int> cmp_pix, cmp_ord, cmp_off;
-    std::vector<int> touched;  // scratch of march_front
+    std::vector<int> touched;  // scratch of the ring march
     std::vector<int> cmp_wg;   // per workgroup: {first pixel, end, first wavefront slot, slots in total}
+    FrontQueue heap;           // the inward front
+    int filled = 0;
+    bool dirty = false;
+    std::vector<int> up_idx, up_ord, cell, stack;  // upload / scheduling scratch kept between calls
+    std::vector<float> up_t, up_ft;
+
+    void clear_sparse() {  // back to the defaults at every index a call touched
+        for (int p : holes) { t[p] = 1.0e6f; ord[p] = 0; mask[p] = 0; }
+        for (int p : seeds) { t[p] = 1.0e6f; band[p] = 0; }
+        for (int p : ring_px) { t[p] = 1.0e6f; ring[p] = 0; }
+        holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
+        heap = FrontQueue();
+        filled = 0;
+        dirty = false;
+    }
+    void prepare(int w_, int h_, int range_) {
+        const size_t en = (size_t)(w_ + 2) * (h_ + 2);
+        if (w_ != w || h_ != h || t.size() != en) {
+            w = w_; h = h_;
+            t.assign(en, 1.0e6f);
+            ord.assign(en, 0);
+            mask.assign(en, 0); band.assign(en, 0); ring.assign(en, 0);
+            holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
+            heap = FrontQueue(); filled = 0; dirty = false;
+        } else if (dirty) {
+            clear_sparse();
+        }
+        range = range_;
+    }
 };
 
-// cvInpaint set-up + icvCalcFMM(negate) + the front recurrence of icvTeleaInpaintFMM (photo/src/inpaint.cpp)
-void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_ring, March &m) {
-    const int ec = w + 2, er = h + 2;
-    const size_t en = (size_t)ec * er;
-    m.w = w;
-    m.h = h;
-    m.range = range;
-    // Everything below works from the list of hole pixels: the maps are only zero-filled, never scanned.
-    std::vector<uint8_t> mask(en, 0), band(en, 0);
-    std::vector<int> holes;
+// cvInpaint set-up + icvCalcFMM(negate) (photo/src/inpaint.cpp): hole list, band seeds, outward ring (Telea) -- everything up
+// to the inward front, which march_advance() then moves on in portions.  Returns false when there is nothing to fill.
+bool march_begin(const uint8_t *mask_in, bool outside_ring, March &m) {
+    const int w = m.w, h = m.h, range = m.range, ec = w + 2, er = h + 2;
+    m.dirty = true;
+    uint8_t *mask = m.mask.data(), *band = m.band.data();
+    std::vector<int> &holes = m.holes, &seeds = m.seeds;
     for (int i = 0; i < h; i++) {
         const uint8_t *row = mask_in + (size_t)i * w;
         for (int j = 0; j < w; j++)
@@ -166,12 +200,8 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
                 holes.push_back((i + 1) * ec + j + 1);
             }
     }
-    m.t.assign(en, 1.0e6f);
-    m.ord.assign(en, 0);
-    m.pix.clear();
-    if (holes.empty()) return;
+    if (holes.empty()) return false;
     // band = dilate(mask, 3x3 cross) - mask, frame zeroed; seeds in row-major order
-    std::vector<int> seeds;
     const int d4[4] = {-ec, -1, 1, ec};
     for (int p : holes)
         for (int q = 0; q < 4; q++) {
@@ -183,10 +213,10 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
             }
         }
     std::sort(seeds.begin(), seeds.end());
-    FrontQueue heap, outq;
+    FrontQueue outq;
     for (int n : seeds) {
         const int i = n / ec, j = n - i * ec;
-        heap.push(i, j, 0);
+        m.heap.push(i, j, 0);
         outq.push(i, j, 0);
         m.t[n] = 0;
     }
@@ -195,7 +225,7 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
     if (outside_ring) {  // CV_INPAINT_TELEA only; CV_INPAINT_NS leaves T = 1e6 off the band
         // ring = dilate(mask, (2r+1)^2 rect) - mask - band, frame zeroed.  A non-hole pixel within Chebyshev distance r of
         // the hole is within r of a hole pixel that has a non-hole 8-neighbour, so only those spread the ring.
-        std::vector<uint8_t> ring(en, 0);
+        uint8_t *ring = m.ring.data();
         bool any_ring = false;
         for (int p : holes) {
             const int pi = p / ec, pj = p - pi * ec;
@@ -206,10 +236,13 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
             any_ring = true;
             for (int a = std::max(pi - range, 1); a <= std::min(pi + range, er - 2); a++)
                 for (int c = std::max(pj - range, 1); c <= std::min(pj + range, ec - 2); c++)
-                    if (!mask[a * ec + c] && !band[a * ec + c]) ring[a * ec + c] = INSIDE;
+                    if (!mask[a * ec + c] && !band[a * ec + c] && !ring[a * ec + c]) {
+                        ring[a * ec + c] = INSIDE;
+                        m.ring_px.push_back(a * ec + c);
+                    }
         }
-        if (!any_ring) return;  // Out->Init fails in the reference: cvInpaint returns without filling
-        uint8_t *f = ring.data();
+        if (!any_ring) return false;  // Out->Init fails in the reference: cvInpaint returns without filling
+        uint8_t *f = ring;
         while (outq.pop(ii, jj)) {
             f[ii * ec + jj] = CHANGE;
             const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
@@ -229,12 +262,24 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
         for (int n : m.touched)
             if (f[n] == CHANGE) t[n] = -t[n];
         m.touched.clear();
+        // the seeds were marked CHANGE in the ring map as they were popped: they are reset with the seeds
+        for (int n : seeds) ring[n] = 0;
     }
     // inward front over the hole; the reference passes `mask` ({KNOWN, INSIDE}) as the flag map
     for (int p : holes) m.ord[p] = kNeverFilled;
-    uint8_t *f = mask.data();
-    int filled = 0;
-    while (heap.pop(ii, jj)) {
+    m.filled = 0;
+    return true;
+}
+
+// the front recurrence of icvTeleaInpaintFMM: moves the inward front on until at least `want` more pixels have their
+// distance and order number (or the front is exhausted); returns how many were added to m.pix
+int march_advance(March &m, int want) {
+    const int ec = m.w + 2, er = m.h + 2;
+    uint8_t *f = m.mask.data();
+    float *t = m.t.data();
+    const size_t before = m.pix.size();
+    int ii, jj;
+    while ((int)(m.pix.size() - before) < want && m.heap.pop(ii, jj)) {
         f[ii * ec + jj] = KNOWN;
         const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
         for (int q = 0; q < 4; q++) {
@@ -244,11 +289,12 @@ void march_front(const uint8_t *mask_in, int w, int h, int range, bool outside_r
             float dist = front_value(i, j, f, t, ec);
             t[i * ec + j] = dist;
             f[i * ec + j] = BAND;
-            heap.push(i, j, dist);
-            m.ord[i * ec + j] = ++filled;
+            m.heap.push(i, j, dist);
+            m.ord[i * ec + j] = ++m.filled;
             m.pix.push_back(i * ec + j);
         }
     }
+    return (int)(m.pix.size() - before);
 }
 
 // level(p) = 1 + max level of the pixels filled before p within Chebyshev distance range+2 (every pixel whose
@@ -352,6 +398,76 @@ void build_levels(March &m, bool dataflow) {
     m.lvl_off.push_back(n);
     m.comp_off.push_back((int)m.lvl_off.size() - 1);
     if (n == 0) m.comp_off.assign(1, 0);
+}
+
+// Dataflow schedule of ONE portion of the fill order, pixels [k0, k1): their components (connected groups of occupied
+// coarse cells, as in build_levels) in fill order, 1..8 workgroups per component.  Appends to the call-wide arrays
+// (sched_pix / sched_ord hold the pixels of all portions one after the other; a workgroup record addresses them
+// absolutely); returns the number of workgroups added.  Pixels of earlier portions are complete when this portion's
+// launch starts (stream order), later ones still carry kNeverFilled in the order map: the polls only ever wait inside
+// the portion.
+int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
+                           std::vector<int> &cell, std::vector<int> &stack, int per_wg) {
+    const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
+    const int cs = 2 * R + 1, gw = (ec + cs - 1) / cs, gh = (er + cs - 1) / cs;
+    const int n = k1 - k0;
+    if (n <= 0) return 0;
+    if (cell.size() != (size_t)gw * gh) cell.assign((size_t)gw * gh, -1);
+    std::vector<int> occupied;
+    for (int k = k0; k < k1; k++) {
+        const int c = (m.pix[k] / ec / cs) * gw + (m.pix[k] % ec) / cs;
+        if (cell[c] == -1) {
+            cell[c] = -2;
+            occupied.push_back(c);
+        }
+    }
+    int ncomp = 0;
+    for (int c0 : occupied) {
+        if (cell[c0] != -2) continue;
+        cell[c0] = ncomp;
+        stack.assign(1, c0);
+        while (!stack.empty()) {
+            int c = stack.back();
+            stack.pop_back();
+            int cy = c / gw, cx = c % gw;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    int yy = cy + dy, xx = cx + dx;
+                    if (yy < 0 || xx < 0 || yy >= gh || xx >= gw || cell[yy * gw + xx] != -2) continue;
+                    cell[yy * gw + xx] = ncomp;
+                    stack.push_back(yy * gw + xx);
+                }
+        }
+        ncomp++;
+    }
+    // counting sort by component keeps the fill order inside each component
+    std::vector<int> off(ncomp + 1, 0), comp(n);
+    for (int k = 0; k < n; k++) {
+        comp[k] = cell[(m.pix[k0 + k] / ec / cs) * gw + (m.pix[k0 + k] % ec) / cs];
+        off[comp[k] + 1]++;
+    }
+    for (int c = 0; c < ncomp; c++) off[c + 1] += off[c];
+    const int base = (int)sched_pix.size();
+    sched_pix.resize(base + n);
+    sched_ord.resize(base + n);
+    std::vector<int> fillp(off.begin(), off.end() - 1);
+    for (int k = 0; k < n; k++) {
+        const int q = base + fillp[comp[k]]++;
+        sched_pix[q] = m.pix[k0 + k];
+        sched_ord[q] = k0 + k + 1;
+    }
+    int nwg = 0;
+    for (int c = 0; c < ncomp; c++) {
+        const int nc = off[c + 1] - off[c];
+        const int g = std::min(8, std::max(1, (nc + per_wg - 1) / per_wg));
+        for (int r = 0; r < g; r++) {
+            const int rec[4] = {base + off[c], base + off[c + 1], r * kFillWavesHost, g * kFillWavesHost};
+            sched_wg.insert(sched_wg.end(), rec, rec + 4);
+            nwg++;
+        }
+    }
+    for (int c : occupied) cell[c] = -1;  // the grid is reused by the next portion
+    return nwg;
 }
 
 // ------------------------------------------------------------------ I4 colour fill (device)
@@ -653,6 +769,48 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     }
 }
 
+// ---- persistent device maps of the march (distance, order number): defaults everywhere, sparse updates per call
+__global__ __launch_bounds__(256) void map_init_kernel(float *__restrict__ t, int *__restrict__ ord, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        t[i] = 1.0e6f;
+        ord[i] = 0;
+    }
+}
+__global__ __launch_bounds__(256) void map_scatter_kernel(const int *__restrict__ idx, const float *__restrict__ tv, const int *__restrict__ ov, int n,
+                                                          float *__restrict__ t, int *__restrict__ ord) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        t[idx[i]] = tv[i];
+        ord[idx[i]] = ov[i];
+    }
+}
+// fill-order pixels k0+1 .. k0+n (their order numbers are consecutive)
+__global__ __launch_bounds__(256) void map_scatter_front_kernel(const int *__restrict__ idx, const float *__restrict__ tv, int first_order, int n,
+                                                                float *__restrict__ t, int *__restrict__ ord) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        t[idx[i]] = tv[i];
+        ord[idx[i]] = first_order + i;
+    }
+}
+__global__ __launch_bounds__(256) void map_reset_kernel(const int *__restrict__ idx, int n, float *__restrict__ t, int *__restrict__ ord) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        t[idx[i]] = 1.0e6f;
+        ord[idx[i]] = 0;
+    }
+}
+// padded order map -> width x height index map of the C ABI (1-based fill order, 0 = not filled)
+__global__ __launch_bounds__(256) void order_map_kernel(const int *__restrict__ ord, int w, int h, int *__restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const int o = ord[(size_t)(y + 1) * (w + 2) + x + 1];
+    out[(size_t)y * w + x] = o == kNeverFilled ? 0 : o;
+}
+
+constexpr int kFillPortion = 8192;  // fill-order pixels per portion of the pipelined dataflow fill
+
 // Termination of the dataflow fill.  A wavefront only ever waits for pixels of its own component with a smaller order
 // number.  Components with ONE workgroup (up to 2000 pixels -- all of them for dust-like masks, however many
 // components there are) therefore wait only inside their workgroup, whose wavefronts are co-resident by construction:
@@ -739,123 +897,233 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     range = std::min(std::max(range, 1), 100);
     const int w = width, h = height, ec = w + 2, er = h + 2;
     const size_t en = (size_t)ec * er;
+    static const bool trace = getenv("OFXCV_TRACE_INPAINT") != nullptr;  // debug: phase times on stderr
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = trace ? now() : 0;
 
     // dst = src (cvCopy(input_img, output_img)); the mask comes back to the host for the front march
     OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_dst, dst_step, d_src, src_step, (size_t)w * channels, h, hipMemcpyDeviceToDevice, s));
     std::vector<uint8_t> mask((size_t)w * h);
     OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(mask.data(), w, d_mask, mask_step, w, h, hipMemcpyDeviceToHost, s));
-    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
 
-    March m;
+    // persistent device maps (distance, order): defaults everywhere, touched only at the hole, its band and the ring
+    int rc;
+    if (ctx->ip_map_w != w || ctx->ip_map_h != h || !ctx->ip_tmap.ptr) {
+        rc = ofxcv_reserve(ctx, ctx->ip_tmap, en * 4);
+        if (rc) return rc;
+        rc = ofxcv_reserve(ctx, ctx->ip_omap, en * 4);
+        if (rc) return rc;
+        hipLaunchKernelGGL(map_init_kernel, dim3((unsigned)((en + 255) / 256)), dim3(256), 0, s, (float *)ctx->ip_tmap.ptr, (int *)ctx->ip_omap.ptr, en);
+        OFXCV_LAUNCH_CHECK(ctx, "map_init_kernel");
+        ctx->ip_map_w = w;
+        ctx->ip_map_h = h;
+    }
+    float *d_t = (float *)ctx->ip_tmap.ptr;
+    int *d_ord = (int *)ctx->ip_omap.ptr;
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the mask is on the host
+
+    if (!ctx->ip_host_state) {
+        ctx->ip_host_state = new March();
+        ctx->ip_host_state_free = [](void *p) { delete (March *)p; };
+    }
+    March &m = *(March *)ctx->ip_host_state;
+    m.prepare(w, h, range);
     const bool dataflow = range <= kMaxLdsRange;
-    march_front(mask.data(), w, h, range, !ns, m);
-    build_levels(m, dataflow);
-    const int n = (int)m.pix.size();
+    const bool any = march_begin(mask.data(), !ns, m);
+    const double t_setup = trace ? now() : 0;
 
-    if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, m.t.data(), en * sizeof(float), hipMemcpyHostToDevice, s));
-    if (d_order_map) {
-        std::vector<int> order((size_t)w * h);
-        for (int i = 0; i < h; i++)
-            for (int j = 0; j < w; j++) {
-                int o = m.ord[(i + 1) * ec + j + 1];
-                order[(size_t)i * w + j] = o == kNeverFilled ? 0 : o;
-            }
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_order_map, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // `order` is a local
-    }
-    if (n > 0) {
-        // schedule arrays: (pixels, order numbers, offsets A, offsets B); dataflow uses only the first three
-        const std::vector<int> &sp = dataflow ? m.cmp_pix : m.lvl_pix, &so = dataflow ? m.cmp_ord : m.lvl_ord;
-        const std::vector<int> &sa = dataflow ? m.cmp_wg : m.lvl_off, &sb = dataflow ? m.cmp_off : m.comp_off;
-        const int ncomp = dataflow ? (int)m.cmp_wg.size() / 4 : (int)sb.size() - 1;  // workgroups to launch
-        const size_t off_t = 0, off_ord = align_up(off_t + en * 4, 256), off_pix = align_up(off_ord + en * 4, 256),
-                     off_po = align_up(off_pix + (size_t)n * 4, 256), off_lo = align_up(off_po + (size_t)n * 4, 256),
-                     off_co = align_up(off_lo + sa.size() * 4, 256), total = align_up(off_co + sb.size() * 4, 256);
-        int rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
-        if (rc) return rc;
-        char *dp = (char *)ctx->ip_maps.ptr;
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_t, m.t.data(), en * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_ord, m.ord.data(), en * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, sp.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, so.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, sa.data(), sa.size() * 4, hipMemcpyHostToDevice, s));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_co, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, s));
-        rc = ofxcv_reserve(ctx, ctx->ip_work, 2 * (size_t)w * h * 4);
-        if (rc) return rc;
-        uint32_t *work_src = (uint32_t *)ctx->ip_work.ptr, *work_out = work_src + (size_t)w * h;
-        dim3 pblock(256), pgrid(ofxcv_div_up(w, 256), h);
-        if (channels == 4)
-            hipLaunchKernelGGL(pack_rgbx_kernel<4>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
-        else
-            hipLaunchKernelGGL(pack_rgbx_kernel<3>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
-        OFXCV_LAUNCH_CHECK(ctx, "pack_rgbx_kernel");
-        FillArgs fa;
-        fa.t = (const float *)(dp + off_t);
-        fa.ord = (const int *)(dp + off_ord);
-        fa.src = work_src;
-        fa.out = work_out;
-        fa.w = w;
-        fa.h = h;
-        fa.range = range;
-        fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);
-        fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
-        fa.lvl_off = fa.cmp_off = (const int *)(dp + off_lo);
-        fa.comp_off = (const int *)(dp + off_co);
-        FillSlot slot;  // released after the stream synchronisation below (or on an early return)
-        if (range <= kMaxLdsRange) {
-            // dataflow kernel with bounded polls; its error flag lives behind the schedule arrays
-            rc = ofxcv_reserve(ctx, ctx->ip_flag, 256);
-            if (rc) return rc;
-            fa.err = (int *)ctx->ip_flag.ptr;
-            fa.spin_limit = ctx->ip_spin_limit >= 0 ? ctx->ip_spin_limit : kSpinLimit;
-            OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fa.err, 0, sizeof(int), s));
-            if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
-            else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
-            OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
-            int timed_out = 0;
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(&timed_out, fa.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    // every index the march touches outside the inward front: holes (order "not yet"), band seeds and ring (their distances)
+    const int n_holes = (int)m.holes.size(), n_static = n_holes + (int)m.seeds.size() + (int)m.ring_px.size();
+    std::vector<int> &st_idx = m.up_idx, &st_ord = m.up_ord;
+    std::vector<float> &st_t = m.up_t;
+    st_idx.clear(); st_ord.clear(); st_t.clear();
+    st_idx.reserve(n_static); st_ord.reserve(n_static); st_t.reserve(n_static);
+    for (int p : m.holes) { st_idx.push_back(p); st_t.push_back(1.0e6f); st_ord.push_back(m.ord[p]); }
+    for (int p : m.seeds) { st_idx.push_back(p); st_t.push_back(m.t[p]); st_ord.push_back(0); }
+    for (int p : m.ring_px) { st_idx.push_back(p); st_t.push_back(m.t[p]); st_ord.push_back(0); }
+    // device scratch: static entries, then per-pixel entries of the front (index, distance, order number), the schedule
+    // arrays (pixels, order numbers: n_holes each) and the workgroup records (4 ints each, at most one per pixel)
+    const size_t a256 = 256;
+    const size_t off_si = 0, off_st = align_up(off_si + (size_t)n_static * 4, a256), off_so = align_up(off_st + (size_t)n_static * 4, a256),
+                 off_fi = align_up(off_so + (size_t)n_static * 4, a256), off_ft = align_up(off_fi + (size_t)n_holes * 4, a256),
+                 off_fo = align_up(off_ft + (size_t)n_holes * 4, a256), off_pix = align_up(off_fo + (size_t)n_holes * 4, a256),
+                 off_po = align_up(off_pix + (size_t)n_holes * 4, a256), off_wg = align_up(off_po + (size_t)n_holes * 4, a256),
+                 off_lo = align_up(off_wg + (size_t)n_holes * 16 + 16, a256), total = align_up(off_lo + ((size_t)n_holes + 2) * 8 + 256, a256);
+    rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
+    if (rc) return rc;
+    char *dp = (char *)ctx->ip_maps.ptr;
+    // pinned host mirror of the per-pixel part of that scratch: the portions of the pipelined fill are handed over with
+    // true asynchronous copies (a copy from pageable memory costs the host ~20 us and there are five per portion)
+    if (ctx->ip_pinned_bytes < total) {
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        if (ctx->ip_pinned) {
             OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
-            if (timed_out) {
-                // a poll gave up: repeat with the level schedule (workgroup barriers between dependency levels, nothing
-                // waits across workgroups).  Same arithmetic, same order: identical colours.
-                ctx->ip_fallbacks++;
-                build_levels(m, false);
-                const size_t o_pix = 0, o_po = align_up((size_t)n * 4, 256), o_lo = align_up(o_po + (size_t)n * 4, 256),
-                             o_co = align_up(o_lo + m.lvl_off.size() * 4, 256), tot = align_up(o_co + m.comp_off.size() * 4, 256);
-                rc = ofxcv_reserve(ctx, ctx->ip_sched2, tot);
-                if (rc) return rc;
-                char *d2 = (char *)ctx->ip_sched2.ptr;
-                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_lo, m.lvl_off.data(), m.lvl_off.size() * 4, hipMemcpyHostToDevice, s));
-                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d2 + o_co, m.comp_off.data(), m.comp_off.size() * 4, hipMemcpyHostToDevice, s));
-                fa.lvl_pix = fa.cmp_pix = (const int *)(d2 + o_pix);
-                fa.lvl_ord = fa.cmp_ord = (const int *)(d2 + o_po);
-                fa.lvl_off = fa.cmp_off = (const int *)(d2 + o_lo);
-                fa.comp_off = (const int *)(d2 + o_co);
-                // working copy back to "nothing filled yet"
-                if (channels == 4)
-                    hipLaunchKernelGGL(pack_rgbx_kernel<4>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
-                else
-                    hipLaunchKernelGGL(pack_rgbx_kernel<3>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
-                const int nwg = (int)m.comp_off.size() - 1;
-                if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
-                else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
-            }
-        } else {
-            fa.err = nullptr;
-            fa.spin_limit = 0;
-            if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
-            else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(ncomp), dim3(kFillThreads), 0, s, fa);
+            (void)hipHostFree(ctx->ip_pinned);
+            ctx->ip_pinned = nullptr;
+            ctx->ip_pinned_bytes = 0;
         }
-        OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
-        if (channels == 4)
-            hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
-        else
-            hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
-        OFXCV_LAUNCH_CHECK(ctx, "unpack_rgbx_kernel");
-        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host vectors above must outlive the copies
+        OFXCV_HIP_CHECK(ctx, hipHostMalloc(&ctx->ip_pinned, total + (total >> 2), hipHostMallocDefault));
+        ctx->ip_pinned_bytes = total + (total >> 2);
     }
+    char *hp = (char *)ctx->ip_pinned;
+    auto reset_maps = [&]() -> int {  // device maps back to their defaults (the host maps are reset at the next prepare())
+        if (n_static) {
+            hipLaunchKernelGGL(map_reset_kernel, dim3((n_static + 255) / 256), dim3(256), 0, s, (const int *)(dp + off_si), n_static, d_t, d_ord);
+            OFXCV_LAUNCH_CHECK(ctx, "map_reset_kernel");
+        }
+        return OFXCV_OK;
+    };
+    if (n_static) {
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_si, st_idx.data(), (size_t)n_static * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_st, st_t.data(), (size_t)n_static * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_so, st_ord.data(), (size_t)n_static * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(map_scatter_kernel, dim3((n_static + 255) / 256), dim3(256), 0, s, (const int *)(dp + off_si), (const float *)(dp + off_st),
+                           (const int *)(dp + off_so), n_static, d_t, d_ord);
+        OFXCV_LAUNCH_CHECK(ctx, "map_scatter_kernel");
+    }
+    auto write_maps = [&]() -> int {  // optional parity outputs, from the device maps
+        if (d_t_map) OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_t_map, d_t, en * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (d_order_map) {
+            hipLaunchKernelGGL(order_map_kernel, dim3(ofxcv_div_up(w, 256), h), dim3(256), 0, s, (const int *)d_ord, w, h, d_order_map);
+            OFXCV_LAUNCH_CHECK(ctx, "order_map_kernel");
+        }
+        return OFXCV_OK;
+    };
+    if (!any || n_holes == 0) {  // nothing to fill (no hole, or the reference's Out->Init failure)
+        if ((rc = write_maps())) return rc;
+        if ((rc = reset_maps())) return rc;
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        return OFXCV_OK;
+    }
+
+    rc = ofxcv_reserve(ctx, ctx->ip_work, 2 * (size_t)w * h * 4);
+    if (rc) return rc;
+    uint32_t *work_src = (uint32_t *)ctx->ip_work.ptr, *work_out = work_src + (size_t)w * h;
+    dim3 pblock(256), pgrid(ofxcv_div_up(w, 256), h);
+    auto pack = [&]() {
+        if (channels == 4) hipLaunchKernelGGL(pack_rgbx_kernel<4>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+        else hipLaunchKernelGGL(pack_rgbx_kernel<3>, pgrid, pblock, 0, s, d_src, src_step, w, h, work_src, work_out);
+    };
+    pack();
+    OFXCV_LAUNCH_CHECK(ctx, "pack_rgbx_kernel");
+    FillArgs fa;
+    fa.t = d_t;
+    fa.ord = d_ord;
+    fa.src = work_src;
+    fa.out = work_out;
+    fa.w = w;
+    fa.h = h;
+    fa.range = range;
+    fa.err = nullptr;
+    fa.spin_limit = 0;
+    fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);
+    fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
+    fa.lvl_off = fa.cmp_off = (const int *)(dp + off_wg);
+    fa.comp_off = (const int *)(dp + off_lo);
+    FillSlot slot;  // released when the call returns (after its last stream synchronisation)
+
+    // uploads the distances / order numbers of fill-order pixels [k0, k1) into the device maps
+    auto scatter_front = [&](int k0, int k1) -> int {
+        const int n = k1 - k0;
+        if (n <= 0) return OFXCV_OK;
+        int *pi = (int *)(hp + off_fi) + k0;
+        float *pt = (float *)(hp + off_ft) + k0;
+        for (int k = 0; k < n; k++) {
+            pi[k] = m.pix[k0 + k];
+            pt[k] = m.t[m.pix[k0 + k]];
+        }
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_fi + (size_t)k0 * 4, pi, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_ft + (size_t)k0 * 4, pt, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(map_scatter_front_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const int *)(dp + off_fi) + k0, (const float *)(dp + off_ft) + k0, k0 + 1, n,
+                           d_t, d_ord);
+        OFXCV_LAUNCH_CHECK(ctx, "map_scatter_front_kernel");
+        return OFXCV_OK;
+    };
+    double t_march = 0, t_sched = 0;
+    int launches = 0;
+    bool timed_out = false;
+    if (dataflow) {
+        // The front is strictly sequential on the host; the colours are not.  The host moves the front on by a portion,
+        // hands that portion's pixels to the GPU (their distances and order numbers into the device maps, their dataflow
+        // schedule, one fill launch) and goes on marching while the GPU fills: the fill of a 1080p frame hides behind the march.
+        rc = ofxcv_reserve(ctx, ctx->ip_flag, 256);
+        if (rc) return rc;
+        fa.err = (int *)ctx->ip_flag.ptr;
+        fa.spin_limit = ctx->ip_spin_limit >= 0 ? ctx->ip_spin_limit : kSpinLimit;
+        OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fa.err, 0, sizeof(int), s));
+        std::vector<int> &sp = m.cmp_pix, &so = m.cmp_ord, &sw = m.cmp_wg;
+        sp.clear(); so.clear(); sw.clear();
+        // no reallocation while asynchronous copies from these arrays may be in flight
+        sp.reserve(n_holes); so.reserve(n_holes); sw.reserve((size_t)n_holes * 4 + 4);
+        m.pix.reserve(n_holes);
+        const int portion = ctx->ip_portion > 0 ? ctx->ip_portion : kFillPortion;
+        for (;;) {
+            const double ta = trace ? now() : 0;
+            const int k0 = (int)m.pix.size();
+            const int got = march_advance(m, portion);
+            const double tb = trace ? now() : 0;
+            t_march += tb - ta;
+            if (got <= 0) break;
+            const int k1 = k0 + got;
+            const size_t wg0 = sw.size() / 4;
+            const int nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256);
+            t_sched += trace ? now() - tb : 0;
+            if ((rc = scatter_front(k0, k1))) return rc;
+            std::memcpy(hp + off_pix + (size_t)k0 * 4, sp.data() + k0, (size_t)got * 4);
+            std::memcpy(hp + off_po + (size_t)k0 * 4, so.data() + k0, (size_t)got * 4);
+            std::memcpy(hp + off_wg + wg0 * 16, sw.data() + wg0 * 4, (size_t)nwg * 16);
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix + (size_t)k0 * 4, hp + off_pix + (size_t)k0 * 4, (size_t)got * 4, hipMemcpyHostToDevice, s));
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po + (size_t)k0 * 4, hp + off_po + (size_t)k0 * 4, (size_t)got * 4, hipMemcpyHostToDevice, s));
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_wg + wg0 * 16, hp + off_wg + wg0 * 16, (size_t)nwg * 16, hipMemcpyHostToDevice, s));
+            fa.cmp_off = (const int *)(dp + off_wg) + wg0 * 4;
+            if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+            else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+            OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
+            launches++;
+        }
+        int flag = 0;
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(&flag, fa.err, sizeof(int), hipMemcpyDeviceToHost, s));
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        timed_out = flag != 0;
+        if (timed_out) ctx->ip_fallbacks++;
+    } else {
+        const double ta = trace ? now() : 0;
+        m.pix.reserve(n_holes);
+        while (march_advance(m, 1 << 30) > 0) {}
+        t_march = trace ? now() - ta : 0;
+        if ((rc = scatter_front(0, (int)m.pix.size()))) return rc;
+    }
+    const int n = (int)m.pix.size();
+    if (n > 0 && (!dataflow || timed_out)) {
+        // barrier-scheduled fill: dependency levels per component, one workgroup per component, nothing waits across
+        // workgroups (large radii; and the repeat of a dataflow fill whose poll gave up -- same arithmetic, same colours)
+        build_levels(m, false);
+        if (timed_out) pack();  // working copy back to "nothing filled yet"
+        if (m.lvl_off.size() > (size_t)n_holes + 2 || m.comp_off.size() > (size_t)n_holes + 2)
+            return ofxcv_fail(ctx, OFXCV_ERR_HIP, "inpaint: level schedule larger than its scratch");
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix, m.lvl_pix.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_wg, m.lvl_off.data(), m.lvl_off.size() * 4, hipMemcpyHostToDevice, s));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.comp_off.data(), m.comp_off.size() * 4, hipMemcpyHostToDevice, s));
+        fa.lvl_off = fa.cmp_off = (const int *)(dp + off_wg);
+        fa.err = nullptr;
+        const int nwg = (int)m.comp_off.size() - 1;
+        if (ns) hipLaunchKernelGGL((telea_fill_kernel<false, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+        else hipLaunchKernelGGL((telea_fill_kernel<false, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+        OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
+        launches++;
+    }
+    if (channels == 4)
+        hipLaunchKernelGGL(unpack_rgbx_kernel<4>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
+    else
+        hipLaunchKernelGGL(unpack_rgbx_kernel<3>, pgrid, pblock, 0, s, (const uint32_t *)work_out, (const uint32_t *)work_src, w, h, d_dst, dst_step);
+    OFXCV_LAUNCH_CHECK(ctx, "unpack_rgbx_kernel");
+    if ((rc = write_maps())) return rc;
+    if ((rc = reset_maps())) return rc;
+    OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host arrays of the march must outlive the copies
+    if (trace)
+        fprintf(stderr, "ofxcv inpaint: %d hole pixels, %d filled: set-up + ring %.2f ms, inward march %.2f ms, schedules %.2f ms, %d fill launches, total %.2f ms\n",
+                n_holes, n, t_setup - t_begin, t_march, t_sched, launches, now() - t_begin);
     return OFXCV_OK;
 }
 

@@ -7,6 +7,8 @@ import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth
 from oracle import binding as oracle
 ctx = ofxcv.Context(0)
+for kv in filter(None, os.environ.get('BENCH_CTX_OPTIONS', '').split(',')):
+    ctx.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 for (w, h) in [(640, 480), (1920, 1080)]:
     fr = synth.inpaint_frame(w, h)
     ctx.inpaint_render_host(fr)

@@ -221,3 +221,42 @@ def test_dataflow_fill_bounded_polls_fall_back_to_the_barrier_kernel(oracle, ofx
     assert np.array_equal(c.inpaint(_dev(rgb), _dev(mask), 3.0, ofxcv.INPAINT_NS).cpu().numpy(), oracle.inpaint(rgb, mask, 3.0, oracle.INPAINT_NS))
     assert c.inpaint_fallback_count() == 2
     c.close()
+
+
+def test_one_context_many_masks_and_sizes(oracle, ofxcv):
+    """the front-march state (host and device distance / order maps) persists with the context and is reset sparsely: masks of
+    every kind and frame sizes in any order on ONE context, both methods, maps and colours bit-exact each time.  Includes the
+    almost-everything-is-a-hole mask (no ring pixel exists, the reference still marches) and the pipelined fill with tiny
+    portions (several launches per call)."""
+    rng = np.random.default_rng(3)
+    ctx = ofxcv.Context(0)
+    ctx.set_option("inpaint.portion", 700)
+    for case in range(15):
+        w, h = int(rng.integers(8, 200)), int(rng.integers(8, 140))
+        if case % 4 == 3:
+            w, h = 120, 90                                            # same size again: sparse reset instead of re-initialisation
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mask = np.zeros((h, w), np.uint8)
+        kind = case % 5
+        if kind == 0:
+            mask[rng.random((h, w)) < 0.05] = 255                    # salt
+        elif kind == 1:
+            mask[h // 4:h // 2, w // 5:w - 3] = 255                  # rectangle
+            mask[0:4, 0:6] = 255                                     # touching the border
+        elif kind == 2:
+            mask[:, ::7] = 255                                       # vertical lines
+        elif kind == 3:
+            mask[:] = 255
+            mask[h // 2, w // 2] = 0                                 # almost everything is a hole
+        else:
+            yy, xx = np.mgrid[0:h, 0:w]
+            mask[(xx - w / 2) ** 2 + (yy - h / 2) ** 2 < (min(w, h) / 3) ** 2] = 255
+        radius = float(rng.choice([1, 3, 5, 7]))
+        method = case % 2
+        ref, t_ref, f_ref, o_ref = oracle.inpaint(rgb, mask, radius, method, maps=True)
+        got, t, order = ctx.inpaint(_dev(rgb), _dev(mask), radius, method, maps=True)
+        assert np.array_equal(order.cpu().numpy(), o_ref), (case, kind)
+        assert np.array_equal(t.cpu().numpy(), t_ref), (case, kind)
+        assert np.array_equal(got.cpu().numpy(), ref), (case, kind)
+    assert ctx.inpaint_fallback_count() == 0
+    ctx.close()
