@@ -299,7 +299,7 @@ def main():
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
                      "kernel": ("iterate3f_kernel<true, 8, 8> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
-                                "iterate3s_kernel<true, 8, true> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
+                                "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
                      "bytes_per_launch": iter_bytes, "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20)",
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r02_bench_pairs1_by_grid.txt)",

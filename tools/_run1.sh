@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_inpaint_gpu.py -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -3
+mkdir -p gpurun_out/refresh
+python bench.py > gpurun_out/refresh/r02_bench.json 2> gpurun_out/refresh/bench.err; head -c 200 gpurun_out/refresh/r02_bench.json
