@@ -279,6 +279,28 @@ def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
             assert (errM <= 1e-5 * np.maximum(1, np.abs(ref_M))).all(), errM.max()
 
 
+def test_opencv_order_mode_wide_dynamic_range(oracle, strict_ctx):
+    """Flat (exactly constant), barely textured (one or two gray levels) and full-contrast regions side by side: the entries
+    of M then span many orders of magnitude inside one column, the f64 column sums are no longer exact, and the strip-parallel
+    evaluation really does re-associate them -- the result must still be within tolerance of the sequential oracle at every
+    sample (in practice it stays bit-identical almost everywhere)."""
+    from openfx_opencv_amd import synth
+    w, h = 640, 480
+    a, b = synth.flow_pair(w, h, seed=21)
+    ga, gb = oracle.to_byte_grayscale(a).astype(np.int32), oracle.to_byte_grayscale(b).astype(np.int32)
+    for g in (ga, gb):
+        g[:, : w // 4] = 128                                        # flat
+        g[:, w // 4 : w // 2] = 128 + (g[:, w // 4 : w // 2] >> 7)  # one gray level of texture
+        g[: h // 3, w // 2 :] = 64 + (g[: h // 3, w // 2 :] >> 6)   # a few levels
+    ga, gb = ga.astype(np.uint8), gb.astype(np.uint8)
+    got = strict_ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+    err = np.abs(ref - got)
+    bad = err > REL_TOL * np.maximum(1, np.abs(ref))
+    print("wide dynamic range: max err %.3g, outside %d, bit-identical %.6f" % (err.max(), bad.sum(), (ref == got).mean()))
+    assert not bad.any(), "max err %g, %d samples outside" % (err.max(), bad.sum())
+
+
 def test_opencv_order_mode_other_parameters(oracle, strict_ctx):
     _strict_vs_faithful(oracle, strict_ctx, 217, 163, levels=2, iterations=4, poly_n=7, poly_sigma=1.5)
     _strict_vs_faithful(oracle, strict_ctx, 217, 163, levels=3, iterations=1)

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/refresh
-python bench.py > gpurun_out/refresh/r02_bench.json 2> gpurun_out/refresh/bench.err; head -c 200 gpurun_out/refresh/r02_bench.json
+python -m pytest tests/test_farneback_gpu.py -m gpu -q -x -s -k "wide_dynamic" 2>&1 | grep -v amdgpu.ids | tail -5
