@@ -423,6 +423,13 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
         ts.append(time.perf_counter() - t0)
     leg = {"workload": "pyramid mean-shift filtering, 3840x2160 8-bit RGB resident in HBM, sp 10, sr 20, maxLevel 2", "ms": med(ts) * 1e3,
            "Mpx_per_s": w * h / med(ts) / 1e6, "bound": "integer VALU issue (window taps), compulsory HBM traffic 6 B/px"}
+    try:  # instruction count from the committed PMC pass (tools/pmc_segment.sh) / issue capacity over the measured time
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_segment_valu.json")) as f:
+            nvalu = json.load(f)["valu_wave_instructions_per_filter_call"]
+        leg["valu_issue_frac"] = nvalu / VALU_ISSUE_PER_S / med(ts)
+        leg["valu_issue_note"] = "SQ_INSTS_VALU per filter call (offline PMC, profiles/r02_pmc_segment_valu.json) / (1024 SIMDs x 2.4 GHz / 4) / measured time"
+    except Exception:
+        pass
     if with_cpu:
         from oracle import binding as oracle
         crop = np.ascontiguousarray(fr[:540, :960])
