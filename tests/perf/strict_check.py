@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth
 from oracle import binding as oracle
