@@ -48,6 +48,15 @@ def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
     return total
 
 
+def pmc_per_pair():
+    """HBM-side bytes of one whole frame pair per window mode (offline PMC, see tools/pmc_traffic_json.py)"""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            return json.load(f).get("per_pair_traffic_bytes", {})
+    except Exception:
+        return {}
+
+
 def pmc_kernels():
     """HBM-side bytes / instruction counts per launch of the level-0 iteration kernels from the committed rocprofv3 --pmc
     passes (tools/pmc_bench.sh + tools/pmc_traffic_json.py): counters need their own profiler runs, so these figures are
@@ -323,6 +332,16 @@ def main():
                        "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS,
                        "direct_window_frac_of_hbm_peak": alg * statistics.median(drates) / world / 1e9 / HBM_PEAK_GBS},
     }
+    pp = pmc_per_pair() if (W, H) == (1920, 1080) else {}
+    if pp.get("opencv_order"):
+        # measured HBM-side traffic of a whole pair x the measured rate: how close the whole job is to the memory roofline
+        t_s, t_d = pp["opencv_order"], pp.get("direct_window")
+        line["whole_call"].update({
+            "traffic_bytes_per_pair": t_s, "traffic_source": "offline PMC, %s (per-launch bytes of every kernel x launches per pair)" % PMC_FILE,
+            "traffic_GBps": t_s * value / world / 1e9, "traffic_frac_of_hbm_peak": t_s * value / world / 1e9 / HBM_PEAK_GBS,
+            "traffic_frac_of_achievable_6300GBps": t_s * value / world / 1e9 / 6300.0,
+            "direct_window_traffic_bytes_per_pair": t_d,
+            "direct_window_traffic_frac_of_hbm_peak": (t_d * statistics.median(drates) / world / 1e9 / HBM_PEAK_GBS) if t_d else None})
     if world == 1 and not args.no_cpu_baseline:
         cb, ref_flow = cpu_farneback(g_a, g_b)
         line["cpu_baseline"] = cb

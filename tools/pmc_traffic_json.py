@@ -34,6 +34,26 @@ for (name, grid), c in rows.items():
             rd, wr = traffic(c)
             out["kernels"][tag] = {"kernel": name, "grid_threads": grid, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                    "traffic_bytes_per_launch": rd + wr, "counters_per_launch": c}
+
+# HBM-side bytes of one whole 1080p frame pair (gray LUT x2 + Farneback with levels 3, iterations 15 + flow -> RGBA) in each
+# window mode: per-launch traffic of every kernel and grid (largest grid = pyramid level 0) x its launches per pair
+def per_level(prefix):
+    grids = sorted(((g, traffic(c)) for (n, g), c in rows.items() if n.startswith(prefix) and "TCC_EA0_RDREQ_sum" in c), reverse=True)
+    return [sum(t) for g, t in grids]
+
+
+def total(spec):
+    return sum(mult * sum(per_level(prefix)) for prefix, mult in spec)
+
+
+shared = [("update_matrices_kernel", 1), ("polyexp_persistent_kernel", 2), ("pyr_", 2), ("gray_lut_kernel", 2), ("flow_to_rgba_kernel", 1)]
+out["per_pair_traffic_bytes"] = {
+    "opencv_order": total(shared + [("iterate3s_kernel<true", 14), ("iterate3s_kernel<false", 1), ("vsum_carry_kernel", 15)]),
+    "direct_window": total(shared + [("iterate3x2_kernel", 7), ("iterate3_kernel<false", 1)]),
+    "note": "sum over kernels of (bytes per launch from the PMC passes) x (launches per 1920x1080 pair: 14 updating iterations + 1 final per level "
+            "and 15 carry pre-passes in the OpenCV-order mode, 7 fused pairs + 1 final in the direct-window mode; 2 pyramid images + 2 polynomial "
+            "expansions + 1 first update per level; 2 gray LUTs, 1 flow -> RGBA)"}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
+print("per pair: OpenCV order %.0f MB, direct window %.0f MB" % (out["per_pair_traffic_bytes"]["opencv_order"] / 1e6, out["per_pair_traffic_bytes"]["direct_window"] / 1e6))
 for k, v in out["kernels"].items():
     print(k, v["kernel"], "%.1f MB" % (v["traffic_bytes_per_launch"] / 1e6))
