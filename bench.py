@@ -240,6 +240,7 @@ def main():
     el = timed_regions(ctxs, bufs, args.steps, args.warmup, max(1, args.repeats))
     pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
     rates = [pairs_per_region / e for e in el]
+    fold_mode = ctxs[0].get_option("farneback.fold_carries")
     main_s, main_n = kernel_leg(ctxs[0], bufs[0], 1)
     carry_s, carry_n = kernel_leg(ctxs[0], bufs[0], 2)
     one_in_flight = None
@@ -271,9 +272,10 @@ def main():
     value = statistics.median(rates)
     alg = algorithmic_bytes_per_pair(W, H)
     pmc = pmc_kernels() if (W, H) == (1920, 1080) else {}
-    folded = carry_n == 0
+    folded = fold_mode != 0  # level 0 runs the folded-carry iteration kernel in modes 1..3
     pm = pmc.get("opencv_order_folded_iteration_level0" if folded else "opencv_order_iteration_level0", {})
-    pc, pf = pmc.get("opencv_order_carry_level0", {}), pmc.get("direct_window_fused_pair_level0", {})
+    pc = pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
+    pf = pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes = ITER_BYTES_PER_PX * W * H
     achieved = iter_bytes / main_s / 1e9
     traffic = pm.get("traffic_bytes_per_launch")
@@ -314,15 +316,18 @@ def main():
                      "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r02_bench_pairs1_by_grid.txt)",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "bound_actual": "hbm: the kernel moves more than its algorithmic bytes (halo rows of M, R1 gather lines, 40 B of carries per "
-                                     "column and strip) at about the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
+                     "bound_actual": "hbm: the kernel moves more than its algorithmic bytes (R1 gather lines fetched once per output row they serve, "
+                                     "halo rows of M) at close to the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
                      "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) / launch time",
-                     "carry_prepass": ({"kernel": "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip; one launch per iteration; option farneback.fold_carries=0)",
-                                        "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n, "algorithmic_bytes": 20.0 * W * H + 5.0 * W * H,
-                                        "traffic": pc.get("traffic_bytes_per_launch"),
-                                        "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None}
-                                       if carry_n else "none: the carries of the f64 column sums are produced by the iteration kernel itself (folded form)"),
+                     "carry_kernel": ({"kernel": ("fold_scan_kernel (prefix of the f64 column sums over the 64-row strips from the strip sums the iteration kernel left "
+                                                  "and the six boundary rows per strip; one small launch per iteration)" if folded else
+                                                  "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip from a pass over M; one launch per iteration)"),
+                                       "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n,
+                                       "traffic": pc.get("traffic_bytes_per_launch"),
+                                       "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None}
+                                      if carry_n else "none: the last workgroup of each tile column runs the prefix inside the iteration kernel"),
+                     "fold_carries_mode": fold_mode,
                      "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
                                               "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes,
                                               "achieved": 2 * iter_bytes / fused_s / 1e9, "frac": 2 * iter_bytes / fused_s / 1e9 / HBM_PEAK_GBS,

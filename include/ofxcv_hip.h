@@ -64,13 +64,16 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "host.register"             0|1  host-image entry points address the host's own (registered) buffers (default 1) or
  *                                    always stage through the pinned ring (0);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
- *   "farneback.fold_carries" 0|1|2   OpenCV-order mode: 0 (default) the column-sum carries come from a pre-pass over M per
- *                                    iteration; 1 / 2 the iteration kernel produces the carries of its own output (prefix over
- *                                    the strips by the last workgroup of a tile column / by a small launch of its own) --
- *                                    identical results, measured slower;
+ *   "farneback.fold_carries" 0..3    OpenCV-order mode, where the carries of the f64 column sums come from: 0 a pre-pass over M
+ *                                    per iteration; 1 / 2 the iteration kernel produces the carries of its own output (prefix
+ *                                    over the strips by the last workgroup of a tile column / by a small launch of its own);
+ *                                    3 (default) = 2 on the bandwidth-bound pyramid levels, 0 on the small ones.  Identical
+ *                                    results; timings in DESIGN.md section 4;
  *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
  *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
+/* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register" */
+int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
  * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of one kernel at pyramid level 0

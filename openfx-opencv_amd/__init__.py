@@ -58,7 +58,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_host_zero_copy_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -125,6 +125,11 @@ class Context:
 
     def set_option(self, name, value):
         self._check(lib().ofxcv_ctx_set_option(self._h, name.encode(), C.c_int(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._check(lib().ofxcv_ctx_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def profile_enable(self, on=True):
         """True/1: event pairs around the dominant kernel at level 0; 2: around the carry pre-pass (OpenCV-order mode); 0: off"""

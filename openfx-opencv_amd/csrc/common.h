@@ -61,7 +61,7 @@ struct ofxcv_ctx {
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
     int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
-    int fb_fold_carries = 0;  // OpenCV-order mode: 0 (default, fastest measured) carry pre-pass over all of M per iteration; 1 carries folded into the iteration kernel,
+    int fb_fold_carries = 3;  // OpenCV-order mode: 3 (default) = 2 on the bandwidth-bound levels (8-row wavefronts), 0 elsewhere; 0 carry pre-pass over all of M per iteration; 1 carries folded into the iteration kernel,
                               // prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
     int fb_strict_variant = 0, fb_carry_groups = 0, fb_lds_pad = 0;  // A/B knobs of the strip-parallel form
     int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
@@ -144,6 +144,7 @@ static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
 int ofxcv_upload_rows(ofxcv_ctx *ctx, void *d_dst, size_t row, const void *h_src, ptrdiff_t src_row_bytes, int rows, hipStream_t s);
 int ofxcv_download_rows(ofxcv_ctx *ctx, void *h_dst, ptrdiff_t dst_row_bytes, const void *d_src, size_t row, int rows, hipStream_t s);
 
+extern "C" void ofxcv_farneback_set_fold_rows(int rows);  // process-wide A/B knob, not part of the public header
 int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation stream and the per-level events
 
 // measurement hook helpers (context.hip)

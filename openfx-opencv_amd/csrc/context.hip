@@ -224,8 +224,12 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_spin_limit = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.fold_rows")) {
+        ofxcv_farneback_set_fold_rows(value);
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.fold_carries")) {
-        ctx->fb_fold_carries = value < 0 ? 0 : (value > 2 ? 2 : value);
+        ctx->fb_fold_carries = value < 0 ? 0 : (value > 3 ? 3 : value);
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.lds_pad")) {
@@ -261,6 +265,17 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "unknown option '%s'", name);
+}
+
+int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
+    if (!ctx || !name || !value) return OFXCV_ERR_INVALID;
+    if (!std::strcmp(name, "farneback.opencv_rounding")) *value = ctx->fb_opencv_rounding;
+    else if (!std::strcmp(name, "farneback.fold_carries")) *value = ctx->fb_fold_carries;
+    else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
+    else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
+    else if (!std::strcmp(name, "host.register")) *value = ctx->host_register ? 1 : 0;
+    else return OFXCV_ERR_INVALID;
+    return OFXCV_OK;
 }
 
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable) {

@@ -1643,7 +1643,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     constexpr bool PIPE = RW < 8;  // with 8 rows per wavefront the second in-flight pixel record does not fit 128 registers
     static_assert(RW >= 3, "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
     __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
-    __shared__ float s_last[NW][3][5][64];   // the last three rows of Mout of every wavefront
+    __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
     __shared__ unsigned s_flag;
     int tbx, tby;
     xcd_tile(tbx, tby);
@@ -1689,8 +1689,8 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
         float fxv, fyv;
     };
     Px prev;
-    float mo[RW][5];   // rows of Mout as they are produced (only 0..2 and the last three finished ones stay live)
-    double I[5] = {0., 0., 0., 0., 0.};
+    float mo[RW][5];   // rows of Mout as they are produced (only the last three finished ones stay live)
+    double I[5] = {0., 0., 0., 0., 0.};  // row differences of Mout with both rows in this wavefront, ascending t
     auto finish = [&](const Px &p, int j) {
         const int y = a + j;
         M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
@@ -1701,8 +1701,10 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
                 if (fa.scan_in_kernel) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
                 else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
             }
+            if (j < 3) s_first[wave][j][c][lane] = mm.v[c];
+            // at the top of the image rows above row 0 are row 0: t = 0, 1 are (row 1 - row 0), (row 2 - row 0)
+            if (A == 0 && wave == 0 && (j == 1 || j == 2)) I[c] += (double)(mm.v[c] - mo[0][c]);
             if (j >= 3) I[c] += (double)(mm.v[c] - mo[j - 3][c]);   // t = y-1: rows y, y-3, both in this wavefront
-            if (j >= RW - 3) s_last[wave][j - (RW - 3)][c][lane] = mm.v[c];
         }
     };
 #pragma unroll
@@ -1744,21 +1746,18 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
                 if (j == nr - 1) finish(prev, j);
         }
     }
-    __syncthreads();  // every wavefront's last three rows are in LDS
-    // the three differences across the boundary to the wavefront above (t = a-1, a, a+1); at the top of the image rows above
-    // row 0 are row 0 (t = 0, 1); the ones across the strip boundary are left to fold_scan
+    __syncthreads();  // every wavefront's first three rows are in LDS
+    // the three differences across the boundary to the wavefront below (t = b-1, b, b+1 with b its first row): its rows
+    // 0..2 against this wavefront's last three; the ones across the strip boundary are left to fold_scan
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        double sum = 0.;
-        if (wave > 0) {
-            sum = (double)(mo[0][c] - s_last[wave - 1][0][c][lane]);
-            sum += (double)(mo[1][c] - s_last[wave - 1][1][c][lane]);
-            sum += (double)(mo[2][c] - s_last[wave - 1][2][c][lane]);
-        } else if (A == 0) {
-            sum = (double)(mo[1][c] - mo[0][c]);
-            sum += (double)(mo[2][c] - mo[0][c]);
+        double sum = I[c];
+        if (wave < NW - 1) {
+            sum += (double)(s_first[wave + 1][0][c][lane] - mo[RW - 3][c]);
+            sum += (double)(s_first[wave + 1][1][c][lane] - mo[RW - 2][c]);
+            sum += (double)(s_first[wave + 1][2][c][lane] - mo[RW - 1][c]);
         }
-        s_w[wave][c][lane] = sum + I[c];
+        s_w[wave][c][lane] = sum;
     }
     fold_finish<NW>(Mout, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
 }
@@ -1990,11 +1989,14 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
 struct FoldGeom {
     int rw, nw, tiles_x, nstrips;
 };
+bool fold_level_is_large(int w, int h) { return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) >= 256; }  // bandwidth-bound level
+int g_fold_rw_override = 0;  // A/B knob (option "farneback.fold_rows"): rows per wavefront on the large levels
 FoldGeom fold_geom(int w, int h) {
     FoldGeom g;
     g.tiles_x = ofxcv_div_up(w, kSsW);
     g.nw = 8;
-    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 64) >= 256 ? 8 : ((long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3);
+    g.rw = fold_level_is_large(w, h) ? 8 : ((long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3);
+    if (fold_level_is_large(w, h) && (g_fold_rw_override == 3 || g_fold_rw_override == 4)) g.rw = g_fold_rw_override;
     g.nstrips = ofxcv_div_up(h, g.rw * g.nw);
     return g;
 }
@@ -2078,6 +2080,8 @@ int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 extern "C" {
 
 int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
+
+void ofxcv_farneback_set_fold_rows(int rows) { g_fold_rw_override = rows; }  // internal A/B hook (context option "farneback.fold_rows")
 
 int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels) {
     return num_levels(width, height, pyr_scale, levels);
@@ -2215,7 +2219,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
-        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && !ctx->fb_strict_rows;
+        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && !ctx->fb_strict_rows &&
+                          (ctx->fb_fold_carries != 3 || fold_level_is_large(w, h));  // 3: only the levels that are bandwidth-bound
         FoldScratch fs = {};
         if (fold) {
             fs = fold_scratch(ctx, width, height);

@@ -244,15 +244,16 @@ def test_opencv_order_mode_strip_heights_and_serial_scan_agree(oracle, ofxcv, ro
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("w,h", [(125, 70), (333, 257), (640, 480)])
+@pytest.mark.parametrize("w,h", [(125, 70), (333, 257), (640, 480), (1920, 1080)])
 def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
     """the carries of the f64 column sums from a pre-pass over M (default) or produced by the iteration kernel itself
     (farneback.fold_carries 1: prefix over the strips by the last workgroup of a tile column, an atomic counter, device-scope
-    loads; 2: by a small launch of its own): the same flow, within tolerance of the faithful oracle at every sample"""
+    loads; 2: by a small launch of its own; 3, the default: 2 on the large pyramid levels, the pre-pass on the small ones):
+    the same flow, within tolerance of the faithful oracle at every sample"""
     ga, gb = _gray_pair(oracle, w, h)
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
     outs = []
-    for fold in (0, 1, 2):
+    for fold in (0, 1, 2, 3):
         ctx = ofxcv.Context(0)
         ctx.set_option("farneback.fold_carries", fold)
         for _ in range(2):   # twice: the tile-column counters must be back at zero after a call
@@ -260,7 +261,7 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
         ctx.close()
         assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), fold
         outs.append(got)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
 
 
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):

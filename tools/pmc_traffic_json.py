@@ -23,7 +23,7 @@ def traffic(c):
 
 out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --steps 2); per-launch averages per kernel and grid",
        "kernels": {}}
-want = {"iterate3f_kernel<true, 8, 8>": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0",
+want = {"iterate3f_kernel<true, 8, 8>": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
         "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
 for (name, grid), c in rows.items():
     for k, tag in want.items():
@@ -48,7 +48,9 @@ def total(spec):
 
 shared = [("update_matrices_kernel", 1), ("polyexp_persistent_kernel", 2), ("pyr_", 2), ("gray_lut_kernel", 2), ("flow_to_rgba_kernel", 1)]
 out["per_pair_traffic_bytes"] = {
-    "opencv_order": total(shared + [("iterate3s_kernel<true", 14), ("iterate3s_kernel<false", 1), ("vsum_carry_kernel", 15)]),
+    # every iteration / carry kernel of the mode as it ran (folded-carry kernels on the large levels, pre-pass form on the small ones)
+    "opencv_order": total(shared + [("iterate3s_kernel<true", 14), ("iterate3s_kernel<false", 1), ("vsum_carry_kernel", 15), ("iterate3f_kernel<true", 14),
+                                    ("iterate3f_kernel<false", 1), ("fold_scan_kernel", 15), ("vsum_seed_kernel", 1)]),
     "direct_window": total(shared + [("iterate3x2_kernel", 7), ("iterate3_kernel<false", 1)]),
     "note": "sum over kernels of (bytes per launch from the PMC passes) x (launches per 1920x1080 pair: 14 updating iterations + 1 final per level "
             "and 15 carry pre-passes in the OpenCV-order mode, 7 fused pairs + 1 final in the direct-window mode; 2 pyramid images + 2 polynomial "
