@@ -192,16 +192,7 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     // than the ring's flow download + host scatter.
     if (cm.k[0] < 0 || cm.k[1] < 0 || cm.k[2] < 0 || cm.k[3] < 0 || dst_row_bytes < (ptrdiff_t)drow || ((uintptr_t)h_dst & 15) || (dst_row_bytes & 15))
         return kNotRegistered;
-    HostRegistrations regs;
-    for (int f = 0; f < nf; f++)
-        if (!regs.add(src[f], (size_t)(height - 1) * src_rb[f] + row)) return kNotRegistered;
-    if (!regs.add(h_dst, (size_t)(height - 1) * dst_row_bytes + drow)) return kNotRegistered;
-    void *d_dst = nullptr;
-    if (hipHostGetDevicePointer(&d_dst, h_dst, 0) != hipSuccess || !d_dst) {
-        (void)hipGetLastError();
-        return kNotRegistered;
-    }
-
+    HostRegistrations regs;  // unregisters when the call returns; every return below happens with nothing in flight
     const size_t frame = align_up(row * height, 256), gray_pitch = align_up((size_t)width, 256), gray = gray_pitch * height,
                  flow_bytes = align_up((size_t)width * height * 8, 256);
     int rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes);
@@ -213,8 +204,14 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     for (int k = 0; k < n_other; k++) d_flow[k] = (float *)(dp + nf * (frame + gray) + k * flow_bytes);
 
     // uploads straight from the host's buffers on the copy stream; the compute stream converts frame f as soon as it has
-    // arrived, so the next frame is on the wire meanwhile
+    // arrived, so the next frame is on the wire meanwhile.  A frame is registered right before its upload is issued, so the
+    // registration of frame f+1 (0.2 ms of host time) overlaps the DMA of frame f; the destination is registered last,
+    // while the GPU computes.
     for (int f = 0; f < nf; f++) {
+        if (!regs.add(src[f], (size_t)(height - 1) * src_rb[f] + row)) {
+            (void)hipStreamSynchronize(ctx->copy);
+            return kNotRegistered;
+        }
         if ((size_t)src_rb[f] == row)  // contiguous rows: one linear DMA
             OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + f * frame, src[f], row * height, hipMemcpyHostToDevice, ctx->copy));
         else
@@ -259,6 +256,12 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
             OFXCV_HIP_CHECK(ctx, hipEventRecord(fc->ev_done, fc->compute));
             OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, fc->ev_done, 0));
         }
+    }
+    void *d_dst = nullptr;
+    if (!regs.add(h_dst, (size_t)(height - 1) * dst_row_bytes + drow) || hipHostGetDevicePointer(&d_dst, h_dst, 0) != hipSuccess || !d_dst) {
+        (void)hipGetLastError();
+        sync_all();
+        return kNotRegistered;  // the destination cannot be addressed by the kernel: the ring path serves the call
     }
     hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
                        (const float2 *)d_flow[1], width, height, (float *)d_dst, dst_row_bytes, cm, render_scale_x, render_scale_y);
