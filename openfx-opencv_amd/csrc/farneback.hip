@@ -1591,12 +1591,72 @@ __device__ __forceinline__ void fold_finish(const float *__restrict__ M, const F
     if (threadIdx.x == 0) __hip_atomic_store(fa.counters + tbx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the prefix over the strips as its own (small) launch: one workgroup per tile column, one wavefront per channel
-__global__ __launch_bounds__(320) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int xr = blockIdx.x * kSsW - 1 + lane;
+// The prefix over the strips as its own (small) launch: one workgroup per tile column and channel, kScanQ wavefronts that
+// each take a portion of the strip boundaries (one workgroup for all five channels is bound by the L1 of its one CU).  A wavefront loads the boundary rows and strip sums of its portion (all loads in
+// flight at once), adds them up in ascending row order, the portion totals meet in LDS, and each wavefront then writes the
+// carries of its portion.  (With one wavefront per channel walking all boundaries in batches the launch took 9.9 us at
+// 1080p -- five dependent batches -- which is on the critical path when one pair is in flight.)
+constexpr int kScanQ = 4, kScanB = 9;  // portions per channel; boundaries per batch of loads
+__global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa) {
+    __shared__ double s_tot[kScanQ][64];
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = blockIdx.y;
+    const int xr = blockIdx.x * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    fold_scan<5, false>(M, fa, sh, xr, w, h, pitch, wave, own);
+    const size_t plane = (size_t)pitch * h;
+    const float *m = M + c * plane + x;
+    const size_t kst = (size_t)5 * pitch, kof = (size_t)c * pitch + x;
+    const int nb = fa.nstrips - 1, per = (nb + kScanQ - 1) / kScanQ;  // boundaries s = 1 .. nstrips-1
+    const int s_lo = 1 + q * per, s_hi = min(s_lo + per, fa.nstrips);
+    // pass 1: total of the portion (strip sums + the three boundary differences each)
+    double tot = 0.;
+    for (int s0 = s_lo; s0 < s_hi; s0 += kScanB) {
+        float r[kScanB][6];
+        double sp[kScanB];
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s0 + i < s_hi) {
+                const int A = (s0 + i) * sh;
+#pragma unroll
+                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
+                sp[i] = fa.Spart[(size_t)(s0 + i - 1) * kst + kof];
+            }
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s0 + i < s_hi) {
+                tot += sp[i];
+                tot += (double)(r[i][3] - r[i][0]);
+                tot += (double)(r[i][4] - r[i][1]);
+                tot += (double)(r[i][5] - r[i][2]);
+            }
+    }
+    s_tot[q][lane] = tot;
+    __syncthreads();
+    double run = (double)(m[0] * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
+    if (q == 0 && own) fa.Kout[kof] = run;
+    for (int u = 0; u < q; u++) run += s_tot[u][lane];
+    // pass 2: the carries of the portion (the same loads again: they hit in the cache)
+    for (int s0 = s_lo; s0 < s_hi; s0 += kScanB) {
+        float r[kScanB][6];
+        double sp[kScanB];
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s0 + i < s_hi) {
+                const int A = (s0 + i) * sh;
+#pragma unroll
+                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
+                sp[i] = fa.Spart[(size_t)(s0 + i - 1) * kst + kof];
+            }
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s0 + i < s_hi) {
+                run += sp[i];                          // differences inside strip s-1
+                run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
+                if (own) fa.Kout[(size_t)(s0 + i) * kst + kof] = run;
+                run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
+                run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
+            }
+    }
 }
 
 // carries of a field that already lies in memory (the first M of a pyramid level)
@@ -1995,8 +2055,9 @@ FoldGeom fold_geom(int w, int h) {
     FoldGeom g;
     g.tiles_x = ofxcv_div_up(w, kSsW);
     g.nw = 8;
-    g.rw = fold_level_is_large(w, h) ? 8 : ((long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3);
-    if (fold_level_is_large(w, h) && (g_fold_rw_override == 3 || g_fold_rw_override == 4)) g.rw = g_fold_rw_override;
+    // 4 rows per wavefront: 7 rows of M in registers leave room for the pipelined gather (8 rows: 918 -> 900 pairs/s at 1080p)
+    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3;
+    if (fold_level_is_large(w, h) && (g_fold_rw_override == 3 || g_fold_rw_override == 8)) g.rw = g_fold_rw_override;
     g.nstrips = ofxcv_div_up(h, g.rw * g.nw);
     return g;
 }
@@ -2026,7 +2087,7 @@ int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
     else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
     OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
     if (!fa.scan_in_kernel) {
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x), dim3(320), 0, s, M, w, h, pitch, g.rw * g.nw, fa);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.rw * g.nw, fa);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
     }
     return OFXCV_OK;
@@ -2056,7 +2117,7 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     if (update && !fa.scan_in_kernel) {
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x), dim3(320), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     }
