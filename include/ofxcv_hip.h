@@ -69,6 +69,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    over the strips by the last workgroup of a tile column / by a small launch of its own);
  *                                    3 (default) = 2 on the bandwidth-bound pyramid levels, 0 on the small ones.  Identical
  *                                    results; timings in DESIGN.md section 4;
+ *   "farneback.fold_rows" 3|8 / >=16 A/B: rows per wavefront of the folded kernel on the large levels (default 4) / number of
+ *                                    62x64-pixel tiles from which a level counts as large (default 256); process-wide;
  *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
  *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);

@@ -2049,7 +2049,8 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
 struct FoldGeom {
     int rw, nw, tiles_x, nstrips;
 };
-bool fold_level_is_large(int w, int h) { return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) >= 256; }  // bandwidth-bound level
+int g_fold_min_tiles = 256;  // A/B knob (option "farneback.fold_min"): 62x64-pixel tiles from which a level counts as large
+bool fold_level_is_large(int w, int h) { return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) >= g_fold_min_tiles; }  // bandwidth-bound level
 int g_fold_rw_override = 0;  // A/B knob (option "farneback.fold_rows"): rows per wavefront on the large levels
 FoldGeom fold_geom(int w, int h) {
     FoldGeom g;
@@ -2142,7 +2143,10 @@ extern "C" {
 
 int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
 
-void ofxcv_farneback_set_fold_rows(int rows) { g_fold_rw_override = rows; }  // internal A/B hook (context option "farneback.fold_rows")
+void ofxcv_farneback_set_fold_rows(int rows) {
+    if (rows >= 16) g_fold_min_tiles = rows;  // values from 16 on set the size threshold instead
+    else g_fold_rw_override = rows;
+}  // internal A/B hook (context option "farneback.fold_rows")
 
 int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels) {
     return num_levels(width, height, pyr_scale, levels);
