@@ -125,12 +125,15 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
     return stream ? reinterpret_cast<hipStream_t>(stream) : ctx->compute;
 }
 
-// Process-wide reader/writer lock for the HIP runtime operations that are not safe against each other across host
-// threads on ROCm 7.2.  EXCLUSIVE: stream capture + graph instantiation, device allocations / frees / host registration,
-// graph-exec destruction and context teardown (a capture in flight was seen to be invalidated by an allocation, and
+// Process-wide lock for the HIP runtime operations that are not safe against each other across host threads on ROCm 7.2:
+// stream capture + graph instantiation, stream creation, device allocations / frees / host registration, graph-exec
+// destruction, context teardown AND hipGraphLaunch.  History: a capture in flight was invalidated by another thread's allocation (round 1);
 // hipGraphExecDestroy tears down the exec's internal streams while another thread's hipGraphLaunch walks the runtime's
-// stream list -- a segfault in hip::Graph::UpdateStreams, caught once in ~10 runs of four concurrent render threads).
-// SHARED: hipGraphLaunch (launches of different threads stay concurrent with each other).
+// stream list (segfault in hip::Graph::UpdateStreams, about 1 in 10 runs of four concurrent render threads); and two
+// threads inside hipGraphLaunch at the same time crash in the same function (1 in 30 runs), as does a launch racing a
+// stream creation (4 in 150).  Kernel launches, copies and
+// synchronisation stay concurrent; a graph launch costs the host 0.4 ms, far below the GPU time of the call it starts.
+// (A shared_mutex because readers may come back if a later runtime makes concurrent launches safe.)
 std::shared_mutex &ofxcv_capture_mutex();
 // Waits for everything this context has in flight (its own streams and the last caller-supplied one); never a
 // device-wide synchronisation, which would stall -- and invalidate the captures of -- other contexts' threads.

@@ -89,6 +89,7 @@ int ofxcv_prof_drain(ofxcv_ctx *ctx) {
 
 int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     if (ctx->prep) return OFXCV_OK;
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());  // stream creation: see ofxcv_ctx_create
     OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
     OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -131,6 +132,8 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     }
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
+        // stream creation changes the runtime's stream list, which another thread's hipGraphLaunch walks: under the runtime lock
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
         OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
         OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));

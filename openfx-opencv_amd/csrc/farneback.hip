@@ -2429,7 +2429,10 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         g = slot;
     }
     {
-        std::shared_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex());
+        // exclusive as well: two threads inside hipGraphLaunch at once (different graph execs, different streams) crashed in
+        // hip::Graph::UpdateStreams on ROCm 7.2 -- about 1 in 30 runs of four concurrent render threads, backtrace under
+        // rocgdb with every other locked operation parked on this lock
+        std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex());
         OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
     }
     return OFXCV_OK;
