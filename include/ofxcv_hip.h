@@ -49,7 +49,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.opencv_rounding" 1|0|2 how the 3x3 box window of FarnebackUpdateFlow_Blur is evaluated.
  *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical
  *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel (a
- *                                      carry pre-pass + a row-walking kernel per iteration).  Reproduces the reference's
+ *                                      row-walking kernel per iteration + a small kernel for the carries of the column sums,
+ *                                      see "farneback.fold_carries").  Reproduces the reference's
  *                                      rounding noise: every sample within 1e-4 (relative) of the CPU result.
  *                                    0: direct sums (each window summed on its own in f64, two iterations fused per launch):
  *                                      ~1.8x faster, but at ill-conditioned pixels (6e-5 of the samples at 1920x1080,
@@ -61,8 +62,11 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
  *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
- *   "host.register"             0|1  host-image entry points address the host's own (registered) buffers (default 1) or
- *                                    always stage through the pinned ring (0);
+ *   "host.register"             0|1  ofxcv_vectorgen_flows_host registers the host's own buffers for the call when it can (all four
+ *                                    channels mapped, top-down images, no other host call in flight; default 1) or always stages
+ *                                    through the pinned ring (0);
+ *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n   A/B: fill-order pixels per portion of the pipelined fill (8192) and
+ *                                    per workgroup of a component (256);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
  *   "farneback.fold_carries" 0..3    OpenCV-order mode, where the carries of the f64 column sums come from: 0 a pre-pass over M
  *                                    per iteration; 1 / 2 the iteration kernel produces the carries of its own output (prefix
@@ -71,8 +75,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    results; timings in DESIGN.md section 4;
  *   "farneback.fold_rows" 3|8 / >=16 A/B: rows per wavefront of the folded kernel on the large levels (default 4) / number of
  *                                    62x64-pixel tiles from which a level counts as large (default 256); process-wide;
- *   "farneback.strict_rows" 0|2|4|8, "farneback.strict_variant", "farneback.carry_groups": A/B knobs of the
- *                                    OpenCV-order kernels (rows per wavefront, unpipelined gather, carry groups). */
+ *   "farneback.strict_rows" 0|2|4|8|16, "farneback.strict_variant" (1 unpipelined gather, 2 rows in pairs), "farneback.carry_groups",
+ *   "farneback.lds_pad" bytes: A/B knobs of the pre-pass form of the OpenCV-order kernels. */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
 /* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register" */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
@@ -80,9 +84,10 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
  * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of one kernel at pyramid level 0
  * with a hipEvent pair on the stream it is launched on.  enable = 1: the dominant kernel (OpenCV-order mode: the
- * blur+solve+update kernel of one iteration, iterate3s_kernel; direct-window mode: the fused two-iteration
- * kernel, iterate3x2_kernel); enable = 2: the carry pre-pass of the OpenCV-order mode (vsum_carry_kernel).  ofxcv_profile_read synchronises, adds up the pairs and returns the total
- * kernel time and the number of launches since the last reset. */
+ * blur+solve+update kernel of one iteration, iterate3f_kernel / iterate3s_kernel; direct-window mode: the fused
+ * two-iteration kernel, iterate3x2_kernel); enable = 2: the carry kernel of the OpenCV-order mode (fold_scan_kernel /
+ * vsum_carry_kernel).  ofxcv_profile_read synchronises, adds up the pairs and returns the total kernel time and the
+ * number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
 int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);
 
