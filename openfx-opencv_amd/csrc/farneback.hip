@@ -2051,11 +2051,12 @@ struct FoldGeom {
 };
 int g_fold_min_tiles = 256;  // A/B knob (option "farneback.fold_min"): 62x64-pixel tiles from which a level counts as large
 bool fold_level_is_large(int w, int h) { return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) >= g_fold_min_tiles; }  // bandwidth-bound level
-int g_fold_rw_override = 0;  // A/B knob (option "farneback.fold_rows"): rows per wavefront on the large levels
+int g_fold_rw_override = 0;
+bool g_fold_nw4 = false;  // A/B: 4-wavefront workgroups on the large levels too  // A/B knob (option "farneback.fold_rows"): rows per wavefront on the large levels
 FoldGeom fold_geom(int w, int h) {
     FoldGeom g;
     g.tiles_x = ofxcv_div_up(w, kSsW);
-    g.nw = 8;
+    g.nw = (fold_level_is_large(w, h) && !g_fold_nw4) ? 8 : 4;  // 4 wavefronts per workgroup where 8 would leave CUs without a second workgroup
     // 4 rows per wavefront: 7 rows of M in registers leave room for the pipelined gather (8 rows: 918 -> 900 pairs/s at 1080p)
     g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3;
     if (fold_level_is_large(w, h) && (g_fold_rw_override == 3 || g_fold_rw_override == 8)) g.rw = g_fold_rw_override;
@@ -2068,7 +2069,7 @@ struct FoldScratch {  // carved from ctx->fb_vsum by the caller
 };
 FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0) {  // sized for the level-0 geometry (the largest)
     const FoldGeom g = fold_geom(w0, h0);
-    const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 8) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 24 rows)
+    const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 4) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 12 rows)
     (void)g;
     FoldScratch fs;
     double *base = (double *)ctx->fb_vsum.ptr;
@@ -2083,9 +2084,14 @@ int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
     FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1};
     dim3 grid(g.tiles_x, g.nstrips);
     const int pitch = plane_pitch(w);
-    if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
-    else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
-    else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+    if (g.nw == 8) {
+        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+    } else {
+        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa);
+    }
     OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
     if (!fa.scan_in_kernel) {
         hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.rw * g.nw, fa);
@@ -2103,16 +2109,21 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     int rc;
     const int mark = ctx->prof_now ? ctx->prof_on : 0;
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-#define OFXCV_LAUNCH_FOLD(RW)                                                                                                            \
+#define OFXCV_LAUNCH_FOLD(RW, NW)                                                                                                        \
     do {                                                                                                                                 \
         if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3f_kernel<true, RW, 8>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3f_kernel<false, RW, 8>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
     } while (0)
-    if (g.rw == 8) OFXCV_LAUNCH_FOLD(8);
-    else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4);
-    else OFXCV_LAUNCH_FOLD(3);
+    if (g.nw == 8) {
+        if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8);
+        else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 8);
+        else OFXCV_LAUNCH_FOLD(3, 8);
+    } else {
+        if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 4);
+        else OFXCV_LAUNCH_FOLD(3, 4);
+    }
 #undef OFXCV_LAUNCH_FOLD
     OFXCV_LAUNCH_CHECK(ctx, "iterate3f_kernel");
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
@@ -2144,7 +2155,8 @@ extern "C" {
 int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
 
 void ofxcv_farneback_set_fold_rows(int rows) {
-    if (rows >= 16) g_fold_min_tiles = rows;  // values from 16 on set the size threshold instead
+    if (rows == 14) g_fold_nw4 = true;
+    else if (rows >= 16) g_fold_min_tiles = rows;  // values from 16 on set the size threshold instead
     else g_fold_rw_override = rows;
 }  // internal A/B hook (context option "farneback.fold_rows")
 
