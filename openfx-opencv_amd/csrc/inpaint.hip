@@ -96,24 +96,28 @@ struct FrontQueue {
     }
 };
 
-inline float eikonal(int i1, int j1, int i2, int j2, const uint8_t *f, const float *t, int ec) {
-    double a11 = t[i1 * ec + j1], a22 = t[i2 * ec + j2], m12 = std::min(a11, a22), sol;
-    if (f[i1 * ec + j1] != INSIDE) {
-        if (f[i2 * ec + j2] != INSIDE) {
-            if (std::fabs(a11 - a22) >= 1.0) sol = 1 + m12;
-            else sol = (a11 + a22 + std::sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
-        } else
-            sol = 1 + a11;
-    } else if (f[i2 * ec + j2] != INSIDE)
-        sol = 1 + a22;
-    else
-        sol = 1 + m12;
-    return (float)sol;
-}
+// photo/src/inpaint.cpp FastMarching_solve for the four quadrants (up|down x left|right) and their minimum; the four
+// neighbours are loaded once
 inline float front_value(int i, int j, const uint8_t *f, const float *t, int ec) {
-    float a = eikonal(i - 1, j, i, j - 1, f, t, ec), b = eikonal(i + 1, j, i, j - 1, f, t, ec);
-    float c = eikonal(i - 1, j, i, j + 1, f, t, ec), d = eikonal(i + 1, j, i, j + 1, f, t, ec);
-    return std::min(std::min(a, b), std::min(c, d));
+    const int c = i * ec + j;
+    const double tu = t[c - ec], td = t[c + ec], tl = t[c - 1], tr = t[c + 1];
+    const bool ku = f[c - ec] != INSIDE, kd = f[c + ec] != INSIDE, kl = f[c - 1] != INSIDE, kr = f[c + 1] != INSIDE;
+    auto solve = [](double a11, bool k1, double a22, bool k2) -> float {
+        double sol;
+        if (k1) {
+            if (k2) {
+                if (std::fabs(a11 - a22) >= 1.0) sol = 1 + std::min(a11, a22);
+                else sol = (a11 + a22 + std::sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
+            } else
+                sol = 1 + a11;
+        } else if (k2)
+            sol = 1 + a22;
+        else
+            sol = 1 + std::min(a11, a22);
+        return (float)sol;
+    };
+    const float a = solve(tu, ku, tl, kl), b = solve(td, kd, tl, kl), cc = solve(tu, ku, tr, kr), d = solve(td, kd, tr, kr);
+    return std::min(std::min(a, b), std::min(cc, d));
 }
 
 void dilate_host(const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, int rows, int cols, int r, bool cross) {
