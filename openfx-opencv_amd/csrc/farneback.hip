@@ -2296,7 +2296,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
-        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && !ctx->fb_strict_rows &&
+        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries &&
                           (ctx->fb_fold_carries != 3 || fold_level_is_large(w, h));  // 3: only the levels that are bandwidth-bound
         FoldScratch fs = {};
         if (fold) {
