@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak (6.29 TB/s meas
 VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4.0  # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 # one iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
 ITER_BYTES_PER_PX = 80.0
-PMC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
@@ -134,7 +134,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pairs", type=int, default=3, help="independent frame pairs per step, each on its own context/stream")
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs per batched Farneback call (ofxcv_calc_optical_flow_farneback_batch)")
+    ap.add_argument("--streams", type=int, default=2, help="batched calls in flight per GPU, each on its own context/stream; "
+                    "pairs per step per GPU = batch x streams")
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
@@ -170,7 +172,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    P = max(1, args.pairs)
+    B, S = max(1, args.batch), max(1, args.streams)
+    P = B * S
     extra_opts = [kv.split("=") for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(","))]  # A/B of kernel variants
 
     def make_ctxs(n, direct):
@@ -181,27 +184,36 @@ def main():
                 c.set_option(k, int(v))
         return cs
 
-    def make_bufs(cs, w, h):
+    def make_bufs(cs, w, h, nb=None):
+        """per context: `nb` independent frame pairs (different seeds), resident in HBM"""
+        nb = nb or B
+        mine = sharding.pairs_for_rank(world * len(cs) * nb, rank, world)
         bufs = []
         for i, c in enumerate(cs):
-            a, b = synth.flow_pair(w, h, seed=sharding.seed_for_pair(sharding.pairs_for_rank(world * len(cs), rank, world)[i]))
             with torch.cuda.stream(c.stream):
-                bufs.append(dict(a=torch.from_numpy(a).cuda(), b=torch.from_numpy(b).cuda(),
-                                 ga=torch.empty((h, w), dtype=torch.uint8, device="cuda"),
-                                 gb=torch.empty((h, w), dtype=torch.uint8, device="cuda"),
-                                 flow=torch.empty((h, w, 2), dtype=torch.float32, device="cuda"),
-                                 out=torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")))
+                t = dict(a=[], b=[], ga=[], gb=[], flow=[], out=[])
+                for j in range(nb):
+                    a, b = synth.flow_pair(w, h, seed=sharding.seed_for_pair(mine[i * nb + j]))
+                    t["a"].append(torch.from_numpy(a).cuda())
+                    t["b"].append(torch.from_numpy(b).cuda())
+                    t["ga"].append(torch.empty((h, w), dtype=torch.uint8, device="cuda"))
+                    t["gb"].append(torch.empty((h, w), dtype=torch.uint8, device="cuda"))
+                    t["flow"].append(torch.empty((h, w, 2), dtype=torch.float32, device="cuda"))
+                    t["out"].append(torch.zeros((h, w, 4), dtype=torch.float32, device="cuda"))
+                bufs.append(t)
         return bufs
 
     def step(cs, bufs):
-        # one batch of independent frame pairs, each on its own context (own HIP stream and scratch): frame pairs never
-        # exchange data, so they shard across streams exactly as they shard across GPUs
+        # independent frame pairs: every context (own HIP stream and scratch) takes a batch of them through ONE batched
+        # Farneback call; frame pairs never exchange data, so they shard across batches and streams exactly as across GPUs
         for c, t in zip(cs, bufs):
             with torch.cuda.stream(c.stream):
-                c.to_byte_grayscale(t["a"], t["ga"])
-                c.to_byte_grayscale(t["b"], t["gb"])
-                c.calc_optical_flow_farneback(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
-                c.flow_to_rgba(t["flow"], t["out"], 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
+                for a, b, ga, gb in zip(t["a"], t["b"], t["ga"], t["gb"]):
+                    c.to_byte_grayscale(a, ga)
+                    c.to_byte_grayscale(b, gb)
+                c.calc_optical_flow_farneback_batch(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+                for fl, o in zip(t["flow"], t["out"]):
+                    c.flow_to_rgba(fl, o, 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
 
     def timed_regions(cs, bufs, steps, warmup, repeats):
         """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; elapsed = max over ranks"""
@@ -224,18 +236,19 @@ def main():
         return out
 
     def kernel_leg(c, t, which):
-        """HIP event pairs around every level-0 launch of one kernel, on the stream it is launched on, one pair in flight"""
+        """HIP event pairs around every level-0 launch of one kernel, on the stream it is launched on, one batched call in
+        flight (a launch carries the whole batch: its algorithmic bytes are those of len(t["ga"]) pairs)"""
         c.profile_enable(which)
         with torch.cuda.stream(c.stream):
             for _ in range(max(3, min(10, args.steps))):
-                c.calc_optical_flow_farneback(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+                c.calc_optical_flow_farneback_batch(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
         torch.cuda.synchronize()
         ms, n = c.profile_read()
         c.profile_enable(0)
         return (ms / 1e3 / max(1, n)), n
 
     # ---- headline: default mode (OpenCV-order window) ----
-    ctxs = make_ctxs(P, direct=False)
+    ctxs = make_ctxs(S, direct=False)
     bufs = make_bufs(ctxs, W, H)
     el = timed_regions(ctxs, bufs, args.steps, args.warmup, max(1, args.repeats))
     pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
@@ -243,23 +256,28 @@ def main():
     fold_mode = ctxs[0].get_option("farneback.fold_carries")
     main_s, main_n = kernel_leg(ctxs[0], bufs[0], 1)
     carry_s, carry_n = kernel_leg(ctxs[0], bufs[0], 2)
-    one_in_flight = None
+    one_in_flight = one_batch_in_flight = None
     if world == 1:
-        e1 = timed_regions(ctxs[:1], bufs[:1], max(10, args.steps // 2), 3, 3)
-        one_in_flight = max(10, args.steps // 2) / statistics.median(e1)
-    strict_flow = bufs[0]["flow"].cpu().numpy()
-    g_a, g_b = bufs[0]["ga"].cpu().numpy(), bufs[0]["gb"].cpu().numpy()
+        n1 = max(10, args.steps // 2)
+        e1 = timed_regions(ctxs[:1], bufs[:1], n1, 3, 3)
+        one_batch_in_flight = n1 * B / statistics.median(e1)
+        one = [{k: v[:1] for k, v in bufs[0].items()}]  # a single pair per call on one stream: what one unbatched caller gets
+        e1 = timed_regions(ctxs[:1], one, n1, 3, 3)
+        one_in_flight = n1 / statistics.median(e1)
+    strict_flow = bufs[0]["flow"][0].cpu().numpy()
+    g_a, g_b = bufs[0]["ga"][0].cpu().numpy(), bufs[0]["gb"][0].cpu().numpy()
     for c in ctxs:
         c.close()
     del bufs
 
     # ---- the opt-in direct-window mode, same workload ----
-    dctxs = make_ctxs(P, direct=True)
-    dbufs = make_bufs(dctxs, W, H)
+    # (its kernels take one pair per launch: P single-pair contexts in flight, as in rounds 1 and 2)
+    dctxs = make_ctxs(min(P, 4), direct=True)
+    dbufs = make_bufs(dctxs, W, H, 1)
     del_ = timed_regions(dctxs, dbufs, args.steps, args.warmup, max(1, min(5, args.repeats)))
-    drates = [pairs_per_region / e for e in del_]
+    drates = [sharding.reduce_count_sum(args.steps * len(dctxs), dist, red_dev) / e for e in del_]
     fused_s, fused_n = kernel_leg(dctxs[0], dbufs[0], 1)
-    direct_flow = dbufs[0]["flow"].cpu().numpy()
+    direct_flow = dbufs[0]["flow"][0].cpu().numpy()
     for c in dctxs:
         c.close()
     del dbufs
@@ -276,7 +294,8 @@ def main():
     pm = pmc.get("opencv_order_folded_iteration_level0" if folded else "opencv_order_iteration_level0", {})
     pc = pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
     pf = pmc.get("direct_window_fused_pair_level0", {})
-    iter_bytes = ITER_BYTES_PER_PX * W * H
+    iter_bytes_pair = ITER_BYTES_PER_PX * W * H
+    iter_bytes = iter_bytes_pair * B  # one launch of the dominant kernel carries the whole batch
     achieved = iter_bytes / main_s / 1e9
     traffic = pm.get("traffic_bytes_per_launch")
     valu = pm.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
@@ -297,12 +316,13 @@ def main():
                                "-> 8-bit sRGB gray -> calcOpticalFlowFarneback -> flow RGBA (BASELINE.json configs[%d])"
                                % (W, H, 4 if (W, H) == (3840, 2160) else 2),
                    "levels": LEVELS, "iterations": ITERS, "poly_n": POLY_N, "poly_sigma": POLY_SIGMA, "winsize": WINSIZE,
-                   "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "streams_per_gpu": P,
+                   "pyr_scale": PYR_SCALE, "pairs_per_step_per_gpu": P, "pairs_per_batched_call": B, "streams_per_gpu": S,
                    "box_window": "OpenCV order (library default): running f64 column sums of f32-rounded row differences, strip-parallel",
                    "parallelism": "independent frame pairs per GPU, no collective"},
         "value_stats": dict(stats(rates), note="each repeat = one timed region of `steps` steps bracketed by barrier + synchronize; value = median"),
         "value_opencv_order": value,  # the timed mode IS the OpenCV-order mode (library default); kept as an explicit key
-        "value_one_pair_in_flight": one_in_flight,
+        "value_one_pair_in_flight": one_in_flight,      # one unbatched call at a time (a single OFX render thread, one direction)
+        "value_one_batch_in_flight": one_batch_in_flight,  # one batched call of `pairs_per_batched_call` pairs at a time
         "value_direct_window": statistics.median(drates),
         "value_direct_window_stats": dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
                                           "fused per launch; does NOT meet 1e-4 at every sample (see parity)"),
@@ -312,11 +332,14 @@ def main():
                      "kernel": ("iterate3f_kernel<true, 4, 8> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
                                 "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
-                     "bytes_per_launch": iter_bytes, "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20)",
+                     "bytes_per_launch": iter_bytes, "pairs_per_launch": B,
+                     "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20) x %d x %d px x %d pairs "
+                                              "per launch (grid z = pair)" % (W, H, B),
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
-                     "timing": "HIP event pairs on the launch stream, one frame pair in flight (compare profiles/r02_bench_pairs1_by_grid.txt)",
+                     "timing": "HIP event pairs on the launch stream, one batched call in flight (compare profiles/r03_bench_streams1_by_grid.txt)",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "traffic_note": "per launch of the batched kernel (PMC passes run the bench workload)",
                      "bound_actual": "hbm: the kernel moves more than its algorithmic bytes (R1 gather lines fetched once per output row they serve, "
                                      "halo rows of M) at close to the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
@@ -330,8 +353,8 @@ def main():
                                       if carry_n else "none: the last workgroup of each tile column runs the prefix inside the iteration kernel"),
                      "fold_carries_mode": fold_mode,
                      "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
-                                              "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes,
-                                              "achieved": 2 * iter_bytes / fused_s / 1e9, "frac": 2 * iter_bytes / fused_s / 1e9 / HBM_PEAK_GBS,
+                                              "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes_pair,
+                                              "achieved": 2 * iter_bytes_pair / fused_s / 1e9, "frac": 2 * iter_bytes_pair / fused_s / 1e9 / HBM_PEAK_GBS,
                                               "traffic": pf.get("traffic_bytes_per_launch"),
                                               "traffic_GBps": (pf["traffic_bytes_per_launch"] / fused_s / 1e9) if pf.get("traffic_bytes_per_launch") else None}},
         "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
@@ -383,26 +406,36 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
     a, b = synth.flow_pair(1920, 1080)
     prev, _ = synth.flow_pair(1920, 1080, seed=11)
 
-    def host_rate(nthreads, n=6):
+    def host_rate(nthreads, seconds=1.5):
+        """every calling thread renders output frames (own context, own host buffers) for `seconds`; >= 1 s per leg"""
         cs = [ofxcv.Context(dev) for _ in range(nthreads)]
         outs = [np.zeros((1080, 1920, 4), np.float32) for _ in range(nthreads)]
-        for c, o in zip(cs, outs):
-            c.vectorgen_flows_host(a, b, prev, o, 1, 2, 4, 8)
+        srcs = [(a.copy(), b.copy(), prev.copy()) for _ in range(nthreads)]  # a host hands every render thread its own frames
+        for c, o, (x, y, z) in zip(cs, outs, srcs):
+            for _ in range(2):
+                c.vectorgen_flows_host(x, y, z, o, 1, 2, 4, 8)
+        counts = [0] * nthreads
+        stop = threading.Event()
 
-        def work(c, o):
-            for _ in range(n):
-                c.vectorgen_flows_host(a, b, prev, o, 1, 2, 4, 8)
+        def work(i):
+            c, o, (x, y, z) = cs[i], outs[i], srcs[i]
+            while not stop.is_set():
+                c.vectorgen_flows_host(x, y, z, o, 1, 2, 4, 8)
+                counts[i] += 1
         t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(c, o)) for c, o in zip(cs, outs)]
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
         [t.start() for t in th]
+        time.sleep(seconds)
+        stop.set()
         [t.join() for t in th]
         el = time.perf_counter() - t0
         for c in cs:
             c.close()
-        return 2 * nthreads * n / el
-    out["end_to_end"] = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs), "
-                                     "three 1920x1080 f32 RGBA host frames in, one host RGBA frame out, PCIe inclusive",
-                         "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_4": host_rate(4)}
+        return 2 * sum(counts) / el
+    out["end_to_end"] = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs, one "
+                                     "batched Farneback call), three 1920x1080 f32 RGBA host frames in, one host RGBA frame out, PCIe inclusive; "
+                                     "every calling thread renders for 1.5 s",
+                         "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_2": host_rate(2), "calling_threads_4": host_rate(4)}
 
     # ---- Telea inpaint (configs[0] size and configs[1]) ----
     ctx = ofxcv.Context(dev)
@@ -467,34 +500,35 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
     ctx.close()
 
     # ---- 3840x2160 Farneback (configs[4] workload on one GPU) ----
-    w, h, p4 = 3840, 2160, 4
+    w, h = 3840, 2160
     alg4 = algorithmic_bytes_per_pair(w, h)
-    leg = {"workload": "Farneback flow, 3840x2160 gray pairs resident in HBM, %d pairs in flight on one GPU (configs[4]: 8 per GPU)" % p4,
-           "unit": "frame-pairs/s"}
+    leg = {"workload": "Farneback flow, 3840x2160 gray pairs resident in HBM, 8 pairs per GPU (BASELINE configs[4]) as 2 batched calls of 4 in flight; "
+                       "direct-window mode: 4 single-pair calls in flight", "unit": "frame-pairs/s"}
     a4, b4 = synth.flow_pair(w, h)
     for direct, key in ((False, "value"), (True, "value_direct_window")):
-        cs = [ofxcv.Context(dev) for _ in range(p4)]
+        ns, nb = (4, 1) if direct else (2, 4)
+        cs = [ofxcv.Context(dev) for _ in range(ns)]
         bufs = []
         for c in cs:
             c.set_option("farneback.opencv_rounding", 0 if direct else 1)
             with torch.cuda.stream(c.stream):
-                bufs.append((c.to_byte_grayscale(torch.from_numpy(a4).cuda()), c.to_byte_grayscale(torch.from_numpy(b4).cuda()),
-                             torch.empty((h, w, 2), device="cuda")))
+                ga, gb = c.to_byte_grayscale(torch.from_numpy(a4).cuda()), c.to_byte_grayscale(torch.from_numpy(b4).cuda())
+                bufs.append(([ga] * nb, [gb] * nb, [torch.empty((h, w, 2), device="cuda") for _ in range(nb)]))
 
         def step4():
             for c, (ga, gb, fl) in zip(cs, bufs):
                 with torch.cuda.stream(c.stream):
-                    c.calc_optical_flow_farneback(ga, gb, fl)
+                    c.calc_optical_flow_farneback_batch(ga, gb, fl)
         for _ in range(3):
             step4()
         rs = []
         for _ in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(8):
+            for _ in range(4):
                 step4()
             torch.cuda.synchronize()
-            rs.append(8 * p4 / (time.perf_counter() - t0))
+            rs.append(4 * ns * nb / (time.perf_counter() - t0))
         leg[key] = med(rs)
         leg[key + "_frac_of_hbm_peak"] = alg4 * med(rs) / 1e9 / HBM_PEAK_GBS
         for c in cs:

@@ -73,8 +73,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    over the strips by the last workgroup of a tile column / by a small launch of its own);
  *                                    3 (default) = 2 on the bandwidth-bound pyramid levels, 0 on the small ones.  Identical
  *                                    results; timings in DESIGN.md section 4;
- *   "farneback.fold_rows" 3|8 / >=16 A/B: rows per wavefront of the folded kernel on the large levels (default 4) / number of
- *                                    62x64-pixel tiles from which a level counts as large (default 256); process-wide;
+ *   "farneback.fold_rows" 3|8, "farneback.fold_min" n, "farneback.fold_nw4" 0|1   A/B: rows per wavefront of the folded kernel on
+ *                                    the large levels (default 4); number of 62x64-pixel tiles (over the whole batch) from which a
+ *                                    level counts as large (default 256); 4-wavefront workgroups on the large levels too;
  *   "farneback.strict_rows" 0|2|4|8|16, "farneback.strict_variant" (1 unpipelined gather, 2 rows in pairs), "farneback.carry_groups",
  *   "farneback.lds_pad" bytes: A/B knobs of the pre-pass form of the OpenCV-order kernels. */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
@@ -112,6 +113,21 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
                                       size_t flow_step, int width, int height, double pyr_scale,
                                       int levels, int winsize, int iterations, int poly_n,
                                       double poly_sigma, int flags, void *stream);
+
+/* The same for `n` independent frame pairs of one size in ONE call (1 <= n <= OFXCV_FARNEBACK_MAX_BATCH): every kernel
+ * launch of the level walk carries all n pairs, so the pyramid levels that cannot fill the device with one pair (their
+ * launches are latency-bound) are amortised over the batch.  Pair i is (d_prev[i], d_next[i]) -> d_flow[i]; pairs may
+ * share images (a default VectorGenerator output frame is two pairs with the same first frame, forward t -> t+1 and
+ * backward t -> t-1, VectorGenerator/VectorGenerator.cpp:597-638; BASELINE configs[4] batches 8 pairs per GPU).
+ * The arrays are host arrays of device pointers / byte strides.  Results are bit-identical to n single calls;
+ * ofxcv_calc_optical_flow_farneback IS this call with n = 1.  Scratch grows with n (about 0.2 GB per 1920x1080 pair). */
+#define OFXCV_FARNEBACK_MAX_BATCH 16
+int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t *const *d_prev,
+                                            const size_t *prev_step, const uint8_t *const *d_next,
+                                            const size_t *next_step, float *const *d_flow,
+                                            const size_t *flow_step, int width, int height, double pyr_scale,
+                                            int levels, int winsize, int iterations, int poly_n,
+                                            double poly_sigma, int flags, void *stream);
 
 /* ---- F7: flow -> RGBA write-back ----------------------------------------------------------
  * replaces the loop at VectorGenerator/VectorGenerator.cpp:494-519.  chan_u_mask/chan_v_mask:

@@ -58,7 +58,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_host_zero_copy_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -174,6 +174,30 @@ class Context:
                    C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n),
                    C.c_double(poly_sigma), C.c_int(flags))
         return flow
+
+    def calc_optical_flow_farneback_batch(self, prevs, nxts, flows=None, pyr_scale=0.5, levels=3, winsize=3, iterations=15,
+                                          poly_n=5, poly_sigma=1.1, flags=0):
+        """n independent frame pairs of one size in one call (ofxcv_calc_optical_flow_farneback_batch): lists of HxW uint8
+        CUDA tensors -> list of HxWx2 float32 flows.  Pairs may share images."""
+        import torch
+        n = len(prevs)
+        assert n == len(nxts) and n >= 1
+        h, w = prevs[0].shape
+        if flows is None:
+            flows = [torch.empty((h, w, 2), dtype=torch.float32, device=prevs[0].device) for _ in range(n)]
+        for p, q, f in zip(prevs, nxts, flows):
+            assert p.is_cuda and q.is_cuda and p.dtype == torch.uint8 and q.dtype == torch.uint8 and p.shape == (h, w) and q.shape == (h, w)
+            assert p.stride(1) == 1 and q.stride(1) == 1
+            assert f.shape == (h, w, 2) and f.dtype == torch.float32 and f.stride(2) == 1 and f.stride(1) == 2
+        vp = (C.c_void_p * n)
+        sz = (C.c_size_t * n)
+        self._call(lib().ofxcv_calc_optical_flow_farneback_batch, C.c_int(n),
+                   vp(*[p.data_ptr() for p in prevs]), sz(*[p.stride(0) for p in prevs]),
+                   vp(*[q.data_ptr() for q in nxts]), sz(*[q.stride(0) for q in nxts]),
+                   vp(*[f.data_ptr() for f in flows]), sz(*[f.stride(0) * 4 for f in flows]),
+                   C.c_int(w), C.c_int(h), C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n),
+                   C.c_double(poly_sigma), C.c_int(flags))
+        return flows
 
     # ---- F7 ----
     def flow_to_rgba(self, flow, dst, chan_u_mask, chan_v_mask, rs_x=1.0, rs_y=1.0):

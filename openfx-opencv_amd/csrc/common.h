@@ -22,13 +22,14 @@ struct DevBuf {
 
 // cache of captured Farneback launch sequences (see ofxcv_calc_optical_flow_farneback)
 #define OFXCV_FB_MAX_LEVELS 10
+#define OFXCV_FB_MAX_BATCH OFXCV_FARNEBACK_MAX_BATCH  // frame pairs per batched call (pointer tables travel as kernel arguments)
 constexpr int kFbGraphSlots = 4;
-struct FbGraphKey {
-    const void *prev, *next, *flow;
-    size_t prev_step, next_step, flow_step;
-    int width, height, levels, winsize, iterations, poly_n, flags, pad_;
+struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
+    int n, width, height, levels, winsize, iterations, poly_n, flags;
     double pyr_scale, poly_sigma;
     const void *planes, *tmp, *cflow, *vsum;  // scratch addresses baked into the graph
+    const void *prev[OFXCV_FB_MAX_BATCH], *next[OFXCV_FB_MAX_BATCH], *flow[OFXCV_FB_MAX_BATCH];
+    size_t prev_step[OFXCV_FB_MAX_BATCH], next_step[OFXCV_FB_MAX_BATCH], flow_step[OFXCV_FB_MAX_BATCH];
 };
 struct FbGraph {
     FbGraphKey key;
@@ -65,6 +66,12 @@ struct ofxcv_ctx {
                               // prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
     int fb_strict_variant = 0, fb_carry_groups = 0, fb_lds_pad = 0;  // A/B knobs of the strip-parallel form
     int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
+    // A/B knobs of the folded form (options "farneback.fold_min" / "farneback.fold_rows" / "farneback.fold_nw4"): 62x64-pixel
+    // tiles (over the whole batch) from which a level counts as large; rows per wavefront on the large levels (0 = default 4);
+    // 4-wavefront workgroups on the large levels too
+    int fb_fold_min_tiles = 256, fb_fold_rows = 0;
+    bool fb_fold_nw4 = false;
+    int fb_debug_gather = 0;     // timing experiments only (wrong results): see FoldArgs::dbg
 
     // inpaint scratch
     DevBuf ip_tmp;   // undilated mask
@@ -92,7 +99,6 @@ struct ofxcv_ctx {
     double prof_ms = 0;
     long prof_launches = 0;
 
-    ofxcv_ctx *sibling = nullptr;  // second context of the host path: the backward flow runs beside the forward one
     bool host_register = true;     // option "host.register": 0 = always stage through the pinned ring
     long host_zero_copy_calls = 0, host_staged_calls = 0;
 
@@ -134,7 +140,9 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
 // stream creation (4 in 150).  Kernel launches, copies and
 // synchronisation stay concurrent; a graph launch costs the host 0.4 ms, far below the GPU time of the call it starts.
 // (A shared_mutex because readers may come back if a later runtime makes concurrent launches safe.)
-std::shared_mutex &ofxcv_capture_mutex();
+// One lock per device: the structures that raced are per-device (the stream list a graph launch walks), and a host
+// process that drives several GPUs from its render threads must not serialise all of them on one lock.
+std::shared_mutex &ofxcv_capture_mutex(int device);
 // Waits for everything this context has in flight (its own streams and the last caller-supplied one); never a
 // device-wide synchronisation, which would stall -- and invalidate the captures of -- other contexts' threads.
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx);
@@ -147,7 +155,6 @@ static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
 int ofxcv_upload_rows(ofxcv_ctx *ctx, void *d_dst, size_t row, const void *h_src, ptrdiff_t src_row_bytes, int rows, hipStream_t s);
 int ofxcv_download_rows(ofxcv_ctx *ctx, void *h_dst, ptrdiff_t dst_row_bytes, const void *d_src, size_t row, int rows, hipStream_t s);
 
-extern "C" void ofxcv_farneback_set_fold_rows(int rows);  // process-wide A/B knob, not part of the public header
 int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation stream and the per-level events
 
 // measurement hook helpers (context.hip)

@@ -15,9 +15,9 @@ int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
-std::shared_mutex &ofxcv_capture_mutex() {
-    static std::shared_mutex m;
-    return m;
+std::shared_mutex &ofxcv_capture_mutex(int device) {
+    static std::shared_mutex m[64];
+    return m[(unsigned)device & 63u];
 }
 
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
@@ -29,7 +29,7 @@ int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
 
 int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
     if (b.ptr) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
@@ -89,7 +89,7 @@ int ofxcv_prof_drain(ofxcv_ctx *ctx) {
 
 int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     if (ctx->prep) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());  // stream creation: see ofxcv_ctx_create
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));  // stream creation: see ofxcv_ctx_create
     OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
     OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -133,7 +133,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
         // stream creation changes the runtime's stream list, which another thread's hipGraphLaunch walks: under the runtime lock
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(device));
         OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
         OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
@@ -154,12 +154,8 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
 
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
-    if (ctx->sibling) {
-        ofxcv_ctx_destroy(ctx->sibling);
-        ctx->sibling = nullptr;
-    }
     (void)hipSetDevice(ctx->device);
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
     (void)ofxcv_ctx_quiesce(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (FbGraph &g : ctx->fb_graphs)
@@ -195,9 +191,8 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute
 
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return OFXCV_ERR_INVALID;
-    if (ctx->sibling) (void)ofxcv_ctx_set_option(ctx->sibling, name, value);
     // captured launch sequences bake the kernel choice in: drop them whenever an option changes
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
     for (FbGraph &g : ctx->fb_graphs)
         if (g.exec) {
             (void)hipGraphExecDestroy(g.exec);
@@ -228,7 +223,19 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.fold_rows")) {
-        ofxcv_farneback_set_fold_rows(value);
+        ctx->fb_fold_rows = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.fold_min")) {
+        ctx->fb_fold_min_tiles = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.debug_gather")) {
+        ctx->fb_debug_gather = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.fold_nw4")) {
+        ctx->fb_fold_nw4 = value != 0;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.fold_carries")) {

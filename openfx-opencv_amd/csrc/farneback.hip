@@ -31,6 +31,19 @@ namespace {
 constexpr int kMaxGaussTaps = 255;
 constexpr int kMaxPolyN = 15;
 constexpr int kMaxLevels = OFXCV_FB_MAX_LEVELS;
+constexpr int kMaxBatch = OFXCV_FB_MAX_BATCH;
+
+// Batched calls: every kernel of the level walk takes the frame pair from the z coordinate of its grid.  Scratch fields of
+// consecutive pairs lie a fixed stride apart; what the caller owns (source images, flow fields) comes as a pointer table
+// in the kernel arguments.  A single call is a batch of one (grid z = 1, stride unused).
+struct ImgTab {   // 8-bit source images: entry 2 * pair + {0 = prev, 1 = next}
+    const uint8_t *p[2 * kMaxBatch];
+    size_t step[2 * kMaxBatch];
+};
+struct FlowTab {  // 2-channel flow fields, one per pair (the caller's at level 0, scratch on the coarser levels)
+    float *p[kMaxBatch];
+    size_t step[kMaxBatch];
+};
 
 struct GaussTaps {
     int ksize;
@@ -157,12 +170,19 @@ __device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, f
 // L2, so with the plain mapping two neighbouring tiles -- which share halo rows/columns and the cache lines of the
 // R1 samples -- never share an L2.  This bijective remap hands every XCD a contiguous row-major run of tiles
 // (cdna_hip_programming.md T1).  It only changes which workgroup computes which tile: results are unaffected.
-__device__ __forceinline__ void xcd_tile(int &bx, int &by) {
-    const unsigned gx = gridDim.x, nwg = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+// With a batch in the grid's z dimension the run continues across pairs (z-major), so the pair index comes out of the remap too.
+__device__ __forceinline__ void xcd_tile(int &bx, int &by, int &bz) {
+    const unsigned gx = gridDim.x, gxy = gx * gridDim.y, nwg = gxy * gridDim.z, id = (blockIdx.z * gridDim.y + blockIdx.y) * gx + blockIdx.x;
     const unsigned xcd = id & 7u, q = nwg >> 3, r = nwg & 7u;
-    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    bz = (int)(t / gxy);
+    t -= (unsigned)bz * gxy;
     by = (int)(t / gx);
     bx = (int)(t - (unsigned)by * gx);
+}
+__device__ __forceinline__ void xcd_tile(int &bx, int &by) {
+    int bz;
+    xcd_tile(bx, by, bz);
 }
 
 // ------------------------------------------------------------------ F1/F2 pyramid image
@@ -254,8 +274,8 @@ struct PyrTile {
     int cw, rh;    // staged source footprint (columns, rows), upper bounds
 };
 
-__global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh, int ntap,
-                                                        GaussTaps gk, PyrTile t, float *__restrict__ I) {
+__global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int H, int lw, int lh, int ntap,
+                                                        GaussTaps gk, PyrTile t, float *__restrict__ I, size_t I_stride) {
     extern __shared__ unsigned char pyr_lds[];
     const int ksize = gk.ksize, r = ksize >> 1;
     const int ncolh = t.ow * ntap;                 // row-filtered columns kept per source row
@@ -265,8 +285,11 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restric
     float *s_yb = (float *)(s_ys + t.oh);          // [oh][2]
     float *s_h = s_yb + 2 * t.oh;                  // [rh][ncolh] row-filtered samples
     unsigned char *s_src = (unsigned char *)(s_h + (size_t)t.rh * ncolh);  // [rh][cw] source bytes
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    const uint8_t *__restrict__ img = imgs.p[tbz];
+    const size_t step = imgs.step[tbz];
+    I += (size_t)tbz * I_stride;
     const int ox0 = tbx * t.ow, oy0 = tby * t.oh;
     const int tid = threadIdx.x;
 
@@ -348,11 +371,14 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(const uint8_t *__restric
 // 3-tap levels (k = 0: sigma 0 -> [1/4 1/2 1/4], identity resize; k = 1: sigma 0.5, half size): the footprint of an
 // output sample is at most 4x4 source bytes, so each lane simply reads it through the L1 -- no staging, no barriers.
 // Same operations in the same order as the generic kernels.
-__global__ __launch_bounds__(256) void pyr_direct3_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh,
+__global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, int H, int lw, int lh,
                                                           int ntap, float k0, float k1, double scale_x, double scale_y,
-                                                          float *__restrict__ I) {
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+                                                          float *__restrict__ I, size_t I_stride) {
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    const uint8_t *__restrict__ img = imgs.p[tbz];
+    const size_t step = imgs.step[tbz];
+    I += (size_t)tbz * I_stride;
     const int dx = tbx * 64 + threadIdx.x, dy = tby * 4 + threadIdx.y;
     if (dx >= lw || dy >= lh) return;
     int sx = dx, sy = dy;
@@ -395,10 +421,13 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(const uint8_t *__restr
 // (k = 0) or two (k = 1) horizontally adjacent samples from them: 2.25 / 6 loads per sample.  Lanes whose dwords
 // would cross the image edge take the byte path with reflected columns.  Arithmetic and order as in the byte kernel.
 template <int NTAP>
-__global__ __launch_bounds__(256) void pyr_direct3v_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H, int lw, int lh,
-                                                           float k0, float k1, float *__restrict__ I) {
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+__global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, int H, int lw, int lh,
+                                                           float k0, float k1, float *__restrict__ I, size_t I_stride) {
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    const uint8_t *__restrict__ img = imgs.p[tbz];
+    const size_t step = imgs.step[tbz];
+    I += (size_t)tbz * I_stride;
     const int c0 = (tbx * 64 + threadIdx.x) * 4;  // first source column of this lane
     const int dy = tby * 4 + threadIdx.y;
     if (c0 >= W || dy >= lh) return;
@@ -474,7 +503,7 @@ constexpr int kPeTW = 64, kPeTH = 16;
 // NT > 0: poly_n known at compile time (loops fully unrolled); NT == 0: run-time poly_n
 template <int NT>
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
-                                                      int pitch, PolyCoef pc) {
+                                                      int pitch, PolyCoef pc, size_t I_stride, size_t pair_stride, size_t field) {
     extern __shared__ float lds[];
     const int n = NT > 0 ? NT : pc.n;
     const int cw = kPeTW + 2 * n;          // staged columns
@@ -483,8 +512,10 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
     float *sI = lds;                       // [ih][ldw]
     float *sV = lds + ih * ldw;            // [3][kPeTH][ldw]
     const int tid = threadIdx.x, lx = tid & 63, tq = tid >> 6;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);  // z = frame: 2 * pair + {0 = prev, 1 = next}
+    I += (size_t)tbz * I_stride;
+    R += (size_t)(tbz >> 1) * pair_stride + (size_t)(tbz & 1) * field;
     const int x0 = tbx * kPeTW, y0 = tby * kPeTH;
 
     // stage I (rows and columns clamped = replicated border); lanes < 2n also fetch the extra halo columns
@@ -560,8 +591,9 @@ typedef float ofxcv_f2 __attribute__((ext_vector_type(2)));
 typedef float ofxcv_f4 __attribute__((ext_vector_type(4)));
 
 template <int N, int TH>
-__global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
-                                                                 int pitch, PolyCoef pc, int tiles_x, int ntiles) {
+__global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__restrict__ Ib, int w, int h, float *__restrict__ Rb,
+                                                                 int pitch, PolyCoef pc, int tiles_x, int ntiles_img, int nimg, size_t I_stride,
+                                                                 size_t pair_stride, size_t field) {
     constexpr int CW = kPeTW + 2 * N, LDW = CW + 2, IH = TH + 2 * N;  // staged columns / row stride (even) / rows
     constexpr int NSR = (IH + 3) / 4;                                 // staged rows per wavefront
     constexpr int NV = (CW / 2) * TH;                                 // column pairs x rows of the vertical pass
@@ -569,14 +601,18 @@ __global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__
     __shared__ ofxcv_f4 sV[TH * CW];
     const int tid = threadIdx.x, lx = tid & 63, tq = tid >> 6;
     // XCD b % 8 works through tiles [lo, hi); its workgroups take them round-robin
+    // (a batch puts the tiles of its 2 * n frames one after the other: tile t belongs to frame t / ntiles_img)
     const unsigned xcd = blockIdx.x & 7u, per = gridDim.x >> 3;
+    const int ntiles = ntiles_img * nimg;
     const int lo = (int)((long)ntiles * xcd / 8), hi = (int)((long)ntiles * (xcd + 1) / 8);
     const float *g = pc.g + pc.n, *xg = pc.xg + pc.n, *xxg = pc.xxg + pc.n;
     const size_t plane = (size_t)pitch * h;
 
     // staging: wavefront tq fetches rows tq, tq + 4, ...; lane lx column lx, lanes < 2N also column 64 + lx
     float pre[NSR], pre2[NSR];
-    auto request = [&](int t) {
+    auto request = [&](int tt) {
+        const int im = tt / ntiles_img, t = tt - im * ntiles_img;
+        const float *I = Ib + (size_t)im * I_stride;
         const int ty0 = t / tiles_x, x0 = (t - ty0 * tiles_x) * kPeTW, y0 = ty0 * TH;
         const int gx0 = clampi(x0 + lx - N, 0, w - 1), gx1 = clampi(x0 + 64 + lx - N, 0, w - 1);
 #pragma unroll
@@ -622,7 +658,9 @@ __global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__
         __syncthreads();
 
         // horizontal pass (f64 accumulators)
-        const int ty0 = t / tiles_x, x0 = (t - ty0 * tiles_x) * kPeTW, y0 = ty0 * TH;
+        const int im = t / ntiles_img, tl = t - im * ntiles_img;
+        float *R = Rb + (size_t)(im >> 1) * pair_stride + (size_t)(im & 1) * field;
+        const int ty0 = tl / tiles_x, x0 = (tl - ty0 * tiles_x) * kPeTW, y0 = ty0 * TH;
         const int x = x0 + lx;
 #pragma unroll
         for (int i = 0; i < TH / 4; i++) {
@@ -778,14 +816,19 @@ __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, c
 // the coarser level (resize INTER_LINEAR, then * 1/pyr_scale); MODE 2: explicit interleaved flow.
 template <int MODE>
 __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                              const float *__restrict__ flow, size_t flow_step, int pw, int ph,
+                                                              FlowTab flows, int pw, int ph,
                                                               double inv_pyr_scale, double scale_x, double scale_y, int w, int h,
-                                                              int pitch, float *__restrict__ M) {
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+                                                              int pitch, float *__restrict__ M, size_t pair_stride) {
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
     int x = tbx * 64 + threadIdx.x;
     int y = tby * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
+    R0 += (size_t)tbz * pair_stride;
+    R1 += (size_t)tbz * pair_stride;
+    M += (size_t)tbz * pair_stride;
+    const float *__restrict__ flow = MODE ? flows.p[tbz] : nullptr;
+    const size_t flow_step = MODE ? flows.step[tbz] : 0;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
         int sx, sy;
@@ -1314,10 +1357,15 @@ constexpr int kSsSPW = 4;   // strips per wavefront of the carry kernel (upper b
 
 template <int RW>
 __global__ __launch_bounds__(1024) void vsum_carry_kernel(const float *__restrict__ M, int w, int h, int pitch, double *__restrict__ carry,
-                                                          double *__restrict__ gtot, int nstrips, int spg, int spw) {
+                                                          double *__restrict__ gtot, int nstrips, int spg, int spw, size_t pair_stride,
+                                                          size_t pair_vsum) {
     __shared__ double tot[16][64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), c = blockIdx.y, g = blockIdx.z;
+    const int pz = blockIdx.y / 5;  // grid y = channel + 5 * pair
+    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), c = blockIdx.y - 5 * pz, g = blockIdx.z;
+    M += (size_t)pz * pair_stride;
+    carry += (size_t)pz * pair_vsum;
+    gtot += (size_t)pz * pair_vsum;
     const int s_first = g * spg + wv * spw, s_end = min(s_first + spw, min((g + 1) * spg, nstrips));
     const float *m = M + (size_t)c * pitch * h + x;
     const int a = s_first * RW;
@@ -1371,13 +1419,22 @@ constexpr int kSsW = 62;  // columns a wavefront of iterate3s_kernel owns (lanes
 template <bool UPDATE, int RW, int MODE>
 __global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                         const float *__restrict__ Min, float *__restrict__ Mout,
-                                                        float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
-                                                        const double *__restrict__ carry, const double *__restrict__ gtot, int spg) {
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+                                                        FlowTab flows, int w, int h, int pitch, double scale,
+                                                        const double *__restrict__ carry, const double *__restrict__ gtot, int spg,
+                                                        size_t pair_stride, size_t pair_vsum) {
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = (tbx * 2 + wave) * kSsW;
     if (x0 >= w) return;  // wave-uniform
+    R0 += (size_t)tbz * pair_stride;
+    R1 += (size_t)tbz * pair_stride;
+    Min += (size_t)tbz * pair_stride;
+    if (UPDATE) Mout += (size_t)tbz * pair_stride;
+    carry += (size_t)tbz * pair_vsum;
+    gtot += (size_t)tbz * pair_vsum;
+    float *__restrict__ flow = flows.p[tbz];  // may be null while UPDATE (the flow then stays on chip)
+    const size_t flow_step = flows.step[tbz];
     const int a = tby * RW;
     const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
@@ -1507,6 +1564,15 @@ struct FoldArgs {
     unsigned *counters;   // [tile columns]       workgroups of the tile column that have finished (0 on entry and on exit)
     int nstrips;
     int scan_in_kernel;   // 1: the last workgroup of a tile column runs the prefix over the strips itself; 0: fold_scan_kernel does
+    size_t pair_vsum;     // batched calls: doubles between the Kin / Kout / Spart of consecutive pairs
+    unsigned pair_ctr;    //                counters between consecutive pairs
+    int dbg;              // timing experiments only (option "farneback.debug_gather"; results are wrong when set): 1 no R1 gather, 2 gather at zero flow
+    __device__ __forceinline__ void select_pair(int z) {
+        if (Kin) Kin += (size_t)z * pair_vsum;
+        Kout += (size_t)z * pair_vsum;
+        Spart += (size_t)z * pair_vsum;
+        counters += (size_t)z * pair_ctr;
+    }
 };
 
 // Data that one workgroup hands to another inside a launch (the boundary rows of the new M, the strip sums) goes through
@@ -1597,10 +1663,13 @@ __device__ __forceinline__ void fold_finish(const float *__restrict__ M, const F
 // carries of its portion.  (With one wavefront per channel walking all boundaries in batches the launch took 9.9 us at
 // 1080p -- five dependent batches -- which is on the critical path when one pair is in flight.)
 constexpr int kScanQ = 4, kScanB = 9;  // portions per channel; boundaries per batch of loads
-__global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa) {
+__global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa,
+                                                                size_t pair_stride) {
     __shared__ double s_tot[kScanQ][64];
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = blockIdx.y;
+    M += (size_t)blockIdx.z * pair_stride;  // grid z = pair
+    fa.select_pair(blockIdx.z);
     const int xr = blockIdx.x * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
     const size_t plane = (size_t)pitch * h;
@@ -1661,11 +1730,13 @@ __global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__r
 
 // carries of a field that already lies in memory (the first M of a pyramid level)
 template <int RW, int NW>
-__global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, FoldArgs fa) {
+__global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, FoldArgs fa, size_t pair_stride) {
     __shared__ double s_w[NW][5][64];
     __shared__ unsigned s_flag;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    M += (size_t)tbz * pair_stride;
+    fa.select_pair(tbz);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
@@ -1698,15 +1769,22 @@ __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restr
 template <bool UPDATE, int RW, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                            const float *__restrict__ Min, float *__restrict__ Mout,
-                                                           float *__restrict__ flow, size_t flow_step, int w, int h, int pitch, double scale,
-                                                           FoldArgs fa) {
+                                                           FlowTab flows, int w, int h, int pitch, double scale,
+                                                           FoldArgs fa, size_t pair_stride) {
     constexpr bool PIPE = RW < 8;  // with 8 rows per wavefront the second in-flight pixel record does not fit 128 registers
     static_assert(RW >= 3, "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
     __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
     __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
     __shared__ unsigned s_flag;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    R0 += (size_t)tbz * pair_stride;
+    R1 += (size_t)tbz * pair_stride;
+    Min += (size_t)tbz * pair_stride;
+    if (UPDATE) Mout += (size_t)tbz * pair_stride;
+    fa.select_pair(tbz);
+    float *__restrict__ flow = flows.p[tbz];  // may be null while UPDATE
+    const size_t flow_step = flows.step[tbz];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = tbx * kSsW;
     constexpr int SH = RW * NW;
@@ -1788,7 +1866,13 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
             cur.fyv = fyv;
 #pragma unroll
             for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
+            if (fa.dbg == 1) {
+                cur.tp = Taps();
+                cur.tp.inb = true;
+                cur.tp.fx = cur.tp.fy = 0.5f;
+            } else {
+                cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fa.dbg == 2 ? 0.f : fxv, fa.dbg == 2 ? 0.f : fyv);
+            }
             if (PIPE) {  // the gather of row j is in flight while row j-1 is finished
                 if (j > 0) finish(prev, j - 1);
                 prev = cur;
@@ -1847,24 +1931,85 @@ void level_geom(int w, int h, double pyr_scale, int k, int &lw, int &lh, double 
 
 inline int plane_pitch(int w) { return (w + 63) & ~63; }
 
-int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t step, int W, int H, int lw, int lh,
-                     double sigma, int ksize, float *d_T1, float *d_I) {
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// How the scratch of one (batched) call is laid out: every pair has the same layout, consecutive pairs lie a fixed
+// stride apart, and the kernels pick their pair from the grid's z coordinate.
+struct Layout {
+    int n = 1;             // frame pairs of the call
+    size_t field0 = 0;     // floats of one 5-plane field at level 0
+    size_t rtotal = 0;     // floats of R0 + R1 over all levels
+    size_t planes = 0;     // floats between the plane scratch (M ping, M pong, R of every level) of consecutive pairs
+    size_t t1 = 0;         // floats of the two-pass pyramid fall-back's row buffer (shared, used sequentially)
+    size_t img = 0;        // floats between the pyramid images of consecutive frames
+    size_t cflow = 0;      // floats of ONE coarse flow field (two per pair)
+    size_t vsum = 0;       // doubles between the column-sum scratch of consecutive pairs
+    unsigned ctr = 0;      // fold counters per pair (after the column-sum scratch of all pairs)
+    size_t planes_bytes() const { return sizeof(float) * planes * n; }
+    size_t tmp_bytes() const { return sizeof(float) * (t1 + 2 * (size_t)n * img); }
+    size_t flow_bytes() const { return sizeof(float) * 2 * cflow * n; }
+    size_t vsum_bytes() const { return sizeof(double) * vsum * n + sizeof(unsigned) * (size_t)ctr * n; }
+};
+
+
+
+// f64 scratch of the OpenCV-order / Gaussian window kernels for one pair at geometry w x h: the largest of
+//   serial column scan / Gaussian vertical pass   5 * pitch * h values
+//   carry pre-pass                                (strips of >= 2 rows + up to 8 group totals + 1) * 5 * pitch
+//   folded carries                                3 * (strips of >= 12 rows + 1) * 5 * pitch
+size_t vsum_doubles(int w, int h) {
+    const size_t pitch = (size_t)plane_pitch(w);
+    const size_t a = 5 * pitch * h, b = (size_t)(ofxcv_div_up(h, 2) + 10) * 5 * pitch, c = 3 * (size_t)(ofxcv_div_up(h, 12) + 1) * 5 * pitch;
+    return round_up(std::max(a, std::max(b, c)), 32);
+}
+
+int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, int levels, Layout &L) {
+    L.n = n;
+    L.field0 = 5 * (size_t)plane_pitch(width) * height;
+    L.rtotal = 0;
+    for (int k = levels; k >= 0; k--) {
+        int w, h, ksz;
+        double sigma;
+        level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+        if (ksz > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksz, kMaxGaussTaps);
+        L.rtotal += 2 * 5 * (size_t)plane_pitch(w) * h;
+    }
+    L.planes = 2 * L.field0 + L.rtotal;
+    L.t1 = round_up((size_t)(width + 4) * height, 64);
+    L.img = round_up((size_t)width * height, 64);
+    L.cflow = 0;
+    if (levels > 0) {
+        int lw, lh, ks;
+        double sg;
+        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
+        L.cflow = round_up((size_t)lw * lh * 2, 64);
+    }
+    L.vsum = vsum_doubles(width, height);
+    L.ctr = (unsigned)round_up((size_t)ofxcv_div_up(width, kSsW) + 1, 2);
+    return OFXCV_OK;
+}
+
+// F1/F2 for `nimg` frames in one launch (grid z = frame); I of frame i at d_I + i * I_stride
+int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg, int W, int H, int lw, int lh, double sigma, int ksize,
+                     float *d_T1, float *d_I, size_t I_stride) {
     if (ksize > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksize, kMaxGaussTaps);
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk);
     int ntap = (lw == W && lh == H) ? 1 : 2;
     const bool no_fused = ctx->fb_unfused_pyr;
-    const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && ((uintptr_t)d_img & 3) == 0 && (step & 3) == 0;
+    bool aligned = true;
+    for (int i = 0; i < nimg; i++) aligned = aligned && ((uintptr_t)imgs.p[i] & 3) == 0 && (imgs.step[i] & 3) == 0;
+    const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && aligned && (I_stride & 3) == 0;
     if (dword_ok && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
-        dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4)), block(64, 4);
-        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, d_img, step, W, H, lw, lh, gk.k[1], gk.k[2], d_I);
-        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, d_img, step, W, H, lw, lh, gk.k[1], gk.k[2], d_I);
+        dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4), nimg), block(64, 4);
+        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride);
+        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3v_kernel");
         return OFXCV_OK;
     }
     if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
-        hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_img, step, W, H, lw, lh, ntap,
-                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I);
+        hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4), nimg), dim3(64, 4), 0, s, imgs, W, H, lw, lh, ntap,
+                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3_kernel");
         return OFXCV_OK;
     }
@@ -1873,7 +2018,7 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     t.ow = (double)W / lw <= 2.01 ? 64 : 32;
     t.oh = 8;
     // coarse levels: smaller tiles until there are enough workgroups to spread over the 256 CUs
-    while ((long)ofxcv_div_up(lw, t.ow) * ofxcv_div_up(lh, t.oh) < 512 && (t.ow > 16 || t.oh > 2)) {
+    while ((long)ofxcv_div_up(lw, t.ow) * ofxcv_div_up(lh, t.oh) * nimg < 512 && (t.ow > 16 || t.oh > 2)) {
         if (t.ow > 16 && t.ow >= 4 * t.oh) t.ow >>= 1;
         else if (t.oh > 2) t.oh >>= 1;
         else t.ow >>= 1;
@@ -1884,34 +2029,39 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const uint8_t *d_img, size_t
     const size_t lds = sizeof(int) * (t.ow + t.oh) + sizeof(float) * 2 * (t.ow + t.oh) + sizeof(float) * (size_t)t.rh * t.ow * ntap +
                        (size_t)t.rh * t.cw;
     if (!no_fused && lds <= 60 * 1024 && lw >= 2 && lh >= 2) {
-        hipLaunchKernelGGL(pyr_fused_kernel, dim3(ofxcv_div_up(lw, t.ow), ofxcv_div_up(lh, t.oh)), dim3(256), lds, s, d_img, step, W, H, lw, lh, ntap,
-                           gk, t, d_I);
+        hipLaunchKernelGGL(pyr_fused_kernel, dim3(ofxcv_div_up(lw, t.ow), ofxcv_div_up(lh, t.oh), nimg), dim3(256), lds, s, imgs, W, H, lw, lh, ntap,
+                           gk, t, d_I, I_stride);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_kernel");
         return OFXCV_OK;
     }
     int ncol = lw * ntap;
-    hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, d_img, step, W, H, lw, ntap, gk, d_T1);
-    OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
-    hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_T1, W, H,
-                       lw, lh, ntap, gk, d_I);
-    OFXCV_LAUNCH_CHECK(ctx, "pyr_vblur_resize_kernel");
+    for (int i = 0; i < nimg; i++) {  // two-pass fall-back, frame by frame through the one row buffer
+        hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, imgs.p[i], imgs.step[i], W, H, lw, ntap, gk, d_T1);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
+        hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_T1, W, H,
+                           lw, lh, ntap, gk, d_I + (size_t)i * I_stride);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_vblur_resize_kernel");
+    }
     return OFXCV_OK;
 }
 
-int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h, float *d_R, int poly_n, double poly_sigma) {
+// F3 for `nimg` frames in one launch: I of frame i at d_I + i * I_stride, R of frame i at d_R + (i / 2) * pair_stride + (i % 2) * field
+int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h, float *d_R, int poly_n, double poly_sigma, int nimg,
+                   size_t I_stride, size_t pair_stride, size_t field) {
     if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
     PolyCoef pc;
     make_poly_coef(poly_n, poly_sigma, pc);
     int cw = kPeTW + 2 * poly_n, ldw = cw | 1, ih = kPeTH + 2 * poly_n;
     size_t lds = sizeof(float) * ((size_t)ih * ldw + 3 * kPeTH * ldw);
-    dim3 grid(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH));
+    dim3 grid(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH), nimg);
     if (ctx->fb_polyexp_variant >= 1 && (poly_n == 5 || poly_n == 7)) {
         const int v = ctx->fb_polyexp_variant;
         const int th = (v & 1) ? 16 : 8, wgs_per_cu = v <= 2 ? 4 : (v <= 4 ? 5 : 6);
         const int tiles_x = (int)grid.x, tiles_y = ofxcv_div_up(h, th), ntiles = tiles_x * tiles_y;
-        const int nwg = std::min((ntiles + 7) & ~7, ctx->num_cus * wgs_per_cu & ~7);  // a multiple of the 8 XCDs
-#define OFXCV_LAUNCH_PE(N, TH) \
-    hipLaunchKernelGGL((polyexp_persistent_kernel<N, TH>), dim3(nwg), dim3(256), 0, s, d_I, w, h, d_R, plane_pitch(w), pc, tiles_x, ntiles)
+        const int nwg = std::min((ntiles * nimg + 7) & ~7, ctx->num_cus * wgs_per_cu & ~7);  // a multiple of the 8 XCDs
+#define OFXCV_LAUNCH_PE(N, TH)                                                                                                          \
+    hipLaunchKernelGGL((polyexp_persistent_kernel<N, TH>), dim3(nwg), dim3(256), 0, s, d_I, w, h, d_R, plane_pitch(w), pc, tiles_x, ntiles, \
+                       nimg, I_stride, pair_stride, field)
         if (poly_n == 5) {
             if (th == 16) OFXCV_LAUNCH_PE(5, 16);
             else OFXCV_LAUNCH_PE(5, 8);
@@ -1923,43 +2073,50 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
         OFXCV_LAUNCH_CHECK(ctx, "polyexp_persistent_kernel");
         return OFXCV_OK;
     }
-    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
-    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
-    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc);
+    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
+    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
+    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
     OFXCV_LAUNCH_CHECK(ctx, "polyexp_kernel");
     return OFXCV_OK;
 }
 
-int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
-                     size_t flow_step, int w, int h, int winsize, bool update) {
+// One blur+solve(+update) iteration for the n pairs of a call.  R0 / R1 / Min / Mout are pair 0's fields (pair z lies
+// z * L.planes floats further), `flows` the per-pair flow outputs (null pointers: the flow stays on chip).  The kernels of
+// the default mode (OpenCV-order 3x3 box) take all pairs in one launch; the other window forms are launched pair by pair.
+int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
+                     int w, int h, int winsize, bool update, const Layout &L) {
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
+    const int pitch = plane_pitch(w);
     if (ctx->fb_opencv_rounding == 1 && winsize == 3) {
         // strip-parallel OpenCV-order window: carries of the column running sums, then the iteration itself
-        const int pitch = plane_pitch(w), tiles_x = ofxcv_div_up(w, kSsW);
+        const int tiles_x = ofxcv_div_up(w, kSsW);
         int rw = ctx->fb_strict_rows;
-        if (rw != 2 && rw != 4 && rw != 8 && rw != 16) rw = (long)tiles_x * ofxcv_div_up(h, 8) >= 4096 ? 8 : ((long)tiles_x * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
+        if (rw != 2 && rw != 4 && rw != 8 && rw != 16) {
+            const long nt = (long)tiles_x * L.n;  // a batch fills the chip with fewer, longer wavefronts
+            rw = nt * ofxcv_div_up(h, 8) >= 4096 ? 8 : (nt * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
+        }
         const int nstrips = ofxcv_div_up(h, rw), G = std::max(ofxcv_div_up(nstrips, 16 * kSsSPW), std::min(ctx->fb_carry_groups, 8)), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
         double *carry = (double *)ctx->fb_vsum.ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
-        dim3 cgrid(ofxcv_div_up(w, 64), 5, G), grid(ofxcv_div_up(tiles_x, 2), nstrips);
+        dim3 cgrid(ofxcv_div_up(w, 64), 5 * L.n, G), grid(ofxcv_div_up(tiles_x, 2), nstrips, L.n);
 #define OFXCV_LAUNCH_SS(RW)                                                                                                              \
     do {                                                                                                                                 \
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-        hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw);            \
+        hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw, L.planes, L.vsum); \
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
         if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
         if (update && pairs)                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 2>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg);                                                        \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 2>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
         else if (update && pipe)                                                                                                         \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 1>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg);                                                        \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 1>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
         else if (update)                                                                                                                 \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg);                                                        \
+            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<false, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg);                                                        \
+            hipLaunchKernelGGL((iterate3s_kernel<false, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
+                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
         if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
     } while (0)
         const int mark = ctx->prof_now ? ctx->prof_on : 0;  // measurement hook: 1 = the iteration kernel, 2 = the carry pre-pass
@@ -1974,52 +2131,53 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         OFXCV_LAUNCH_CHECK(ctx, "iterate3s_kernel");
         return OFXCV_OK;
     }
-    if (ctx->fb_opencv_rounding && winsize == 3) {  // 2: the serial column scan (cross-check of the strip-parallel form)
-        const int pitch = plane_pitch(w);
-        double *V = (double *)ctx->fb_vsum.ptr;  // reserved by the caller
-        hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, Min, w, h, pitch, V);
-        OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
-        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-        if (update)
-            hipLaunchKernelGGL(strict_solve_kernel<true>, grid, block, 0, s, R0, R1, (const double *)V, Mout, flow, flow_step, w, h, pitch, scale);
-        else
-            hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, R0, R1, (const double *)V, Mout, flow, flow_step, w, h, pitch, scale);
-        OFXCV_LAUNCH_CHECK(ctx, "strict_solve_kernel");
-        return OFXCV_OK;
-    }
-    if (winsize == 3) {
-        // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
-        const int cols = ofxcv_div_up(w, 64);
-        int rows = 4;
-        while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
-        dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
-        const int pitch = plane_pitch(w);
+    for (int z = 0; z < L.n; z++) {  // the other window forms: pair by pair
+        const float *r0 = R0 ? R0 + (size_t)z * L.planes : nullptr, *r1 = R1 ? R1 + (size_t)z * L.planes : nullptr, *mi = Min + (size_t)z * L.planes;
+        float *mo = Mout ? Mout + (size_t)z * L.planes : nullptr, *flow = flows.p[z];
+        const size_t flow_step = flows.step[z];
+        if (ctx->fb_opencv_rounding && winsize == 3) {  // 2: the serial column scan (cross-check of the strip-parallel form)
+            double *V = (double *)ctx->fb_vsum.ptr + (size_t)z * L.vsum;  // reserved by the caller
+            hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, mi, w, h, pitch, V);
+            OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
+            dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+            if (update)
+                hipLaunchKernelGGL(strict_solve_kernel<true>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale);
+            else
+                hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale);
+            OFXCV_LAUNCH_CHECK(ctx, "strict_solve_kernel");
+        } else if (winsize == 3) {
+            // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
+            const int cols = ofxcv_div_up(w, 64);
+            int rows = 4;
+            while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
+            dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
 #define OFXCV_LAUNCH_IT(UPD, RW) \
-    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale)
-        if (update) {
-            if (rows == 4) OFXCV_LAUNCH_IT(true, 4);
-            else if (rows == 2) OFXCV_LAUNCH_IT(true, 2);
-            else OFXCV_LAUNCH_IT(true, 1);
-        } else {
-            if (rows == 4) OFXCV_LAUNCH_IT(false, 4);
-            else if (rows == 2) OFXCV_LAUNCH_IT(false, 2);
-            else OFXCV_LAUNCH_IT(false, 1);
-        }
+    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, scale)
+            if (update) {
+                if (rows == 4) OFXCV_LAUNCH_IT(true, 4);
+                else if (rows == 2) OFXCV_LAUNCH_IT(true, 2);
+                else OFXCV_LAUNCH_IT(true, 1);
+            } else {
+                if (rows == 4) OFXCV_LAUNCH_IT(false, 4);
+                else if (rows == 2) OFXCV_LAUNCH_IT(false, 2);
+                else OFXCV_LAUNCH_IT(false, 1);
+            }
 #undef OFXCV_LAUNCH_IT
-        OFXCV_LAUNCH_CHECK(ctx, "iterate3_kernel");
-        return OFXCV_OK;
+            OFXCV_LAUNCH_CHECK(ctx, "iterate3_kernel");
+        } else {
+            dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
+            if (update)
+                hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale);
+            else
+                hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale);
+            OFXCV_LAUNCH_CHECK(ctx, "blur_solve_update_kernel");
+        }
     }
-    dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-    if (update)
-        hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
-    else
-        hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, plane_pitch(w), m, scale);
-    OFXCV_LAUNCH_CHECK(ctx, "blur_solve_update_kernel");
     return OFXCV_OK;
 }
 
-int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
-                           size_t flow_step, int w, int h, int winsize, bool update) {
+int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
+                           int w, int h, int winsize, bool update, const Layout &L) {
     WinTaps t;
     t.m = winsize / 2;
     if (t.m + 1 > kMaxWinTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "Gaussian window of %d exceeds %d", winsize, 2 * kMaxWinTaps - 1);
@@ -2033,77 +2191,79 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
     sum = 1. / sum;
     for (int i = 0; i <= t.m; i++) t.k[i] = (float)(t.k[i] * sum);
     const int pitch = plane_pitch(w);
-    float *V = (float *)ctx->fb_vsum.ptr;  // reserved by the caller
     dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-    hipLaunchKernelGGL(gauss_vpass_kernel, grid, block, 0, s, Min, w, h, pitch, t, V);
-    OFXCV_LAUNCH_CHECK(ctx, "gauss_vpass_kernel");
-    if (update)
-        hipLaunchKernelGGL(gauss_hpass_solve_kernel<true>, grid, block, 0, s, R0, R1, (const float *)V, Mout, flow, flow_step, w, h, pitch, t);
-    else
-        hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, R0, R1, (const float *)V, Mout, flow, flow_step, w, h, pitch, t);
-    OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
+    for (int z = 0; z < L.n; z++) {
+        const float *r0 = R0 + (size_t)z * L.planes, *r1 = R1 + (size_t)z * L.planes, *mi = Min + (size_t)z * L.planes;
+        float *mo = Mout + (size_t)z * L.planes, *V = (float *)((double *)ctx->fb_vsum.ptr + (size_t)z * L.vsum);  // reserved by the caller
+        hipLaunchKernelGGL(gauss_vpass_kernel, grid, block, 0, s, mi, w, h, pitch, t, V);
+        OFXCV_LAUNCH_CHECK(ctx, "gauss_vpass_kernel");
+        if (update)
+            hipLaunchKernelGGL(gauss_hpass_solve_kernel<true>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t);
+        else
+            hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t);
+        OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
+    }
     return OFXCV_OK;
 }
 
-// OpenCV-order window with the carries folded into the iteration kernel (winsize 3).  Strip geometry by level size.
+// OpenCV-order window with the carries folded into the iteration kernel (winsize 3).  Strip geometry by level size
+// (of the whole batch: what matters is how many workgroups a launch has).
 struct FoldGeom {
     int rw, nw, tiles_x, nstrips;
 };
-int g_fold_min_tiles = 256;  // A/B knob (option "farneback.fold_min"): 62x64-pixel tiles from which a level counts as large
-bool fold_level_is_large(int w, int h) { return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) >= g_fold_min_tiles; }  // bandwidth-bound level
-int g_fold_rw_override = 0;
-bool g_fold_nw4 = false;  // A/B: 4-wavefront workgroups on the large levels too  // A/B knob (option "farneback.fold_rows"): rows per wavefront on the large levels
-FoldGeom fold_geom(int w, int h) {
+bool fold_level_is_large(const ofxcv_ctx *ctx, int w, int h, int n) {  // bandwidth-bound level
+    return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) * n >= ctx->fb_fold_min_tiles;
+}
+FoldGeom fold_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     FoldGeom g;
     g.tiles_x = ofxcv_div_up(w, kSsW);
-    g.nw = (fold_level_is_large(w, h) && !g_fold_nw4) ? 8 : 4;  // 4 wavefronts per workgroup where 8 would leave CUs without a second workgroup
+    const bool large = fold_level_is_large(ctx, w, h, n);
+    g.nw = (large && !ctx->fb_fold_nw4) ? 8 : 4;  // 4 wavefronts per workgroup where 8 would leave CUs without a second workgroup
     // 4 rows per wavefront: 7 rows of M in registers leave room for the pipelined gather (8 rows: 918 -> 900 pairs/s at 1080p)
-    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) >= 128 ? 4 : 3;
-    if (fold_level_is_large(w, h) && (g_fold_rw_override == 3 || g_fold_rw_override == 8)) g.rw = g_fold_rw_override;
+    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) * n >= 128 ? 4 : 3;
+    if (large && (ctx->fb_fold_rows == 3 || ctx->fb_fold_rows == 8)) g.rw = ctx->fb_fold_rows;
     g.nstrips = ofxcv_div_up(h, g.rw * g.nw);
     return g;
 }
-struct FoldScratch {  // carved from ctx->fb_vsum by the caller
+struct FoldScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles / L.ctr counters further)
     double *K[2], *Spart;
     unsigned *counters;
 };
-FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0) {  // sized for the level-0 geometry (the largest)
-    const FoldGeom g = fold_geom(w0, h0);
+FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
     const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 4) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 12 rows)
-    (void)g;
     FoldScratch fs;
     double *base = (double *)ctx->fb_vsum.ptr;
     fs.K[0] = base;
     fs.K[1] = base + n;
     fs.Spart = base + 2 * n;
-    fs.counters = (unsigned *)(base + 3 * n);
+    fs.counters = (unsigned *)(base + L.vsum * L.n);
     return fs;
 }
-int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot) {
-    const FoldGeom g = fold_geom(w, h);
-    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1};
-    dim3 grid(g.tiles_x, g.nstrips);
+int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot, const Layout &L) {
+    const FoldGeom g = fold_geom(ctx, w, h, L.n);
+    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, ctx->fb_debug_gather};
+    dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
     if (g.nw == 8) {
-        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
-        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa);
+        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
     } else {
-        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa);
+        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
     }
     OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
     if (!fa.scan_in_kernel) {
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.rw * g.nw, fa);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.rw * g.nw, fa, L.planes);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
     }
     return OFXCV_OK;
 }
-int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, float *flow,
-                          size_t flow_step, int w, int h, bool update, const FoldScratch &fs, int kslot) {
-    const FoldGeom g = fold_geom(w, h);
-    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1};
-    dim3 grid(g.tiles_x, g.nstrips);
+int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
+                          int w, int h, bool update, const FoldScratch &fs, int kslot, const Layout &L) {
+    const FoldGeom g = fold_geom(ctx, w, h, L.n);
+    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, ctx->fb_debug_gather};
+    dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
     const double scale = 1. / 9.;
     int rc;
@@ -2112,9 +2272,9 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 #define OFXCV_LAUNCH_FOLD(RW, NW)                                                                                                        \
     do {                                                                                                                                 \
         if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flow, flow_step, w, h, pitch, scale, fa); \
+            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
     } while (0)
     if (g.nw == 8) {
         if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8);
@@ -2129,36 +2289,41 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     if (update && !fa.scan_in_kernel) {
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa, L.planes);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     }
     return OFXCV_OK;
 }
 
-// two fused iterations M -> M'' (winsize 3 only)
+// two fused iterations M -> M'' (winsize 3, direct-window mode), pair by pair
 int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
-                          bool level0) {
+                          bool level0, const Layout &L) {
     dim3 grid(ofxcv_div_up(w, kFtW), ofxcv_div_up(h, kFtH));
-    if (level0)
-        hipLaunchKernelGGL(iterate3x2_kernel<true>, grid, dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h, plane_pitch(w), 1. / 9.);
-    else
-        hipLaunchKernelGGL(iterate3x2_kernel<false>, grid, dim3(kFtThreads), 0, s, R0, R1, Min, Mout, w, h, plane_pitch(w), 1. / 9.);
-    OFXCV_LAUNCH_CHECK(ctx, "iterate3x2_kernel");
+    for (int z = 0; z < L.n; z++) {
+        const size_t o = (size_t)z * L.planes;
+        if (level0)
+            hipLaunchKernelGGL(iterate3x2_kernel<true>, grid, dim3(kFtThreads), 0, s, R0 + o, R1 + o, Min + o, Mout + o, w, h, plane_pitch(w), 1. / 9.);
+        else
+            hipLaunchKernelGGL(iterate3x2_kernel<false>, grid, dim3(kFtThreads), 0, s, R0 + o, R1 + o, Min + o, Mout + o, w, h, plane_pitch(w), 1. / 9.);
+        OFXCV_LAUNCH_CHECK(ctx, "iterate3x2_kernel");
+    }
     return OFXCV_OK;
 }
+
+FlowTab one_flow(float *p, size_t step) {
+    FlowTab t = {};
+    t.p[0] = p;
+    t.step[0] = step;
+    return t;
+}
+Layout one_pair_layout() { return Layout(); }
 
 }  // namespace
 
 extern "C" {
 
 int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
-
-void ofxcv_farneback_set_fold_rows(int rows) {
-    if (rows == 14) g_fold_nw4 = true;
-    else if (rows >= 16) g_fold_min_tiles = rows;  // values from 16 on set the size threshold instead
-    else g_fold_rw_override = rows;
-}  // internal A/B hook (context option "farneback.fold_rows")
 
 int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels) {
     return num_levels(width, height, pyr_scale, levels);
@@ -2178,7 +2343,10 @@ int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step,
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_pyr_image: bad argument");
     int rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(2 * lw + 2) * height));
     if (rc) return rc;
-    return launch_pyr_image(ctx, ofxcv_stream(ctx, stream), d_img, step, width, height, lw, lh, sigma, ksize, (float *)ctx->fb_tmp.ptr, d_I);
+    ImgTab imgs = {};
+    imgs.p[0] = d_img;
+    imgs.step[0] = step;
+    return launch_pyr_image(ctx, ofxcv_stream(ctx, stream), imgs, 1, width, height, lw, lh, sigma, ksize, (float *)ctx->fb_tmp.ptr, d_I, 0);
 }
 
 int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n, double poly_sigma,
@@ -2186,7 +2354,7 @@ int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int hei
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_I || !d_R || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_polyexp: bad argument");
-    return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma);
+    return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma, 1, 0, 0, 0);
 }
 
 int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow, size_t flow_step,
@@ -2196,7 +2364,8 @@ int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const flo
     if (!d_R0 || !d_R1 || !d_flow || !d_M || width <= 0 || height <= 0 || (flow_step & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
     hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
-                       ofxcv_stream(ctx, stream), d_R0, d_R1, d_flow, flow_step, 0, 0, 1.0, 1.0, 1.0, width, height, plane_pitch(width), d_M);
+                       ofxcv_stream(ctx, stream), d_R0, d_R1, one_flow(const_cast<float *>(d_flow), flow_step), 0, 0, 1.0, 1.0, 1.0, width, height,
+                       plane_pitch(width), d_M, (size_t)0);
     OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
     return OFXCV_OK;
 }
@@ -2208,36 +2377,34 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
     if (!d_M_in || width <= 0 || height <= 0 || winsize < 1 || !(winsize & 1) || (d_flow && (flow_step & 7)) ||
         (update && (!d_R0 || !d_R1 || !d_M_out || d_M_out == d_M_in)) || (!update && !d_flow))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_flow_blur: bad argument");
+    Layout L = one_pair_layout();
+    L.vsum = vsum_doubles(width, height);
     if (ctx->fb_opencv_rounding) {
-        int rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * 5 * (size_t)plane_pitch(width) * height);
+        int rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * L.vsum);
         if (rc) return rc;
     }
-    return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, d_flow, flow_step, width, height, winsize, update != 0);
+    return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, one_flow(d_flow, flow_step), width, height, winsize,
+                            update != 0, L);
 }
 
-// The launch sequence of one call.  The pyramid images and polynomial expansions of ALL levels depend only on the
-// two input frames, so they run on the context's preparation stream (coarsest level first) while the main stream
-// walks the levels; an event per level hands R0/R1 over.  The coarse levels cannot fill the chip (a 240x135 level
-// is 127 workgroups on 256 CUs), so their iterations overlap with the preparation of the finer levels.
-static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, const uint8_t *const img[2], const size_t step[2],
-                             float *d_flow, size_t flow_step, int width, int height, double pyr_scale, int levels, int winsize,
+// The launch sequence of one call (n frame pairs).  The pyramid images and polynomial expansions of ALL levels depend only
+// on the input frames, so they run on the context's preparation stream (coarsest level first) while the main stream
+// walks the levels; an event per level hands R0/R1 over.  The coarse levels of a single pair cannot fill the chip (a
+// 240x135 level is 127 workgroups on 256 CUs): their launches are latency-bound, which is what a batch amortises --
+// every launch of the walk carries all n pairs in its grid's z dimension.
+static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, const Layout &L, const ImgTab &imgs, const FlowTab &out,
+                             int width, int height, double pyr_scale, int levels, int winsize,
                              int iterations, int poly_n, double poly_sigma, int flags, bool profile) {
     int rc;
-    // scratch carving (sizes were reserved by the caller)
-    const size_t field0 = 5 * (size_t)plane_pitch(width) * height;
+    const int n = L.n;
+    // scratch carving (sizes were reserved by the caller); pointers are pair 0's
     float *base = (float *)ctx->fb_planes.ptr;
-    float *Mbuf[2] = {base, base + field0};
-    float *Rk = base + 2 * field0;  // R0/R1 of level levels, levels-1, ..., 0 packed one after the other
+    float *Mbuf[2] = {base, base + L.field0};
+    float *Rk = base + 2 * L.field0;  // R0/R1 of level levels, levels-1, ..., 0 packed one after the other
     float *T1 = (float *)ctx->fb_tmp.ptr;
-    float *I = T1 + (size_t)(width + 4) * height;
-    size_t coarse = 0;
-    if (levels > 0) {
-        int lw, lh, ks;
-        double sg;
-        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
-        coarse = (size_t)lw * lh * 2;
-    }
-    float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + coarse};
+    float *I = T1 + L.t1;
+    float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + L.cflow};
+    const size_t pair_cflow = 2 * L.cflow;
 
     // fork: the preparation stream starts once the inputs are ready on the main stream
     OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
@@ -2250,19 +2417,27 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             double sigma;
             level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
             const size_t field = 5 * (size_t)plane_pitch(w) * h;
-            for (int i = 0; i < 2; i++) {
-                R[k][i] = p;
-                p += field;
-                rc = launch_pyr_image(ctx, sp, img[i], step[i], width, height, w, h, sigma, ksz, T1, I);
-                if (rc) return rc;
-                rc = launch_polyexp(ctx, sp, I, w, h, R[k][i], poly_n, poly_sigma);
-                if (rc) return rc;
-            }
+            R[k][0] = p;
+            R[k][1] = p + field;
+            p += 2 * field;
+            rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, I, L.img);
+            if (rc) return rc;
+            rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field);
+            if (rc) return rc;
             OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[k], sp));
         }
     }
-    const float *prev_flow = nullptr;
-    size_t prev_flow_step = 0;
+    auto coarse_tab = [&](float *p0, size_t step) {
+        FlowTab t = {};
+        for (int z = 0; z < n; z++) {
+            t.p[z] = p0 + (size_t)z * pair_cflow;
+            t.step[z] = step;
+        }
+        return t;
+    };
+    const FlowTab no_flow = {};
+    FlowTab prev_tab = {};
+    bool have_prev = false;
     int pw = 0, ph = 0;
     for (int k = levels; k >= 0; k--) {
         int w, h, ksz;
@@ -2270,39 +2445,37 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
         const int pitch = plane_pitch(w);
-        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
-        if (!prev_flow && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
+        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4), n), block(64, 4);
+        if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
             // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
-            const float *init = d_flow;
-            size_t init_step = flow_step;
+            FlowTab init = out;
             if (k > 0) {
                 double scale = 1;
                 for (int i = 0; i < k; i++) scale *= pyr_scale;
-                float *top = cflow[(k & 1) ^ 1];
-                hipLaunchKernelGGL(initial_flow_kernel, grid, block, 0, s, (const float *)d_flow, flow_step, width, height, top, w, h, scale);
-                OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
-                init = top;
-                init_step = (size_t)w * 8;
+                init = coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8);
+                for (int z = 0; z < n; z++) {
+                    hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z], out.step[z], width, height, init.p[z], w, h, scale);
+                    OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
+                }
             }
-            hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R[k][0], R[k][1], init, init_step, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0]);
-        } else if (!prev_flow)
-            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], (const float *)nullptr, (size_t)0, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0]);
+            hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R[k][0], R[k][1], init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0], L.planes);
+        } else if (!have_prev)
+            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0], L.planes);
         else
-            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_flow, prev_flow_step, pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, w, h, pitch, Mbuf[0]);
+            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_tab, pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, w, h, pitch, Mbuf[0], L.planes);
         OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
-        float *out_flow = k == 0 ? d_flow : cflow[k & 1];
-        size_t out_step = k == 0 ? flow_step : (size_t)w * 8;
+        const FlowTab out_tab = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         int cur = 0;
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
         const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries &&
-                          (ctx->fb_fold_carries != 3 || fold_level_is_large(w, h));  // 3: only the levels that are bandwidth-bound
+                          (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, n));  // 3: only the levels that are bandwidth-bound
         FoldScratch fs = {};
         if (fold) {
-            fs = fold_scratch(ctx, width, height);
-            if (k == levels) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fs.counters, 0, sizeof(unsigned) * (ofxcv_div_up(width, kSsW) + 1), s));
-            rc = launch_fold_seed(ctx, s, Mbuf[0], w, h, fs, 0);
+            fs = fold_scratch(ctx, width, height, L);
+            if (k == levels) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fs.counters, 0, sizeof(unsigned) * (size_t)L.ctr * n, s));
+            rc = launch_fold_seed(ctx, s, Mbuf[0], w, h, fs, 0, L);
             if (rc) return rc;
         }
         for (int i = 0; i < iterations;) {
@@ -2312,16 +2485,17 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             ctx->prof_now = inner;
             if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             if (pair) {  // two updating iterations in one launch
-                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h, k == 0);
+                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h, k == 0, L);
                 i += 2;
             } else {
                 bool update = i < iterations - 1;
+                const FlowTab &ft = update ? no_flow : out_tab;
                 if (gaussian)
-                    rc = launch_gauss_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                    rc = launch_gauss_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, winsize, update, L);
                 else if (fold)
-                    rc = launch_fold_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, update, fs, cur);
+                    rc = launch_fold_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, update, fs, cur, L);
                 else
-                    rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], update ? nullptr : out_flow, out_step, w, h, winsize, update);
+                    rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, winsize, update, L);
                 i += 1;
             }
             ctx->prof_now = false;
@@ -2329,22 +2503,27 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
             cur ^= 1;
         }
-        prev_flow = out_flow;
-        prev_flow_step = out_step;
+        prev_tab = out_tab;
+        have_prev = true;
         pw = w;
         ph = h;
     }
     return OFXCV_OK;
 }
 
-int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step, const uint8_t *d_next,
-                                      size_t next_step, float *d_flow, size_t flow_step, int width, int height, double pyr_scale,
-                                      int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
+int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t *const *d_prev, const size_t *prev_step,
+                                            const uint8_t *const *d_next, const size_t *next_step, float *const *d_flow,
+                                            const size_t *flow_step, int width, int height, double pyr_scale, int levels, int winsize,
+                                            int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
-    if (!d_prev || !d_next || !d_flow || width <= 0 || height <= 0 || prev_step < (size_t)width || next_step < (size_t)width ||
-        flow_step < (size_t)width * 8 || (flow_step & 7) || (((uintptr_t)d_flow) & 7))
+    if (n < 1 || n > kMaxBatch) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: batch of %d pairs outside 1..%d", n, kMaxBatch);
+    if (!d_prev || !prev_step || !d_next || !next_step || !d_flow || !flow_step || width <= 0 || height <= 0)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument");
+    for (int z = 0; z < n; z++)
+        if (!d_prev[z] || !d_next[z] || !d_flow[z] || prev_step[z] < (size_t)width || next_step[z] < (size_t)width ||
+            flow_step[z] < (size_t)width * 8 || (flow_step[z] & 7) || (((uintptr_t)d_flow[z]) & 7))
+            return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument (pair %d)", z);
     if (flags & ~(OFXCV_OPTFLOW_USE_INITIAL_FLOW | OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN))
         return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: flags 0x%x not supported (USE_INITIAL_FLOW, FARNEBACK_GAUSSIAN)", flags);
     if (!(pyr_scale > 0 && pyr_scale < 1) || levels < 0 || iterations < 1 || winsize < 1 || !(winsize & 1))
@@ -2353,52 +2532,60 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
     if ((size_t)plane_pitch(width) * height * 20 >= (size_t)1 << 31)
         return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: frames above %d pixels exceed the 32-bit buffer offsets",
                           (int)(((size_t)1 << 31) / 20));
+    if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
     hipStream_t s = ofxcv_stream(ctx, stream);
-    const uint8_t *img[2] = {d_prev, d_next};
-    const size_t step[2] = {prev_step, next_step};
     levels = num_levels(width, height, pyr_scale, levels);
     if (levels > kMaxLevels) levels = kMaxLevels;
 
-    // scratch: M ping + M pong (level-0 size) + R0/R1 of every level, blur rows + one pyramid image, two coarse flows
-    size_t rtotal = 0;
-    for (int k = levels; k >= 0; k--) {
-        int w, h, ksz;
-        double sigma;
-        level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
-        if (ksz > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksz, kMaxGaussTaps);
-        rtotal += 2 * 5 * (size_t)plane_pitch(w) * h;
-    }
-    if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
-    const size_t field0 = 5 * (size_t)plane_pitch(width) * height;
-    int rc = ofxcv_reserve(ctx, ctx->fb_planes, sizeof(float) * (2 * field0 + rtotal));
+    // scratch per pair: M ping + M pong (level-0 size) + R0/R1 of every level, two coarse flows, the f64 column-sum scratch;
+    // per frame: one pyramid image; shared: the row buffer of the two-pass pyramid fall-back
+    Layout L;
+    int rc = make_layout(ctx, n, width, height, pyr_scale, levels, L);
     if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(width + 4) * height + (size_t)width * height));
+    rc = ofxcv_reserve(ctx, ctx->fb_planes, L.planes_bytes());
+    if (rc) return rc;
+    rc = ofxcv_reserve(ctx, ctx->fb_tmp, L.tmp_bytes());
     if (rc) return rc;
     if (levels > 0) {
-        int lw, lh, ks;
-        double sg;
-        level_geom(width, height, pyr_scale, 1, lw, lh, sg, ks);
-        rc = ofxcv_reserve(ctx, ctx->fb_flow, sizeof(float) * 4 * (size_t)lw * lh);
+        rc = ofxcv_reserve(ctx, ctx->fb_flow, L.flow_bytes());
         if (rc) return rc;
     }
-    if (ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
-        rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * field0);
+    const bool need_vsum = ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN);
+    if (need_vsum) {
+        rc = ofxcv_reserve(ctx, ctx->fb_vsum, L.vsum_bytes());
         if (rc) return rc;
     }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;
     hipStream_t sp = ctx->fb_one_stream ? s : ctx->prep;
 
-    // hipGraph replay: the ~90 launches of a call are captured once per (pointers, geometry, parameters) and replayed
-    // with one hipGraphLaunch (host launch cost 0.55 ms -> ~0.02 ms per call).  The measurement hook needs its event
-    // pairs between launches and therefore uses the eager path.
+    ImgTab imgs = {};
+    FlowTab out = {};
+    for (int z = 0; z < n; z++) {
+        imgs.p[2 * z] = d_prev[z];
+        imgs.step[2 * z] = prev_step[z];
+        imgs.p[2 * z + 1] = d_next[z];
+        imgs.step[2 * z + 1] = next_step[z];
+        out.p[z] = d_flow[z];
+        out.step[z] = flow_step[z];
+    }
+
+    // hipGraph replay: the launches of a call are captured once per (pointers, geometry, parameters) and replayed
+    // with one hipGraphLaunch.  The measurement hook needs its event pairs between launches and therefore uses the eager path.
     const bool use_graph = !ctx->prof_on && !ctx->fb_no_graph;
     if (!use_graph)
-        return enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations,
-                                 poly_n, poly_sigma, flags, ctx->prof_on != 0);
-    FbGraphKey key = {d_prev, d_next, d_flow, prev_step, next_step, flow_step, width, height, levels, winsize, iterations, poly_n, flags, 0,
-                      pyr_scale, poly_sigma, ctx->fb_planes.ptr, ctx->fb_tmp.ptr, ctx->fb_flow.ptr,
-                      (ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) ? ctx->fb_vsum.ptr : nullptr};
+        return enqueue_farneback(ctx, s, sp, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags,
+                                 ctx->prof_on != 0);
+    FbGraphKey key;
+    std::memset(&key, 0, sizeof(key));
+    key.n = n;
+    key.width = width; key.height = height; key.levels = levels; key.winsize = winsize; key.iterations = iterations; key.poly_n = poly_n; key.flags = flags;
+    key.pyr_scale = pyr_scale; key.poly_sigma = poly_sigma;
+    key.planes = ctx->fb_planes.ptr; key.tmp = ctx->fb_tmp.ptr; key.cflow = ctx->fb_flow.ptr; key.vsum = need_vsum ? ctx->fb_vsum.ptr : nullptr;
+    for (int z = 0; z < n; z++) {
+        key.prev[z] = d_prev[z]; key.next[z] = d_next[z]; key.flow[z] = d_flow[z];
+        key.prev_step[z] = prev_step[z]; key.next_step[z] = next_step[z]; key.flow_step[z] = flow_step[z];
+    }
     FbGraph *g = nullptr;
     for (FbGraph &c : ctx->fb_graphs)
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
@@ -2408,18 +2595,17 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         // its own context: allocations, synchronising copies) must not be able to invalidate this capture.  If the
         // capture cannot be completed anyway, the call falls back to plain launches and stops using graphs.
         hipGraph_t graph = nullptr;
-        // one capture at a time per process, and no device allocation / free / context teardown of another host thread
+        // one capture at a time per device, and no device allocation / free / context teardown of another host thread
         // during it (ofxcv_capture_mutex): either was seen to invalidate a capture on ROCm 7.2.  Launches, copies
         // and graph replays of other threads stay concurrent.
-        std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex());
+        std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex(ctx->device));
         if (slot->exec) {  // evicted entry: destroyed under the exclusive lock (see common.h)
             (void)hipGraphExecDestroy(slot->exec);
             slot->exec = nullptr;
         }
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
-            rc = enqueue_farneback(ctx, s, sp, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
-                                   poly_sigma, flags, false);
+            rc = enqueue_farneback(ctx, s, sp, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false);
             ok = hipStreamEndCapture(s, &graph) == hipSuccess && rc == OFXCV_OK && graph != nullptr;
             if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
@@ -2433,10 +2619,8 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
             ctx->fb_no_graph = true;
             ctx->fb_one_stream = true;
             ctx->err[0] = 0;
-            return enqueue_farneback(ctx, s, s, img, step, d_flow, flow_step, width, height, pyr_scale, levels, winsize, iterations, poly_n,
-                                     poly_sigma, flags, false);
+            return enqueue_farneback(ctx, s, s, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false);
         }
-        std::memset(&slot->key, 0, sizeof(slot->key));
         slot->key = key;
         g = slot;
     }
@@ -2444,10 +2628,18 @@ int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, siz
         // exclusive as well: two threads inside hipGraphLaunch at once (different graph execs, different streams) crashed in
         // hip::Graph::UpdateStreams on ROCm 7.2 -- about 1 in 30 runs of four concurrent render threads, backtrace under
         // rocgdb with every other locked operation parked on this lock
-        std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex());
+        std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex(ctx->device));
         OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
     }
     return OFXCV_OK;
+}
+
+int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step, const uint8_t *d_next,
+                                      size_t next_step, float *d_flow, size_t flow_step, int width, int height, double pyr_scale,
+                                      int levels, int winsize, int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
+    // a batch of one: the same launch sequence with a grid z of 1
+    return ofxcv_calc_optical_flow_farneback_batch(ctx, 1, &d_prev, &prev_step, &d_next, &next_step, &d_flow, &flow_step, width, height, pyr_scale,
+                                                   levels, winsize, iterations, poly_n, poly_sigma, flags, stream);
 }
 
 }  // extern "C"

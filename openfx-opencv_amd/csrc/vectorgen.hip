@@ -7,8 +7,8 @@
 //    host's own buffers are registered with the driver for the duration of the call (hipHostRegister: 0.2 ms per 1080p
 //    frame, no cache -- a registration does not survive the host freeing and re-allocating the addresses), the copy
 //    engine reads the f32 frames in place (no staging memcpy), and one kernel stores the four flow channels of both
-//    directions straight into the host's destination image.  The backward flow runs on a sibling context beside the
-//    forward one.
+//    directions straight into the host's destination image.  The forward and the backward flow of an output frame
+//    run as ONE batched Farneback call (two pairs per launch).
 //  * pinned ring (everything else: bottom-up / oddly strided images, partial channel maps, registration refused,
 //    option "host.register" 0): the frames are copied in row blocks into a pinned ring and sent to HBM with
 //    hipMemcpyAsync on the copy stream while the compute stream converts the previous frame; only the flow (8 B/px)
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ fl
 
 int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_pinned_bytes) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
     if (ctx->h_pinned) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
@@ -124,10 +124,12 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // pointing at the old pages (measured: a pointer-keyed cache produced wrong frames with numpy-allocated buffers).
 // Register / unregister take the exclusive runtime lock like every other memory operation.
 struct HostRegistrations {
+    ofxcv_ctx *ctx;
     void *p[4];
     int n = 0;
+    explicit HostRegistrations(ofxcv_ctx *c) : ctx(c) {}
     bool add(const void *ptr, size_t bytes) {
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
         if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
             (void)hipGetLastError();  // e.g. already registered by the host application itself (or by another render thread
             return false;             // reading the same source frame): this call stages through the ring
@@ -135,9 +137,14 @@ struct HostRegistrations {
         p[n++] = const_cast<void *>(ptr);
         return true;
     }
+    // Every way out of the call -- error returns included -- passes here: whatever the call still has in flight (DMA out of
+    // the registered frames, the kernel that stores into the registered destination) is waited for BEFORE the ranges are
+    // unregistered, so a failed call returns its error instead of leaving the GPU writing to unpinned pages.
     ~HostRegistrations() {
         if (!n) return;
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex());
+        (void)hipStreamSynchronize(ctx->copy);
+        (void)hipStreamSynchronize(ctx->compute);
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
         for (int i = 0; i < n; i++) (void)hipHostUnregister(p[i]);
         (void)hipGetLastError();
     }
@@ -192,7 +199,7 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     // than the ring's flow download + host scatter.
     if (cm.k[0] < 0 || cm.k[1] < 0 || cm.k[2] < 0 || cm.k[3] < 0 || dst_row_bytes < (ptrdiff_t)drow || ((uintptr_t)h_dst & 15) || (dst_row_bytes & 15))
         return kNotRegistered;
-    HostRegistrations regs;  // unregisters when the call returns; every return below happens with nothing in flight
+    HostRegistrations regs(ctx);  // waits for the call's streams, then unregisters, on every return below
     const size_t frame = align_up(row * height, 256), gray_pitch = align_up((size_t)width, 256), gray = gray_pitch * height,
                  flow_bytes = align_up((size_t)width * height * 8, 256);
     int rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes);
@@ -208,59 +215,30 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     // registration of frame f+1 (0.2 ms of host time) overlaps the DMA of frame f; the destination is registered last,
     // while the GPU computes.
     for (int f = 0; f < nf; f++) {
-        if (!regs.add(src[f], (size_t)(height - 1) * src_rb[f] + row)) {
-            (void)hipStreamSynchronize(ctx->copy);
-            return kNotRegistered;
-        }
+        if (!regs.add(src[f], (size_t)(height - 1) * src_rb[f] + row)) return kNotRegistered;
         if ((size_t)src_rb[f] == row)  // contiguous rows: one linear DMA
             OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + f * frame, src[f], row * height, hipMemcpyHostToDevice, ctx->copy));
         else
             OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(dp + f * frame, row, src[f], (size_t)src_rb[f], row, height, hipMemcpyHostToDevice, ctx->copy));
         OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
     }
-    // The two flows of an output frame are independent: the second one runs on a sibling context (its own Farneback
-    // scratch and streams) concurrently with the first -- one flow alone does not fill the device.
-    ofxcv_ctx *c2 = nullptr;
-    if (n_other > 1) {
-        if (!ctx->sibling && ofxcv_ctx_create(ctx->device, &ctx->sibling) != OFXCV_OK) ctx->sibling = nullptr;
-        c2 = ctx->sibling;
-        if (c2 && (c2->fb_opencv_rounding != ctx->fb_opencv_rounding || c2->fb_no_graph != ctx->fb_no_graph)) {
-            (void)ofxcv_ctx_set_option(c2, "farneback.opencv_rounding", ctx->fb_opencv_rounding);
-            (void)ofxcv_ctx_set_option(c2, "farneback.graph", ctx->fb_no_graph ? 0 : 1);
-        }
-    }
-    auto sync_all = [&]() {
-        (void)hipStreamSynchronize(ctx->copy);
-        (void)hipStreamSynchronize(ctx->compute);
-        if (c2) (void)hipStreamSynchronize(c2->compute);
-    };
     for (int f = 0; f < nf; f++) {
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
         rc = ofxcv_to_byte_grayscale(ctx, (const float *)(dp + f * frame), (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
-        if (rc) { sync_all(); return rc; }
-        if (f == 0) continue;
-        ofxcv_ctx *fc = (f == 2 && c2) ? c2 : ctx;
-        if (fc != ctx) {  // hand gray[0] / gray[2] over to the sibling's stream
-            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));
-            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(fc->compute, ctx->ev_done, 0));
-        }
-        // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
-        rc = ofxcv_calc_optical_flow_farneback(fc, d_gray[0], gray_pitch, d_gray[f], gray_pitch, d_flow[f - 1], (size_t)width * 8, width, height,
-                                               0.5, levels, 3, iterations, poly_n, poly_sigma, 0, fc->compute);
-        if (rc) {
-            if (fc != ctx) std::snprintf(ctx->err, sizeof(ctx->err), "%s", fc->err);
-            sync_all();
-            return rc;
-        }
-        if (fc != ctx) {  // join: the write-back on the main stream waits for the sibling's flow
-            OFXCV_HIP_CHECK(ctx, hipEventRecord(fc->ev_done, fc->compute));
-            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, fc->ev_done, 0));
-        }
+        if (rc) return rc;
+    }
+    // The two flows of an output frame are independent pairs with the same first frame: one batched call (every launch of
+    // the level walk carries both).  VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+    {
+        const uint8_t *prevs[2] = {d_gray[0], d_gray[0]}, *nexts[2] = {d_gray[1], n_other > 1 ? d_gray[2] : nullptr};
+        const size_t gsteps[2] = {gray_pitch, gray_pitch}, fsteps[2] = {(size_t)width * 8, (size_t)width * 8};
+        rc = ofxcv_calc_optical_flow_farneback_batch(ctx, n_other, prevs, gsteps, nexts, gsteps, d_flow, fsteps, width, height, 0.5, levels, 3,
+                                                     iterations, poly_n, poly_sigma, 0, ctx->compute);
+        if (rc) return rc;
     }
     void *d_dst = nullptr;
     if (!regs.add(h_dst, (size_t)(height - 1) * dst_row_bytes + drow) || hipHostGetDevicePointer(&d_dst, h_dst, 0) != hipSuccess || !d_dst) {
         (void)hipGetLastError();
-        sync_all();
         return kNotRegistered;  // the destination cannot be addressed by the kernel: the ring path serves the call
     }
     hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
@@ -268,7 +246,6 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     OFXCV_LAUNCH_CHECK(ctx, "flows_to_rgba_kernel");
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy));
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
-    if (c2) OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(c2->compute));
     ctx->host_zero_copy_calls++;
     return OFXCV_OK;  // `regs` unregisters the host ranges here: nothing of this call is in flight any more
 }

@@ -392,3 +392,70 @@ def test_farneback_unaligned_sources(oracle, ofxcv, direct_ctx):
     pb.copy_(_dev(gb))
     got = direct_ctx.calc_optical_flow_farneback(pa, pb).cpu().numpy()
     assert np.array_equal(got, oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT))
+
+
+# ---- batched calls (ofxcv_calc_optical_flow_farneback_batch: BASELINE configs[4] batches pairs per GPU; a default
+# VectorGenerator output frame is a batch of two, VectorGenerator.cpp:597-638) ----
+
+def _pairs(oracle, w, h, seeds):
+    return [_gray_pair(oracle, w, h, seed) for seed in seeds]
+
+
+@pytest.mark.parametrize("w,h,n", [(64, 48, 3), (333, 257, 3), (640, 480, 5), (125, 70, 16), (1920, 1080, 3)])
+def test_batch_equals_single_calls_bit_for_bit(oracle, ofxcv, w, h, n):
+    """n DIFFERENT pairs in one batched call (every launch of the level walk carries all of them in its grid's z dimension)
+    give, bit for bit, the flows of n single calls -- and the first pair is within tolerance of the faithful oracle at every
+    sample.  Twice: the captured graph is replayed the second time."""
+    prs = _pairs(oracle, w, h, range(100, 100 + n))
+    single = ofxcv.Context(0)
+    batch = ofxcv.Context(0)
+    singles = [single.calc_optical_flow_farneback(_dev(a), _dev(b)).cpu().numpy() for a, b in prs]
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    for _ in range(2):
+        flows = batch.calc_optical_flow_farneback_batch(da, db)
+        got = [f.cpu().numpy() for f in flows]
+        for z in range(n):
+            assert np.array_equal(got[z], singles[z]), "pair %d of %d: max diff %g" % (z, n, np.abs(got[z] - singles[z]).max())
+    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL)
+    assert (np.abs(got[0] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
+    single.close()
+    batch.close()
+
+
+def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
+    """forward + backward flow of one reference frame (two pairs that share their first image) as a batch, in every
+    evaluation mode of the window (OpenCV order with each carry form, serial scan, direct sums, other window size,
+    Gaussian window): identical to single calls"""
+    w, h = 333, 257
+    (a, b), (_, c) = _pairs(oracle, w, h, (5, 6))
+    da, db, dc = _dev(a), _dev(b), _dev(c)
+    cases = [dict(opts=dict(opencv_rounding=1, fold_carries=f)) for f in (0, 1, 2, 3)]
+    cases += [dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
+              dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
+              dict(opts=dict(opencv_rounding=1, fold_carries=2, fold_min=1)), dict(opts=dict(opencv_rounding=1, fold_carries=1, fold_min=1))]
+    for case in cases:
+        ctx = ofxcv.Context(0)
+        for k, v in case["opts"].items():
+            ctx.set_option("farneback." + k, v)
+        kw = case.get("kw", {})
+        s0 = ctx.calc_optical_flow_farneback(da, db, **kw).cpu().numpy()
+        s1 = ctx.calc_optical_flow_farneback(da, dc, **kw).cpu().numpy()
+        f0, f1 = ctx.calc_optical_flow_farneback_batch([da, da], [db, dc], **kw)
+        assert np.array_equal(f0.cpu().numpy(), s0) and np.array_equal(f1.cpu().numpy(), s1), case
+        ctx.close()
+
+
+def test_batch_initial_flow_and_argument_checks(oracle, ofxcv):
+    w, h = 320, 240
+    prs = _pairs(oracle, w, h, (1, 2, 3))
+    rng = np.random.default_rng(3)
+    inits = [rng.normal(0, 2, size=(h, w, 2)).astype(np.float32) for _ in prs]
+    ctx = ofxcv.Context(0)
+    singles = [ctx.calc_optical_flow_farneback(_dev(a), _dev(b), _dev(i0), flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW).cpu().numpy() for (a, b), i0 in zip(prs, inits)]
+    flows = ctx.calc_optical_flow_farneback_batch([_dev(a) for a, _ in prs], [_dev(b) for _, b in prs], [_dev(i0) for i0 in inits],
+                                                  flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)
+    for f, s in zip(flows, singles):
+        assert np.array_equal(f.cpu().numpy(), s)
+    with pytest.raises(ofxcv.OfxcvError):   # more pairs than the pointer tables hold
+        ctx.calc_optical_flow_farneback_batch([_dev(prs[0][0])] * 17, [_dev(prs[0][1])] * 17)
+    ctx.close()
