@@ -71,6 +71,9 @@ struct ofxcv_ctx {
     // 4-wavefront workgroups on the large levels too
     int fb_fold_min_tiles = 256, fb_fold_rows = 0;
     bool fb_fold_nw4 = false;
+    int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
+    int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
+                                 // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one
     int fb_debug_gather = 0;     // timing experiments only (wrong results): see FoldArgs::dbg
 
     // inpaint scratch

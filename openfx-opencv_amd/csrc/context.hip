@@ -230,8 +230,16 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->fb_fold_min_tiles = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.batch_mb")) {
+        ctx->fb_batch_mb = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.debug_gather")) {
         ctx->fb_debug_gather = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.fold_strip")) {
+        ctx->fb_fold_strip = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.fold_nw4")) {

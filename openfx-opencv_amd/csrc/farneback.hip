@@ -1566,6 +1566,7 @@ struct FoldArgs {
     int scan_in_kernel;   // 1: the last workgroup of a tile column runs the prefix over the strips itself; 0: fold_scan_kernel does
     size_t pair_vsum;     // batched calls: doubles between the Kin / Kout / Spart of consecutive pairs
     unsigned pair_ctr;    //                counters between consecutive pairs
+    int sh;               // rows per strip (= rows per wavefront x wavefronts, or anything above (rows - 1) x wavefronts: wave_rows)
     int dbg;              // timing experiments only (option "farneback.debug_gather"; results are wrong when set): 1 no R1 gather, 2 gather at zero flow
     __device__ __forceinline__ void select_pair(int z) {
         if (Kin) Kin += (size_t)z * pair_vsum;
@@ -1728,8 +1729,25 @@ __global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__r
     }
 }
 
+// Rows of a strip over the wavefronts of its workgroup.  A strip of `sh` rows (NW*(RW-1) < sh <= NW*RW) is cut into NW
+// wavefronts of RW-1 or RW rows: the first sh - NW*(RW-1) wavefronts take RW.  With sh = NW*RW every wavefront has RW rows
+// (VAR = false: known at compile time).  The strip height is free because the launch should not end with a nearly empty
+// round of workgroups: 1080 rows in 32-row strips are 34 x 31 = 1054 workgroups on 512 resident slots (two full rounds and
+// a third of 30 workgroups, 5.5 us of 41); in 33-row strips they are 33 x 31 = 1023.
+template <int RW, int NW, bool VAR>
+__device__ __forceinline__ void wave_rows(int sh, int wave, int &off, int &nr) {
+    if (!VAR) {
+        off = wave * RW;
+        nr = RW;
+        return;
+    }
+    const int extra = sh - NW * (RW - 1);
+    off = wave * (RW - 1) + min(wave, extra);
+    nr = RW - 1 + (wave < extra ? 1 : 0);
+}
+
 // carries of a field that already lies in memory (the first M of a pyramid level)
-template <int RW, int NW>
+template <int RW, int NW, bool VAR>
 __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, FoldArgs fa, size_t pair_stride) {
     __shared__ double s_w[NW][5][64];
     __shared__ unsigned s_flag;
@@ -1740,8 +1758,10 @@ __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    constexpr int SH = RW * NW;
-    const int A = tby * SH, a = A + wave * RW;
+    const int SH = VAR ? fa.sh : RW * NW;
+    int off, nr;
+    wave_rows<RW, NW, VAR>(SH, wave, off, nr);
+    const int A = tby * SH, a = A + off;
     const size_t plane = (size_t)pitch * h;
     // rows a-3 .. a+RW-1: the differences with the later row inside this wavefront's rows
     float m[RW + 3][5];
@@ -1757,7 +1777,7 @@ __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restr
             // t = a+j-1: rows a+j and a+j-3.  The first three of a strip belong to the strip boundary (fold_scan), except
             // at the top of the image, where rows above 0 are row 0: t = 0, 1 are (row 1 - row 0), (row 2 - row 0).
             const int row = a + j;
-            if (row >= h || row - 1 < 0) continue;                   // t = row - 1 >= 0
+            if (j >= nr || row >= h || row - 1 < 0) continue;        // t = row - 1 >= 0
             if (wave == 0 && j < 3 && A > 0) continue;
             sum += (double)(m[j + 3][c] - m[j][c]);
         }
@@ -1766,13 +1786,13 @@ __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restr
     fold_finish<NW>(M, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
 }
 
-template <bool UPDATE, int RW, int NW>
+template <bool UPDATE, int RW, int NW, bool VAR>
 __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                            const float *__restrict__ Min, float *__restrict__ Mout,
                                                            FlowTab flows, int w, int h, int pitch, double scale,
                                                            FoldArgs fa, size_t pair_stride) {
     constexpr bool PIPE = RW < 8;  // with 8 rows per wavefront the second in-flight pixel record does not fit 128 registers
-    static_assert(RW >= 3, "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
+    static_assert(RW >= 3 && (!VAR || RW >= 4), "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
     __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
     __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
     __shared__ unsigned s_flag;
@@ -1787,8 +1807,10 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     const size_t flow_step = flows.step[tbz];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int x0 = tbx * kSsW;
-    constexpr int SH = RW * NW;
-    const int A = tby * SH, a = A + wave * RW;
+    const int SH = VAR ? fa.sh : RW * NW;
+    int off, nr;  // this wavefront's rows inside the strip (wave-uniform)
+    wave_rows<RW, NW, VAR>(SH, wave, off, nr);
+    const int A = tby * SH, a = A + off;
     const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
     const size_t plane = (size_t)pitch * h;
@@ -1796,10 +1818,15 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
               bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
 
-    // rows a-2 .. a+RW of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
+    // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
     float m[RW + 3][5];
 #pragma unroll
     for (int r = 0; r < RW + 3; r++) {
+        if (VAR && r == RW + 2 && nr < RW) {  // a short wavefront has no use for the last row
+#pragma unroll
+            for (int c = 0; c < 5; c++) m[r][c] = 0.f;
+            continue;
+        }
         const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
         for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
@@ -1807,12 +1834,18 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     double D[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) D[c] = fa.Kin[((size_t)tby * 5 + c) * pitch + x];
+    // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
+    float d[RW][5];
+#pragma unroll
+    for (int j = 0; j < RW; j++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) d[j][c] = m[j + 3][c] - m[j][c];
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         double t = 0.;
 #pragma unroll
         for (int j = 0; j < RW; j++)
-            if (a + j < h) t += (double)(m[j + 3][c] - m[j][c]);
+            if (j < nr && a + j < h) t += (double)d[j][c];
         s_w[wave][c][lane] = t;
     }
     __syncthreads();
@@ -1835,7 +1868,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             mo[j][c] = mm.v[c];
-            if (own) {
+            if (own && !(fa.dbg & 8)) {
                 if (fa.scan_in_kernel) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
                 else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
             }
@@ -1848,15 +1881,15 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 #pragma unroll
     for (int j = 0; j < RW; j++) {
         const int y = a + j;
-        if (y >= h) break;  // wave-uniform
+        if (j >= nr || y >= h) break;  // wave-uniform
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            D[c] += (double)(m[j + 3][c] - m[j][c]);  // the reference's vsum[x] += srow1[x] - srow0[x]
+            D[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
             acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
         }
         double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        double idet = (fa.dbg & 16) ? 1e-3 : 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
         float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
         float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
         if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
@@ -1865,13 +1898,13 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
             cur.fxv = fxv;
             cur.fyv = fyv;
 #pragma unroll
-            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            if (fa.dbg == 1) {
+            for (int c = 0; c < 5; c++) cur.r0v[c] = (fa.dbg & 64) ? 1.f : buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+            if ((fa.dbg & 3) == 1) {
                 cur.tp = Taps();
                 cur.tp.inb = true;
                 cur.tp.fx = cur.tp.fy = 0.5f;
             } else {
-                cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fa.dbg == 2 ? 0.f : fxv, fa.dbg == 2 ? 0.f : fyv);
+                cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, (fa.dbg & 3) == 2 ? 0.f : fxv, (fa.dbg & 3) == 2 ? 0.f : fyv);
             }
             if (PIPE) {  // the gather of row j is in flight while row j-1 is finished
                 if (j > 0) finish(prev, j - 1);
@@ -1882,12 +1915,13 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
         }
     }
     if (!UPDATE) return;
+    if (fa.dbg & 32) return;  // (every wavefront of the launch: no barrier is left waiting)
+    const int nre = min(nr, h - a);  // rows of this wavefront inside the image (<= 0: none, bottom strip only)
     if (PIPE) {
-        const int nr = min(RW, h - a);  // rows of this wavefront inside the image (<= 0: none, bottom strip only)
-        if (nr > 0) {
+        if (nre > 0) {
 #pragma unroll
             for (int j = 0; j < RW; j++)
-                if (j == nr - 1) finish(prev, j);
+                if (j == nre - 1) finish(prev, j);
         }
     }
     __syncthreads();  // every wavefront's first three rows are in LDS
@@ -1897,14 +1931,19 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     for (int c = 0; c < 5; c++) {
         double sum = I[c];
         if (wave < NW - 1) {
-            sum += (double)(s_first[wave + 1][0][c][lane] - mo[RW - 3][c]);
-            sum += (double)(s_first[wave + 1][1][c][lane] - mo[RW - 2][c]);
-            sum += (double)(s_first[wave + 1][2][c][lane] - mo[RW - 1][c]);
+            // this wavefront's last three rows (a short wavefront's are one index earlier)
+            const bool full = !VAR || nr == RW;
+            const float l0 = full ? mo[RW - 3][c] : mo[RW >= 4 ? RW - 4 : 0][c], l1 = full ? mo[RW - 2][c] : mo[RW - 3][c],
+                        l2 = full ? mo[RW - 1][c] : mo[RW - 2][c];
+            sum += (double)(s_first[wave + 1][0][c][lane] - l0);
+            sum += (double)(s_first[wave + 1][1][c][lane] - l1);
+            sum += (double)(s_first[wave + 1][2][c][lane] - l2);
         }
         s_w[wave][c][lane] = sum;
     }
     fold_finish<NW>(Mout, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
 }
+
 
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
@@ -1945,6 +1984,8 @@ struct Layout {
     size_t cflow = 0;      // floats of ONE coarse flow field (two per pair)
     size_t vsum = 0;       // doubles between the column-sum scratch of consecutive pairs
     unsigned ctr = 0;      // fold counters per pair (after the column-sum scratch of all pairs)
+    double *vsum_ptr = nullptr;    // column-sum scratch / fold counters of the first pair of the launch group (set by the level walk)
+    unsigned *ctr_ptr = nullptr;
     size_t planes_bytes() const { return sizeof(float) * planes * n; }
     size_t tmp_bytes() const { return sizeof(float) * (t1 + 2 * (size_t)n * img); }
     size_t flow_bytes() const { return sizeof(float) * 2 * cflow * n; }
@@ -2097,7 +2138,7 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
             rw = nt * ofxcv_div_up(h, 8) >= 4096 ? 8 : (nt * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
         }
         const int nstrips = ofxcv_div_up(h, rw), G = std::max(ofxcv_div_up(nstrips, 16 * kSsSPW), std::min(ctx->fb_carry_groups, 8)), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
-        double *carry = (double *)ctx->fb_vsum.ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
+        double *carry = L.vsum_ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
         dim3 cgrid(ofxcv_div_up(w, 64), 5 * L.n, G), grid(ofxcv_div_up(tiles_x, 2), nstrips, L.n);
 #define OFXCV_LAUNCH_SS(RW)                                                                                                              \
     do {                                                                                                                                 \
@@ -2136,7 +2177,7 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         float *mo = Mout ? Mout + (size_t)z * L.planes : nullptr, *flow = flows.p[z];
         const size_t flow_step = flows.step[z];
         if (ctx->fb_opencv_rounding && winsize == 3) {  // 2: the serial column scan (cross-check of the strip-parallel form)
-            double *V = (double *)ctx->fb_vsum.ptr + (size_t)z * L.vsum;  // reserved by the caller
+            double *V = L.vsum_ptr + (size_t)z * L.vsum;  // reserved by the caller
             hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, mi, w, h, pitch, V);
             OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
@@ -2194,7 +2235,7 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
     dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
     for (int z = 0; z < L.n; z++) {
         const float *r0 = R0 + (size_t)z * L.planes, *r1 = R1 + (size_t)z * L.planes, *mi = Min + (size_t)z * L.planes;
-        float *mo = Mout + (size_t)z * L.planes, *V = (float *)((double *)ctx->fb_vsum.ptr + (size_t)z * L.vsum);  // reserved by the caller
+        float *mo = Mout + (size_t)z * L.planes, *V = (float *)(L.vsum_ptr + (size_t)z * L.vsum);  // reserved by the caller
         hipLaunchKernelGGL(gauss_vpass_kernel, grid, block, 0, s, mi, w, h, pitch, t, V);
         OFXCV_LAUNCH_CHECK(ctx, "gauss_vpass_kernel");
         if (update)
@@ -2209,7 +2250,8 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
 // OpenCV-order window with the carries folded into the iteration kernel (winsize 3).  Strip geometry by level size
 // (of the whole batch: what matters is how many workgroups a launch has).
 struct FoldGeom {
-    int rw, nw, tiles_x, nstrips;
+    int rw, nw, tiles_x, nstrips, sh;
+    bool var;  // strips of sh rows with rw - 1 or rw rows per wavefront (wave_rows)
 };
 bool fold_level_is_large(const ofxcv_ctx *ctx, int w, int h, int n) {  // bandwidth-bound level
     return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) * n >= ctx->fb_fold_min_tiles;
@@ -2222,7 +2264,30 @@ FoldGeom fold_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     // 4 rows per wavefront: 7 rows of M in registers leave room for the pipelined gather (8 rows: 918 -> 900 pairs/s at 1080p)
     g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) * n >= 128 ? 4 : 3;
     if (large && (ctx->fb_fold_rows == 3 || ctx->fb_fold_rows == 8)) g.rw = ctx->fb_fold_rows;
-    g.nstrips = ofxcv_div_up(h, g.rw * g.nw);
+    g.sh = g.rw * g.nw;
+    g.var = false;
+    if (large && g.nw == 8 && g.rw == 4 && ctx->fb_fold_strip != 32) {
+        // Strip height 32 .. 40 (4 or 5 rows per wavefront) by the number of rounds the launch makes over the resident
+        // workgroup slots (two 8-wavefront workgroups per CU): a round that is nearly empty costs almost a full one.
+        const double slots = 2.0 * ctx->num_cus;
+        int best = 32;
+        double best_cost = 0;
+        for (int sh = 32; sh <= 40; sh++) {
+            if (ctx->fb_fold_strip >= 33 && ctx->fb_fold_strip <= 40 && sh != ctx->fb_fold_strip) continue;
+            const double r = (double)g.tiles_x * ofxcv_div_up(h, sh) * n / slots, full = std::floor(r), frac = r - full;
+            const double cost = sh * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0)) * (sh > 32 ? 1.02 : 1.0);
+            if (best_cost == 0 || cost < best_cost) {
+                best_cost = cost;
+                best = sh;
+            }
+        }
+        if (best > 32) {
+            g.sh = best;
+            g.rw = 5;
+            g.var = true;
+        }
+    }
+    g.nstrips = ofxcv_div_up(h, g.sh);
     return g;
 }
 struct FoldScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles / L.ctr counters further)
@@ -2232,29 +2297,31 @@ struct FoldScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair 
 FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
     const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 4) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 12 rows)
     FoldScratch fs;
-    double *base = (double *)ctx->fb_vsum.ptr;
+    double *base = L.vsum_ptr;
     fs.K[0] = base;
     fs.K[1] = base + n;
     fs.Spart = base + 2 * n;
-    fs.counters = (unsigned *)(base + L.vsum * L.n);
+    fs.counters = L.ctr_ptr;
     return fs;
 }
 int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot, const Layout &L) {
     const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, ctx->fb_debug_gather};
+    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh, ctx->fb_debug_gather};
     dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
-    if (g.nw == 8) {
-        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+    if (g.var) {
+        hipLaunchKernelGGL((vsum_seed_kernel<5, 8, true>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+    } else if (g.nw == 8) {
+        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
     } else {
-        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
+        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
+        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
     }
     OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
     if (!fa.scan_in_kernel) {
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.rw * g.nw, fa, L.planes);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.sh, fa, L.planes);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
     }
     return OFXCV_OK;
@@ -2262,34 +2329,36 @@ int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
 int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
                           int w, int h, bool update, const FoldScratch &fs, int kslot, const Layout &L) {
     const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, ctx->fb_debug_gather};
+    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh, ctx->fb_debug_gather};
     dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
     const double scale = 1. / 9.;
     int rc;
     const int mark = ctx->prof_now ? ctx->prof_on : 0;
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-#define OFXCV_LAUNCH_FOLD(RW, NW)                                                                                                        \
+#define OFXCV_LAUNCH_FOLD(RW, NW, VAR)                                                                                                   \
     do {                                                                                                                                 \
         if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
+            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW, VAR>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
         else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
+            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW, VAR>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
     } while (0)
-    if (g.nw == 8) {
-        if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8);
-        else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 8);
-        else OFXCV_LAUNCH_FOLD(3, 8);
+    if (g.var) {
+        OFXCV_LAUNCH_FOLD(5, 8, true);
+    } else if (g.nw == 8) {
+        if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8, false);
+        else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 8, false);
+        else OFXCV_LAUNCH_FOLD(3, 8, false);
     } else {
-        if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 4);
-        else OFXCV_LAUNCH_FOLD(3, 4);
+        if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 4, false);
+        else OFXCV_LAUNCH_FOLD(3, 4, false);
     }
 #undef OFXCV_LAUNCH_FOLD
     OFXCV_LAUNCH_CHECK(ctx, "iterate3f_kernel");
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     if (update && !fa.scan_in_kernel) {
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.rw * g.nw, fa, L.planes);
+        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.sh, fa, L.planes);
         OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
         if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     }
@@ -2383,6 +2452,7 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
         int rc = ofxcv_reserve(ctx, ctx->fb_vsum, sizeof(double) * L.vsum);
         if (rc) return rc;
     }
+    L.vsum_ptr = (double *)ctx->fb_vsum.ptr;
     return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, one_flow(d_flow, flow_step), width, height, winsize,
                             update != 0, L);
 }
@@ -2404,7 +2474,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     float *T1 = (float *)ctx->fb_tmp.ptr;
     float *I = T1 + L.t1;
     float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + L.cflow};
-    const size_t pair_cflow = 2 * L.cflow;
 
     // fork: the preparation stream starts once the inputs are ready on the main stream
     OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
@@ -2427,6 +2496,20 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[k], sp));
         }
     }
+    // Launch groups.  A level whose working set (M ping + M pong + R0 + R1 = 80 B/px) for the whole batch stays inside the
+    // Infinity Cache is walked with all pairs in every launch; a larger level is walked in groups of as many pairs as fit
+    // (at least one), group after group, so that the fields an iteration re-reads are still on the die when it comes back
+    // to them (measured at 1920x1080, level 0: 42.5 us per pair and iteration alone, 46.8 us in a batch of three).
+    const size_t budget = (size_t)std::max(1, ctx->fb_batch_mb) << 20;
+    const size_t pair_cflow = 2 * L.cflow;
+    auto sub_tab = [&](const FlowTab &t, int z0, int gn) {
+        FlowTab r = {};
+        for (int z = 0; z < gn; z++) {
+            r.p[z] = t.p[z0 + z];
+            r.step[z] = t.step[z0 + z];
+        }
+        return r;
+    };
     auto coarse_tab = [&](float *p0, size_t step) {
         FlowTab t = {};
         for (int z = 0; z < n; z++) {
@@ -2436,74 +2519,94 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         return t;
     };
     const FlowTab no_flow = {};
-    FlowTab prev_tab = {};
+    FlowTab prev_all = {};
     bool have_prev = false;
     int pw = 0, ph = 0;
+    bool counters_clear = false;
     for (int k = levels; k >= 0; k--) {
         int w, h, ksz;
         double sigma;
         level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
         const int pitch = plane_pitch(w);
-        dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4), n), block(64, 4);
-        if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
-            // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
-            FlowTab init = out;
-            if (k > 0) {
-                double scale = 1;
-                for (int i = 0; i < k; i++) scale *= pyr_scale;
-                init = coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8);
-                for (int z = 0; z < n; z++) {
-                    hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z], out.step[z], width, height, init.p[z], w, h, scale);
-                    OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
-                }
-            }
-            hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R[k][0], R[k][1], init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0], L.planes);
-        } else if (!have_prev)
-            hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R[k][0], R[k][1], no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, Mbuf[0], L.planes);
-        else
-            hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R[k][0], R[k][1], prev_tab, pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, w, h, pitch, Mbuf[0], L.planes);
-        OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
-        const FlowTab out_tab = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
-        int cur = 0;
+        const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)pitch * h;
+        const int per_group = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
+        const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
-        // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
-        const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries &&
-                          (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, n));  // 3: only the levels that are bandwidth-bound
-        FoldScratch fs = {};
-        if (fold) {
-            fs = fold_scratch(ctx, width, height, L);
-            if (k == levels) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fs.counters, 0, sizeof(unsigned) * (size_t)L.ctr * n, s));
-            rc = launch_fold_seed(ctx, s, Mbuf[0], w, h, fs, 0, L);
-            if (rc) return rc;
-        }
-        for (int i = 0; i < iterations;) {
-            const bool pair = fuse && i + 2 <= iterations - 1;
-            const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
-            const bool inner = prof && !pair && !gaussian && ctx->fb_opencv_rounding == 1 && winsize == 3;  // marks set around the kernels inside
-            ctx->prof_now = inner;
-            if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            if (pair) {  // two updating iterations in one launch
-                rc = launch_iteration_pair(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], w, h, k == 0, L);
-                i += 2;
-            } else {
-                bool update = i < iterations - 1;
-                const FlowTab &ft = update ? no_flow : out_tab;
-                if (gaussian)
-                    rc = launch_gauss_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, winsize, update, L);
-                else if (fold)
-                    rc = launch_fold_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, update, fs, cur, L);
-                else
-                    rc = launch_iteration(ctx, s, R[k][0], R[k][1], Mbuf[cur], Mbuf[cur ^ 1], ft, w, h, winsize, update, L);
-                i += 1;
+        for (int z0 = 0; z0 < n; z0 += per_group) {
+            const int gn = std::min(per_group, n - z0);
+            Layout G = L;  // this group's view of the scratch: its first pair is "pair 0" of every launch
+            G.n = gn;
+            G.vsum_ptr = (double *)ctx->fb_vsum.ptr + (size_t)z0 * L.vsum;
+            G.ctr_ptr = (unsigned *)((double *)ctx->fb_vsum.ptr + L.vsum * L.n) + (size_t)z0 * L.ctr;
+            const size_t po = (size_t)z0 * L.planes;
+            float *M0 = Mbuf[0] + po, *M1 = Mbuf[1] + po;
+            const float *R0 = R[k][0] + po, *R1 = R[k][1] + po;
+            float *Mg[2] = {M0, M1};
+            dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4), gn), block(64, 4);
+            const FlowTab out_tab = sub_tab(out_all, z0, gn);
+            if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
+                // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
+                FlowTab init = sub_tab(out, z0, gn);
+                if (k > 0) {
+                    double scale = 1;
+                    for (int i = 0; i < k; i++) scale *= pyr_scale;
+                    init = sub_tab(coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8), z0, gn);
+                    for (int z = 0; z < gn; z++) {
+                        hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z0 + z], out.step[z0 + z], width, height,
+                                           init.p[z], w, h, scale);
+                        OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
+                    }
+                }
+                hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R0, R1, init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+            } else if (!have_prev)
+                hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+            else
+                hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R0, R1, sub_tab(prev_all, z0, gn), pw, ph, 1. / pyr_scale, (double)pw / w,
+                                   (double)ph / h, w, h, pitch, M0, L.planes);
+            OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
+            int cur = 0;
+            // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
+            const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries &&
+                              (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, gn));  // 3: only the levels that are bandwidth-bound
+            FoldScratch fs = {};
+            if (fold) {
+                fs = fold_scratch(ctx, width, height, G);
+                if (!counters_clear) {
+                    OFXCV_HIP_CHECK(ctx, hipMemsetAsync((double *)ctx->fb_vsum.ptr + L.vsum * L.n, 0, sizeof(unsigned) * (size_t)L.ctr * n, s));
+                    counters_clear = true;
+                }
+                rc = launch_fold_seed(ctx, s, M0, w, h, fs, 0, G);
+                if (rc) return rc;
             }
-            ctx->prof_now = false;
-            if (rc) return rc;
-            if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-            cur ^= 1;
+            for (int i = 0; i < iterations;) {
+                const bool pair = fuse && i + 2 <= iterations - 1;
+                const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
+                const bool inner = prof && !pair && !gaussian && ctx->fb_opencv_rounding == 1 && winsize == 3;  // marks set around the kernels inside
+                ctx->prof_now = inner;
+                if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+                if (pair) {  // two updating iterations in one launch
+                    rc = launch_iteration_pair(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], w, h, k == 0, G);
+                    i += 2;
+                } else {
+                    bool update = i < iterations - 1;
+                    const FlowTab &ft = update ? no_flow : out_tab;
+                    if (gaussian)
+                        rc = launch_gauss_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
+                    else if (fold)
+                        rc = launch_fold_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, update, fs, cur, G);
+                    else
+                        rc = launch_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
+                    i += 1;
+                }
+                ctx->prof_now = false;
+                if (rc) return rc;
+                if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+                cur ^= 1;
+            }
         }
-        prev_tab = out_tab;
+        prev_all = out_all;
         have_prev = true;
         pw = w;
         ph = h;

@@ -445,6 +445,24 @@ def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
         ctx.close()
 
 
+@pytest.mark.parametrize("mb", [1, 20, 100000])
+def test_batch_launch_groups(oracle, ofxcv, mb):
+    """a level whose working set for the whole batch exceeds the Infinity Cache budget (option farneback.batch_mb) is
+    walked in groups of pairs: groups of one (1 MiB), of two with a remainder (20 MiB), everything in one launch"""
+    w, h, n = 333, 257, 5
+    prs = _pairs(oracle, w, h, range(40, 40 + n))
+    ctx = ofxcv.Context(0)
+    singles = [ctx.calc_optical_flow_farneback(_dev(a), _dev(b)).cpu().numpy() for a, b in prs]
+    ctx.set_option("farneback.batch_mb", mb)
+    for fold in (3, 2):
+        ctx.set_option("farneback.fold_carries", fold)
+        ctx.set_option("farneback.fold_min", 1 if fold == 2 else 256)
+        flows = ctx.calc_optical_flow_farneback_batch([_dev(a) for a, _ in prs], [_dev(b) for _, b in prs])
+        for f, s in zip(flows, singles):
+            assert np.array_equal(f.cpu().numpy(), s)
+    ctx.close()
+
+
 def test_batch_initial_flow_and_argument_checks(oracle, ofxcv):
     w, h = 320, 240
     prs = _pairs(oracle, w, h, (1, 2, 3))
