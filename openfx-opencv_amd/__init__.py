@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libofxcv_hip.so")
+LIB_PATH = os.environ.get("OFXCV_LIB_PATH") or os.path.join(_HERE, "lib", "libofxcv_hip.so")  # (override: A/B of two builds)
 
 OK = 0
 _lib = None

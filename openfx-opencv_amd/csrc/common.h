@@ -43,7 +43,10 @@ struct ofxcv_ctx {
     hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_done = nullptr;
     hipStream_t prep = nullptr;     // Farneback: pyramid + polynomial expansion of all levels, ahead of the level walk
-    hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {};
+    hipStream_t coarse = nullptr;   // Farneback: the coarse (latency-bound) pyramid levels of the walk, at high priority (option below)
+    hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {}, ev_coarse = nullptr;
+    int fb_priority = 0;            // environment OFXCV_STREAM_PRIORITY at context creation: 0 all streams alike; 1 preparation stream at high
+                                    // priority; 2 also the coarse levels of the walk, on a high-priority stream of their own
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned fb_graph_next = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
@@ -74,7 +77,6 @@ struct ofxcv_ctx {
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one
-    int fb_debug_gather = 0;     // timing experiments only (wrong results): see FoldArgs::dbg
 
     // inpaint scratch
     DevBuf ip_tmp;   // undilated mask

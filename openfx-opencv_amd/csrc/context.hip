@@ -21,7 +21,7 @@ std::shared_mutex &ofxcv_capture_mutex(int device) {
 }
 
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
-    hipStream_t streams[] = {ctx->compute, ctx->copy, ctx->prep, ctx->last_stream};
+    hipStream_t streams[] = {ctx->compute, ctx->copy, ctx->prep, ctx->coarse, ctx->last_stream};
     for (hipStream_t st : streams)
         if (st) OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return OFXCV_OK;
@@ -90,7 +90,14 @@ int ofxcv_prof_drain(ofxcv_ctx *ctx) {
 int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     if (ctx->prep) return OFXCV_OK;
     std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));  // stream creation: see ofxcv_ctx_create
-    OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
+    int lo = 0, hi = 0;  // (numerically lower = higher priority)
+    OFXCV_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (ctx->fb_priority >= 1) OFXCV_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->prep, hipStreamNonBlocking, hi));
+    else OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->prep, hipStreamNonBlocking));
+    if (ctx->fb_priority >= 2) {
+        OFXCV_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->coarse, hipStreamNonBlocking, hi));
+        OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_coarse, hipEventDisableTiming));
+    }
     OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (hipEvent_t &e : ctx->ev_level) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return OFXCV_OK;
@@ -130,6 +137,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
         if (!std::strcmp(e, "direct")) ctx->fb_opencv_rounding = 0;
         else if (!std::strcmp(e, "opencv")) ctx->fb_opencv_rounding = 1;
     }
+    if (const char *e = getenv("OFXCV_STREAM_PRIORITY")) ctx->fb_priority = atoi(e);
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
         // stream creation changes the runtime's stream list, which another thread's hipGraphLaunch walks: under the runtime lock
@@ -164,6 +172,8 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_level)
         if (e) (void)hipEventDestroy(e);
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
+    if (ctx->coarse) (void)hipStreamDestroy(ctx->coarse);
+    if (ctx->ev_coarse) (void)hipEventDestroy(ctx->ev_coarse);
     DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -232,10 +242,6 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     if (!std::strcmp(name, "farneback.batch_mb")) {
         ctx->fb_batch_mb = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.debug_gather")) {
-        ctx->fb_debug_gather = value;
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.fold_strip")) {

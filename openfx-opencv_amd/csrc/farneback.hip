@@ -1567,7 +1567,6 @@ struct FoldArgs {
     size_t pair_vsum;     // batched calls: doubles between the Kin / Kout / Spart of consecutive pairs
     unsigned pair_ctr;    //                counters between consecutive pairs
     int sh;               // rows per strip (= rows per wavefront x wavefronts, or anything above (rows - 1) x wavefronts: wave_rows)
-    int dbg;              // timing experiments only (option "farneback.debug_gather"; results are wrong when set): 1 no R1 gather, 2 gather at zero flow
     __device__ __forceinline__ void select_pair(int z) {
         if (Kin) Kin += (size_t)z * pair_vsum;
         Kout += (size_t)z * pair_vsum;
@@ -1868,7 +1867,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             mo[j][c] = mm.v[c];
-            if (own && !(fa.dbg & 8)) {
+            if (own) {
                 if (fa.scan_in_kernel) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
                 else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
             }
@@ -1889,7 +1888,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
             acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
         }
         double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        double idet = (fa.dbg & 16) ? 1e-3 : 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
         float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
         float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
         if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
@@ -1898,14 +1897,8 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
             cur.fxv = fxv;
             cur.fyv = fyv;
 #pragma unroll
-            for (int c = 0; c < 5; c++) cur.r0v[c] = (fa.dbg & 64) ? 1.f : buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            if ((fa.dbg & 3) == 1) {
-                cur.tp = Taps();
-                cur.tp.inb = true;
-                cur.tp.fx = cur.tp.fy = 0.5f;
-            } else {
-                cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, (fa.dbg & 3) == 2 ? 0.f : fxv, (fa.dbg & 3) == 2 ? 0.f : fyv);
-            }
+            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
             if (PIPE) {  // the gather of row j is in flight while row j-1 is finished
                 if (j > 0) finish(prev, j - 1);
                 prev = cur;
@@ -1915,7 +1908,6 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
         }
     }
     if (!UPDATE) return;
-    if (fa.dbg & 32) return;  // (every wavefront of the launch: no barrier is left waiting)
     const int nre = min(nr, h - a);  // rows of this wavefront inside the image (<= 0: none, bottom strip only)
     if (PIPE) {
         if (nre > 0) {
@@ -2306,7 +2298,7 @@ FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0, const Layout &L) {  // 
 }
 int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot, const Layout &L) {
     const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh, ctx->fb_debug_gather};
+    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh};
     dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
     if (g.var) {
@@ -2329,7 +2321,7 @@ int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
 int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
                           int w, int h, bool update, const FoldScratch &fs, int kslot, const Layout &L) {
     const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh, ctx->fb_debug_gather};
+    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh};
     dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
     const double scale = 1. / 9.;
@@ -2523,10 +2515,20 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     bool have_prev = false;
     int pw = 0, ph = 0;
     bool counters_clear = false;
+    hipStream_t s_main = s;
+    const bool use_coarse = ctx->coarse && levels > 0 && sp != s && !profile;
     for (int k = levels; k >= 0; k--) {
         int w, h, ksz;
         double sigma;
         level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+        // the coarse levels may run on a high-priority stream of their own: their short launches are then not queued behind
+        // another call's full-size kernels (several calls in flight on one device)
+        if (use_coarse && k == levels) OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->coarse, ctx->ev_fork, 0));
+        if (use_coarse && k == 0) {
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_coarse, ctx->coarse));
+            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s_main, ctx->ev_coarse, 0));
+        }
+        hipStream_t s = (use_coarse && k > 0) ? ctx->coarse : s_main;
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
         const int pitch = plane_pitch(w);
         const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)pitch * h;
