@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4, help="frame pairs per batched Farneback call (ofxcv_calc_optical_flow_farneback_batch)")
-    ap.add_argument("--streams", type=int, default=2, help="batched calls in flight per GPU, each on its own context/stream; "
+    ap.add_argument("--streams", type=int, default=3, help="batched calls in flight per GPU, each on its own context/stream; "
                     "pairs per step per GPU = batch x streams")
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,6 +254,10 @@ def main():
     pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
     rates = [pairs_per_region / e for e in el]
     fold_mode = ctxs[0].get_option("farneback.fold_carries")
+    # pairs one level-0 launch carries: a level is walked in groups of pairs whose working set (80 B/px each) stays inside the
+    # Infinity Cache budget (option farneback.batch_mb), see enqueue_farneback
+    pitch = ofxcv.farneback_plane_pitch(W) if hasattr(ofxcv, "farneback_plane_pitch") else (W + 63) // 64 * 64
+    ppl = max(1, min(B, (ctxs[0].get_option("farneback.batch_mb") << 20) // (80 * pitch * H)))
     main_s, main_n = kernel_leg(ctxs[0], bufs[0], 1)
     carry_s, carry_n = kernel_leg(ctxs[0], bufs[0], 2)
     one_in_flight = one_batch_in_flight = None
@@ -295,7 +299,7 @@ def main():
     pc = pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
     pf = pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes_pair = ITER_BYTES_PER_PX * W * H
-    iter_bytes = iter_bytes_pair * B  # one launch of the dominant kernel carries the whole batch
+    iter_bytes = iter_bytes_pair * ppl  # one launch of the dominant kernel carries `ppl` pairs of the batch
     achieved = iter_bytes / main_s / 1e9
     traffic = pm.get("traffic_bytes_per_launch")
     valu = pm.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
@@ -329,12 +333,12 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
-                     "kernel": ("iterate3f_kernel<true, 4, 8> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
+                     "kernel": ("iterate3f_kernel<true, 5, 8, true> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
                                 "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
-                     "bytes_per_launch": iter_bytes, "pairs_per_launch": B,
+                     "bytes_per_launch": iter_bytes, "pairs_per_launch": ppl,
                      "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20) x %d x %d px x %d pairs "
-                                              "per launch (grid z = pair)" % (W, H, B),
+                                              "per launch (grid z = pair)" % (W, H, ppl),
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one batched call in flight (compare profiles/r03_bench_streams1_by_grid.txt)",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,

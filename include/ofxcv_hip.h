@@ -62,9 +62,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
  *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
- *   "host.register"             0|1  ofxcv_vectorgen_flows_host registers the host's own buffers for the call when it can (all four
- *                                    channels mapped, top-down images, no other host call in flight; default 1) or always stages
- *                                    through the pinned ring (0);
+ *   "host.register"           0|1|2  how ofxcv_vectorgen_flow(s)_host moves host images: 1 (default) asynchronous copies straight from / into
+ *                                    the host's pageable images; 2 the host's buffers registered (hipHostRegister) for the duration of the
+ *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n   A/B: fill-order pixels per portion of the pipelined fill (8192) and
  *                                    per workgroup of a component (256);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
@@ -162,9 +162,12 @@ int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref
                                double render_scale_y, int levels, int iterations, int poly_n,
                                double poly_sigma);
 
-/* number of host-image calls on this context that ran zero-copy (the host's buffers registered with hipHostRegister and
- * addressed directly by the kernels) instead of staging through the pinned ring; option "host.register" 0 forces the ring */
+/* How the host-image calls on this context moved their frames (context option "host.register"): copied straight from the
+ * host's pageable images (1, default: ofxcv_host_direct_calls), with the host's buffers registered for the call and addressed
+ * by the copy engine / the write-back kernel in place (2: ofxcv_host_zero_copy_calls), or staged through the pinned ring (0,
+ * and whatever the other two cannot address: bottom-up images). */
 long ofxcv_host_zero_copy_calls(const ofxcv_ctx *ctx);
+long ofxcv_host_direct_calls(const ofxcv_ctx *ctx);
 
 /* ---- I0-I2: inpaint hole mask -------------------------------------------------------------
  * replaces cvCvtColor(imgSrc, mask, CV_RGBA2GRAY) + cvThreshold(mask, mask, 0, 255, CV_THRESH_BINARY_INV)

@@ -45,8 +45,8 @@ struct ofxcv_ctx {
     hipStream_t prep = nullptr;     // Farneback: pyramid + polynomial expansion of all levels, ahead of the level walk
     hipStream_t coarse = nullptr;   // Farneback: the coarse (latency-bound) pyramid levels of the walk, at high priority (option below)
     hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {}, ev_coarse = nullptr;
-    int fb_priority = 0;            // environment OFXCV_STREAM_PRIORITY at context creation: 0 all streams alike; 1 preparation stream at high
-                                    // priority; 2 also the coarse levels of the walk, on a high-priority stream of their own
+    int fb_priority = 1;            // environment OFXCV_STREAM_PRIORITY at context creation: 0 all streams alike; 1 (default) preparation stream
+                                    // at high priority; 2 also the coarse levels of the walk, on a high-priority stream of their own
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned fb_graph_next = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
@@ -104,7 +104,9 @@ struct ofxcv_ctx {
     double prof_ms = 0;
     long prof_launches = 0;
 
-    bool host_register = true;     // option "host.register": 0 = always stage through the pinned ring
+    int host_register = 1;         // option "host.register": 0 stage through the pinned ring; 1 (default) copies straight from / into the host's
+                                   // pageable images; 2 the host's images registered for the duration of the call (zero copy)
+    long host_direct_calls = 0;
     long host_zero_copy_calls = 0, host_staged_calls = 0;
 
     // host-path staging

@@ -191,6 +191,8 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
 
 long ofxcv_host_zero_copy_calls(const ofxcv_ctx *ctx) { return ctx ? ctx->host_zero_copy_calls : -1; }
 
+long ofxcv_host_direct_calls(const ofxcv_ctx *ctx) { return ctx ? ctx->host_direct_calls : -1; }
+
 long ofxcv_inpaint_fallback_count(const ofxcv_ctx *ctx) { return ctx ? ctx->ip_fallbacks : -1; }
 
 const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "null context"; }
@@ -217,7 +219,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "host.register")) {
-        ctx->host_register = value != 0;
+        ctx->host_register = value < 0 ? 0 : (value > 2 ? 1 : value);
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "inpaint.pixels_per_workgroup")) {
@@ -297,7 +299,8 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.fold_carries")) *value = ctx->fb_fold_carries;
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
-    else if (!std::strcmp(name, "host.register")) *value = ctx->host_register ? 1 : 0;
+    else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
+    else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else return OFXCV_ERR_INVALID;
     return OFXCV_OK;
 }

@@ -2,18 +2,22 @@
 // Farneback branch) for host-resident OFX images.
 //
 // The reference marshals each OFX image into a cv::Mat through CVImageWrapper / OFX::ImageMemory
-// (OpenCV/GenericOpenCVPlugin.cpp:58-165, 223-265).  Two ways here:
-//  * registered buffers (default for the usual case: top-down images, all four destination channels mapped): the
-//    host's own buffers are registered with the driver for the duration of the call (hipHostRegister: 0.2 ms per 1080p
-//    frame, no cache -- a registration does not survive the host freeing and re-allocating the addresses), the copy
-//    engine reads the f32 frames in place (no staging memcpy), and one kernel stores the four flow channels of both
-//    directions straight into the host's destination image.  The forward and the backward flow of an output frame
-//    run as ONE batched Farneback call (two pairs per launch).
-//  * pinned ring (everything else: bottom-up / oddly strided images, partial channel maps, registration refused,
-//    option "host.register" 0): the frames are copied in row blocks into a pinned ring and sent to HBM with
-//    hipMemcpyAsync on the copy stream while the compute stream converts the previous frame; only the flow (8 B/px)
-//    comes back and the mapped channels of the destination are filled from the pinned copy (unmapped channels stay
-//    untouched, :507-516).
+// (OpenCV/GenericOpenCVPlugin.cpp:58-165, 223-265).  Three ways here (context option "host.register"):
+//  * direct (1, default): asynchronous copies straight from the host's pageable frames on the copy stream while the compute
+//    stream converts the frames that have arrived; the forward and the backward flow of an output frame run as ONE batched
+//    Farneback call; with all four destination channels mapped a kernel composes the RGBA image in HBM and one copy takes
+//    it into the host's image.  On the MI355X box the runtime moves pageable memory at the rate of pinned memory, and calls
+//    of several render threads overlap (profiles/r03_host_overlap.txt, r03_host_path_threads.txt: 410 / 782 / 730 pairs/s
+//    for 1 / 2 / 4 calling threads).
+//  * registered buffers (2): the host's own buffers are registered with the driver for the duration of the call
+//    (hipHostRegister, no cache -- a registration does not survive the host freeing and re-allocating the addresses), the
+//    copy engine reads the f32 frames in place, and one kernel stores the four flow channels of both directions straight
+//    into the host's destination image.  Same speed as the direct form for one calling thread, but registering and
+//    unregistering stalls other threads' GPU work (407 / 444 / 434 pairs/s).
+//  * pinned ring (0; and whatever the others cannot address: bottom-up / oddly strided images): the frames are copied in
+//    row blocks into a pinned ring and sent to HBM with hipMemcpyAsync.
+// With a partial channel map only the flows (8 B/px) come back and the mapped channels of the destination are filled on
+// the host (unmapped channels stay untouched, :507-516).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -144,9 +148,20 @@ struct HostRegistrations {
         if (!n) return;
         (void)hipStreamSynchronize(ctx->copy);
         (void)hipStreamSynchronize(ctx->compute);
+        release_all();
+    }
+    // the source frames are only read by the copy engine: once the copy stream has drained they can be unregistered while
+    // the kernels still run (0.1-0.2 ms each, off the end of the call)
+    void release_sources_after_uploads() {
+        if (hipStreamSynchronize(ctx->copy) != hipSuccess) return;
+        release_all();
+    }
+    void release_all() {
+        if (!n) return;
         std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
         for (int i = 0; i < n; i++) (void)hipHostUnregister(p[i]);
         (void)hipGetLastError();
+        n = 0;
     }
 };
 
@@ -178,7 +193,6 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
                                  const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
                                  const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
                                  int levels, int iterations, int poly_n, double poly_sigma) {
-    if (!ctx->host_register) return kNotRegistered;
     const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
     const float *src[3] = {h_ref, h_other[0], n_other > 1 ? h_other[1] : nullptr};
@@ -236,6 +250,7 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
                                                      iterations, poly_n, poly_sigma, 0, ctx->compute);
         if (rc) return rc;
     }
+    regs.release_sources_after_uploads();
     void *d_dst = nullptr;
     if (!regs.add(h_dst, (size_t)(height - 1) * dst_row_bytes + drow) || hipHostGetDevicePointer(&d_dst, h_dst, 0) != hipSuccess || !d_dst) {
         (void)hipGetLastError();
@@ -251,123 +266,145 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
 }
 
 // One reference frame against one or two other frames (forward: t+1, backward: t-1 -- the two directions a default
-// VectorGenerator output frame needs, VectorGenerator.cpp:739-779).  The reference is staged, uploaded and converted once;
-// the first flow is computed while the host still stages the third frame and is downloaded on the copy stream while
-// the second one runs; one pass over the destination image writes every mapped channel.
+// VectorGenerator output frame needs, VectorGenerator.cpp:739-779).  The reference frame is uploaded and converted once, the
+// flows of both directions are ONE batched Farneback call, and one pass writes the destination.
+//
+// Uploads.  Default: hipMemcpyAsync straight from the host's own (pageable) frames on the copy stream.  On this platform
+// the runtime moves pageable memory at the rate of pinned memory (measured on the MI355X box, tools/host_pieces.py and
+// tools/host_overlap.py: 47 GB/s against 56 GB/s pinned for one thread; 3 uploads + 1 download of 33 MB frames from 1 / 2 / 4
+// threads: 409 / 535 / 519 per second pageable, 392 / 479 / 538 pinned), without the per-call hipHostRegister of the
+// registered form (which stalls other threads' GPU work) and without the staging memcpy of the ring (30 GB/s per host
+// thread, the largest term of a staged call).  Bottom-up or oddly strided images, and option "host.register" 0, stage
+// through the pinned ring instead.
+// Write-back.  With all four destination channels mapped (the default output frame) a kernel composes the RGBA image in
+// HBM and one copy takes it into the host's image; otherwise only the flows come back (8 B/px each) and the mapped
+// channels are filled on the host (unmapped channels stay untouched, :507-516).
 static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, int n_other, const float *const h_other[2],
                       const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
                       const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
                       int levels, int iterations, int poly_n, double poly_sigma) {
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int nf = 1 + n_other;
-    const size_t row = (size_t)width * ncomp * sizeof(float);
-    // Registering and unregistering host memory stalls every thread's GPU work (measured: with per-call registration the
-    // frame rate does not grow with the number of calling threads at all -- 187 / 188 / 195 output frames/s for 1 / 2 / 4
-    // threads -- while the pinned ring reaches 150 / 183 / 242): the registered form is for a render thread that has the
-    // GPU to itself; while host calls overlap (and for a second afterwards) every call stages through the ring.
-    struct ActiveCall {  // has any host call overlapped another one during the last second?
-        static std::atomic<int> &count() { static std::atomic<int> n{0}; return n; }
-        static std::atomic<long long> &busy_until() { static std::atomic<long long> t{0}; return t; }
-        static long long now_ms() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-        bool alone;
-        ActiveCall() {
-            const bool overlap = count().fetch_add(1) != 0;
-            if (overlap) busy_until().store(now_ms() + 1000);
-            alone = !overlap && now_ms() >= busy_until().load();
-        }
-        ~ActiveCall() {
-            if (count().fetch_sub(1) != 1) busy_until().store(now_ms() + 1000);
-        }
-    } active;
-    if (active.alone) {
+    const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
+    if (ctx->host_register == 2) {  // opt-in: the host's buffers registered for the call, the kernel stores into the host image
         int rc0 = flows_host_registered(ctx, h_ref, ref_row_bytes, n_other, h_other, other_row_bytes, ncomp, width, height, h_dst, dst_row_bytes,
                                         chan_u_mask, chan_v_mask, render_scale_x, render_scale_y, levels, iterations, poly_n, poly_sigma);
         if (rc0 != kNotRegistered) return rc0;
     }
-    ctx->host_staged_calls++;
-    const size_t frame = align_up(row * height, 256);
-    const size_t gray_pitch = align_up((size_t)width, 256);
-    const size_t gray = gray_pitch * height;
-    const size_t flow_bytes = align_up((size_t)width * height * 8, 256);
-    int rc = reserve_pinned(ctx, nf * frame + n_other * flow_bytes);
+    const float *src[3] = {h_ref, h_other[0], n_other > 1 ? h_other[1] : nullptr};
+    const ptrdiff_t src_rb[3] = {ref_row_bytes, other_row_bytes[0], n_other > 1 ? other_row_bytes[1] : 0};
+    bool topdown = true;
+    for (int f = 0; f < nf; f++) topdown = topdown && src_rb[f] >= (ptrdiff_t)row;
+    const bool direct_up = ctx->host_register != 0 && topdown;
+    // channel -> (flow, coordinate): per direction v wins over u, a later direction overwrites an earlier one (:507-516)
+    ChanMap cm = {{-1, -1, -1, -1}, {0, 0, 0, 0}};
+    for (int k = 0; k < n_other; k++) {
+        const unsigned mu = chan_u_mask[k] & 15u, mv = chan_v_mask[k] & 15u;
+        for (int c = 0; c < 4; c++) {
+            if (mv & (1u << c)) { cm.k[c] = k; cm.comp[c] = 1; }
+            else if (mu & (1u << c)) { cm.k[c] = k; cm.comp[c] = 0; }
+        }
+    }
+    const bool whole_pixels = cm.k[0] >= 0 && cm.k[1] >= 0 && cm.k[2] >= 0 && cm.k[3] >= 0 && dst_row_bytes >= (ptrdiff_t)drow;
+    const bool direct_down = ctx->host_register != 0 && whole_pixels;
+
+    const size_t frame = align_up(row * height, 256), gray_pitch = align_up((size_t)width, 256), gray = gray_pitch * height,
+                 flow_bytes = align_up((size_t)width * height * 8, 256), rgba_bytes = align_up(drow * height, 256);
+    int rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes + (direct_down ? rgba_bytes : 0));
     if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->d_stage, nf * (frame + gray) + n_other * flow_bytes);
-    if (rc) return rc;
-    char *hp = (char *)ctx->h_pinned;
-    char *dp = (char *)ctx->d_stage.ptr;
+    const size_t pin_frames = direct_up ? 0 : nf * frame, pin_flows = direct_down ? 0 : n_other * flow_bytes;
+    if (pin_frames + pin_flows) {
+        rc = reserve_pinned(ctx, pin_frames + pin_flows);
+        if (rc) return rc;
+    }
+    char *hp = (char *)ctx->h_pinned, *dp = (char *)ctx->d_stage.ptr;
     char *d_frame[3], *h_frame[3];
     uint8_t *d_gray[3];
-    float *d_flow[2], *h_flow[2];
+    float *d_flow[2] = {nullptr, nullptr}, *h_flow[2] = {nullptr, nullptr};
     for (int f = 0; f < nf; f++) {
         d_frame[f] = dp + f * frame;
-        h_frame[f] = hp + f * frame;
+        h_frame[f] = direct_up ? nullptr : hp + f * frame;
         d_gray[f] = (uint8_t *)(dp + nf * frame + f * gray);
     }
     for (int k = 0; k < n_other; k++) {
         d_flow[k] = (float *)(dp + nf * (frame + gray) + k * flow_bytes);
-        h_flow[k] = (float *)(hp + nf * frame + k * flow_bytes);
+        h_flow[k] = direct_down ? nullptr : (float *)(hp + pin_frames + k * flow_bytes);
     }
+    float *d_rgba = direct_down ? (float *)(dp + nf * (frame + gray) + n_other * flow_bytes) : nullptr;
+    // whatever happens below, nothing of this call may still be reading the host's frames or writing its image on return
+    struct Drain {
+        ofxcv_ctx *c;
+        ~Drain() {
+            (void)hipStreamSynchronize(c->copy);
+            (void)hipStreamSynchronize(c->compute);
+        }
+    } drain{ctx};
 
-    const float *src[3] = {h_ref, h_other[0], n_other > 1 ? h_other[1] : nullptr};
-    const ptrdiff_t src_rb[3] = {ref_row_bytes, other_row_bytes[0], n_other > 1 ? other_row_bytes[1] : 0};
-    const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ~4 MiB per DMA
+    // uploads on the copy stream; the compute stream converts frame f as soon as it has arrived
+    const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ring: ~4 MiB per DMA
     for (int f = 0; f < nf; f++) {
-        for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
-            int y1 = std::min(height, y0 + rows_per_chunk);
-            const int nblk = std::min(4, y1 - y0);
-            HostPool::get().run(nblk, [&](int b) {
-                const int ya = y0 + (int)((long)(y1 - y0) * b / nblk), yb = y0 + (int)((long)(y1 - y0) * (b + 1) / nblk);
-                for (int y = ya; y < yb; y++) std::memcpy(h_frame[f] + (size_t)y * row, (const char *)src[f] + (ptrdiff_t)y * src_rb[f], row);
-            });
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f] + (size_t)y0 * row, h_frame[f] + (size_t)y0 * row, (size_t)(y1 - y0) * row,
-                                                hipMemcpyHostToDevice, ctx->copy));
+        if (direct_up) {
+            if ((size_t)src_rb[f] == row)  // contiguous rows: one linear copy
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f], src[f], row * height, hipMemcpyHostToDevice, ctx->copy));
+            else
+                OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(d_frame[f], row, src[f], (size_t)src_rb[f], row, height, hipMemcpyHostToDevice, ctx->copy));
+        } else {
+            for (int y0 = 0; y0 < height; y0 += rows_per_chunk) {
+                int y1 = std::min(height, y0 + rows_per_chunk);
+                const int nblk = std::min(4, y1 - y0);
+                HostPool::get().run(nblk, [&](int b) {
+                    const int ya = y0 + (int)((long)(y1 - y0) * b / nblk), yb = y0 + (int)((long)(y1 - y0) * (b + 1) / nblk);
+                    for (int y = ya; y < yb; y++) std::memcpy(h_frame[f] + (size_t)y * row, (const char *)src[f] + (ptrdiff_t)y * src_rb[f], row);
+                });
+                OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f] + (size_t)y0 * row, h_frame[f] + (size_t)y0 * row, (size_t)(y1 - y0) * row,
+                                                    hipMemcpyHostToDevice, ctx->copy));
+            }
         }
         OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
         rc = ofxcv_to_byte_grayscale(ctx, (const float *)d_frame[f], (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
         if (rc) return rc;
-        if (f == 0) continue;
-        const int k = f - 1;
-        // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
-        rc = ofxcv_calc_optical_flow_farneback(ctx, d_gray[0], gray_pitch, d_gray[f], gray_pitch, d_flow[k], (size_t)width * 8, width, height, 0.5,
-                                               levels, 3, iterations, poly_n, poly_sigma, 0, ctx->compute);
+    }
+    if (direct_up) ctx->host_direct_calls++;
+    else ctx->host_staged_calls++;
+    // The two flows of an output frame are independent pairs with the same first frame: one batched call (every launch of
+    // the level walk carries both).  VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+    {
+        const uint8_t *prevs[2] = {d_gray[0], d_gray[0]}, *nexts[2] = {d_gray[1], n_other > 1 ? d_gray[2] : nullptr};
+        const size_t gsteps[2] = {gray_pitch, gray_pitch}, fsteps[2] = {(size_t)width * 8, (size_t)width * 8};
+        rc = ofxcv_calc_optical_flow_farneback_batch(ctx, n_other, prevs, gsteps, nexts, gsteps, d_flow, fsteps, width, height, 0.5, levels, 3,
+                                                     iterations, poly_n, poly_sigma, 0, ctx->compute);
         if (rc) return rc;
+    }
+    if (direct_down) {
+        hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
+                           (const float2 *)d_flow[1], width, height, d_rgba, (ptrdiff_t)drow, cm, render_scale_x, render_scale_y);
+        OFXCV_LAUNCH_CHECK(ctx, "flows_to_rgba_kernel");
+        if ((size_t)dst_row_bytes == drow)
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_rgba, drow * height, hipMemcpyDeviceToHost, ctx->compute));
+        else
+            OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, (size_t)dst_row_bytes, d_rgba, drow, drow, height, hipMemcpyDeviceToHost, ctx->compute));
+        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+        return OFXCV_OK;
+    }
+    for (int k = 0; k < n_other; k++) {
         if (render_scale_x != 1.0 || render_scale_y != 1.0) {
             size_t n = (size_t)width * height;
             hipLaunchKernelGGL(scale_flow_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (float2 *)d_flow[k], n,
                                render_scale_x, render_scale_y);
             OFXCV_LAUNCH_CHECK(ctx, "scale_flow_kernel");
         }
-        if (k + 1 < n_other) {  // download on the copy stream (behind the last frame's upload) while the next flow runs
-            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));
-        } else {
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[k], d_flow[k], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
-        }
-    }
-    if (n_other > 1) {
-        OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->copy, ctx->ev_done, 0));
-        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[0], d_flow[0], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->copy));
-        OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy));
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[k], d_flow[k], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
     }
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
 
-    // write-back into the host-owned destination (:507-516): per direction, channel c receives flow.y if mapped to v,
-    // else flow.x if mapped to u, else stays untouched; a later direction overwrites an earlier one.  The channel ->
-    // (flow, coordinate) table is resolved once, not per pixel.
-    int src_k[4] = {-1, -1, -1, -1}, src_c[4] = {0, 0, 0, 0};
-    for (int k = 0; k < n_other; k++) {
-        const unsigned mu = chan_u_mask[k] & 15u, mv = chan_v_mask[k] & 15u;
-        for (int c = 0; c < 4; c++) {
-            if (mv & (1u << c)) { src_k[c] = k; src_c[c] = 1; }
-            else if (mu & (1u << c)) { src_k[c] = k; src_c[c] = 0; }
-        }
-    }
+    // write-back into the host-owned destination (:507-516): the channel -> (flow, coordinate) table was resolved above
     int nmap = 0, dst_c[4];
     const float *map_src[4];
     for (int c = 0; c < 4; c++)
-        if (src_k[c] >= 0) {
+        if (cm.k[c] >= 0) {
             dst_c[nmap] = c;
-            map_src[nmap++] = h_flow[src_k[c]] + src_c[c];
+            map_src[nmap++] = h_flow[cm.k[c]] + cm.comp[c];
         }
     const int nblk = nmap ? std::min(8, height) : 0;
     HostPool::get().run(nblk, [&](int b) {
@@ -397,6 +434,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     });
     return OFXCV_OK;
 }
+
 
 extern "C" int ofxcv_vectorgen_flow_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_other,
                                          ptrdiff_t other_row_bytes, int ncomp, int width, int height, float *h_dst,

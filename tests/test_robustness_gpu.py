@@ -195,42 +195,56 @@ def test_bottom_up_host_images(ofxcv, oracle):
     c.close()
 
 
-def test_registered_host_path_equals_the_pinned_ring(ofxcv):
-    """ofxcv_vectorgen_flows_host registers the host's own buffers for the call when all four destination channels are mapped
-    (the copy engine reads the frames in place, a kernel stores whole pixels into the host image, the backward flow runs on a
-    sibling context); with option host.register = 0, for partial channel maps and for bottom-up images the frames are staged
-    through the pinned ring.  Same pixels either way; buffers that the host frees and re-allocates between calls are fine."""
+def test_host_path_forms_agree(ofxcv):
+    """ofxcv_vectorgen_flows_host moves the host's frames in one of three ways: copies straight from / into the host's pageable
+    images (default; with all four destination channels mapped a kernel composes the RGBA image in HBM and one copy brings it
+    back), the host's buffers registered for the call (option host.register = 2: the copy engine reads the frames in place and a
+    kernel stores whole pixels into the host image), or staged through the pinned ring (host.register = 0; also what bottom-up
+    images get).  Same pixels every way; buffers that the host frees and re-allocates between calls are fine."""
     from openfx_opencv_amd import synth
     w, h = 200, 120
-    zc, ring = ofxcv.Context(0), ofxcv.Context(0)
+    direct, zc, ring = ofxcv.Context(0), ofxcv.Context(0), ofxcv.Context(0)
+    zc.set_option("host.register", 2)
     ring.set_option("host.register", 0)
-    n_reg = 0
+    n_reg = n_dir = 0
     for rep in range(3):                       # fresh numpy buffers every time: the allocator hands the same addresses again
         ref, nxt = synth.flow_pair(w, h, seed=5 + rep)
         prev, _ = synth.flow_pair(w, h, seed=16 + rep)
         for fu, fv, bu, bv, rx, ry, registered in [(1, 2, 4, 8, 1.0, 1.0, True), (4, 8, 1, 2, 0.5, 0.25, True), (3, 12, 0, 0, 1.0, 2.0, True),
                                                    (1, 0, 0, 8, 1.0, 1.0, False), (1, 2, 2, 4, 1.0, 1.0, False)]:
-            a = np.full((h, w, 4), -3.0, np.float32)
-            b = np.full((h, w, 4), -3.0, np.float32)
-            zc.vectorgen_flows_host(ref, nxt, prev, a, fu, fv, bu, bv, rx, ry)
-            ring.vectorgen_flows_host(ref, nxt, prev, b, fu, fv, bu, bv, rx, ry)
-            assert np.array_equal(a, b), (rep, fu, fv, bu, bv)
+            outs = []
+            for c in (direct, zc, ring):
+                o = np.full((h, w, 4), -3.0, np.float32)
+                c.vectorgen_flows_host(ref, nxt, prev, o, fu, fv, bu, bv, rx, ry)
+                outs.append(o)
+            assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[2]), (rep, fu, fv, bu, bv)
             n_reg += registered
+            n_dir += 1
             assert zc.host_zero_copy_calls() == n_reg, (rep, fu, fv, bu, bv)
-    assert ring.host_zero_copy_calls() == 0
+            assert direct.host_direct_calls() == n_dir and zc.host_direct_calls() == n_dir - n_reg
+    assert ring.host_zero_copy_calls() == 0 and ring.host_direct_calls() == 0 and direct.host_zero_copy_calls() == 0
     # padded destination / source rows and RGB sources, one direction mapped to all four channels
     pad = np.full((h, w + 12, 4), 5.0, np.float32)
-    a, b = pad.copy(), pad.copy()
+    a, b, d0 = pad.copy(), pad.copy(), pad.copy()
     ref3, nxt3 = np.ascontiguousarray(ref[..., :3]), np.ascontiguousarray(nxt[..., :3])
     zc.vectorgen_flow_host(ref3, nxt3, a[:, :w], 0b0101, 0b1010)
     ring.vectorgen_flow_host(ref3, nxt3, b[:, :w], 0b0101, 0b1010)
-    assert np.array_equal(a, b) and (a[:, w:] == 5.0).all() and zc.host_zero_copy_calls() == n_reg + 1
+    direct.vectorgen_flow_host(ref3, nxt3, d0[:, :w], 0b0101, 0b1010)
+    assert np.array_equal(a, b) and np.array_equal(d0, b) and (a[:, w:] == 5.0).all() and zc.host_zero_copy_calls() == n_reg + 1
+    # padded source rows (a view into a wider image)
+    wide = np.zeros((h, w + 7, 4), np.float32)
+    wide[:, :w] = ref
+    e0, e1 = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    direct.vectorgen_flow_host(wide[:, :w], nxt, e0, 0b0101, 0b1010)
+    ring.vectorgen_flow_host(ref, nxt, e1, 0b0101, 0b1010)
+    assert np.array_equal(e0, e1)
     # bottom-up images cannot be addressed as one ascending range: the ring serves them
     refp, nxtp = np.ascontiguousarray(ref[::-1])[::-1], np.ascontiguousarray(nxt[::-1])[::-1]    # same images, stored bottom-up
-    cp = np.zeros((h, w, 4), np.float32)
-    zc.vectorgen_flow_host(refp, nxtp, cp[::-1], 0b0101, 0b1010)
-    d = np.zeros((h, w, 4), np.float32)
-    ring.vectorgen_flow_host(ref, nxt, d, 0b0101, 0b1010)
-    assert np.array_equal(cp[::-1], d) and zc.host_zero_copy_calls() == n_reg + 1
-    zc.close()
-    ring.close()
+    for c in (zc, direct):
+        n0 = c.host_direct_calls()
+        cp = np.zeros((h, w, 4), np.float32)
+        c.vectorgen_flow_host(refp, nxtp, cp[::-1], 0b0101, 0b1010)
+        assert np.array_equal(cp[::-1], e1) and c.host_direct_calls() == n0
+    assert zc.host_zero_copy_calls() == n_reg + 1
+    for c in (direct, zc, ring):
+        c.close()
