@@ -127,6 +127,11 @@ OPTFLOW_USE_INITIAL_FLOW = 4
 OPTFLOW_FARNEBACK_GAUSSIAN = 256
 
 
+def set_gaussian_kernel_generation(generation):
+    """3 (default) = getGaussianKernel of OpenCV 2.4 / 3.x, 4 = 4.x; only tests/test_cv2_crosscheck.py flips it"""
+    lib().orc_set_gaussian_kernel_generation(C.c_int(generation))
+
+
 def calc_optical_flow_farneback(prev, nxt, pyr_scale=0.5, levels=3, winsize=3, iterations=15, poly_n=5,
                                 poly_sigma=1.1, flags=0, blur_mode=BLUR_FAITHFUL, initial_flow=None):
     prev = np.ascontiguousarray(prev, np.uint8)

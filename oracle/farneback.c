@@ -8,6 +8,11 @@
  * is neither vendored nor version-pinned by the reference and is absent from this image.
  * Each function below names the upstream function whose published behaviour it restates.
  *
+ * GENERATION: the restatement follows the OpenCV 2.4 / 3.x sources (the reference's CI installs 2.4, .travis.yml:22-30;
+ * VectorGenerator.cpp:80-88 compiles against 2.x-4.x).  The one place where 4.x is known to differ in the last bit is
+ * getGaussianKernel (4.x normalises the taps in double before the cast to float, getGaussianKernelBitExact): see
+ * orc_set_gaussian_kernel_generation(), a switch that only tests/test_cv2_crosscheck.py flips when it finds a 4.x cv2.
+ *
  * Build with -ffp-contract=off: OpenCV's scalar code is evaluated op by op in the type of
  * each expression (float*float in float, running sums in double), and the oracle follows that.
  */
@@ -34,9 +39,38 @@ int orc_border_reflect101(int p, int len)
     return p;
 }
 
-/* smooth.cpp getGaussianKernel(n, sigma, CV_32F) */
+/* which getGaussianKernel is restated: 3 (default) = 2.4 / 3.x, 4 = 4.x */
+static int g_gauss_generation = 3;
+void orc_set_gaussian_kernel_generation(int generation) { g_gauss_generation = generation >= 4 ? 4 : 3; }
+int orc_get_gaussian_kernel_generation(void) { return g_gauss_generation; }
+
+/* smooth.cpp getGaussianKernel(n, sigma, CV_32F).
+ * 2.4 / 3.x: the taps are cast to float first, the sum runs over the float values (in double), then float(tap * 1/sum).
+ * 4.x (getGaussianKernelBitExact): taps and their sum stay double (softdouble there, libm exp here: the exponential may
+ * differ in the last bit of the double, which the cast to float hides except at a rounding boundary), one cast at the end. */
 void orc_gaussian_kernel_f32(int n, double sigma, float *k)
 {
+    if (g_gauss_generation >= 4) {
+        static const double small_tab4[4][7] = {
+            {1.},
+            {0.25, 0.5, 0.25},
+            {0.0625, 0.25, 0.375, 0.25, 0.0625},
+            {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125}};
+        if (n % 2 == 1 && n <= 7 && sigma <= 0) {
+            for (int i = 0; i < n; i++) k[i] = (float)small_tab4[n >> 1][i];
+            return;
+        }
+        double sigmaX4 = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+        double scale4 = -0.5 / (sigmaX4 * sigmaX4), sum4 = 0, t4[256];
+        for (int i = 0; i < n && i < 256; i++) {
+            double x = i - (n - 1) * 0.5;
+            t4[i] = exp(scale4 * x * x);
+            sum4 += t4[i];
+        }
+        sum4 = 1. / sum4;
+        for (int i = 0; i < n && i < 256; i++) k[i] = (float)(t4[i] * sum4);
+        return;
+    }
     static const float small_tab[4][7] = {
         {1.f},
         {0.25f, 0.5f, 0.25f},

@@ -46,6 +46,10 @@ int orc_border_reflect101(int p, int len);
 
 /* getGaussianKernel(n, sigma, CV_32F)  [smooth.cpp] */
 void orc_gaussian_kernel_f32(int n, double sigma, float *k);
+/* which OpenCV generation's getGaussianKernel is restated: 3 (default: 2.4 / 3.x) or 4 (4.x, taps normalised in double);
+ * only the cv2 cross-check flips it */
+void orc_set_gaussian_kernel_generation(int generation);
+int orc_get_gaussian_kernel_generation(void);
 
 /* GaussianBlur(src,dst,Size(ksize,ksize),sigma,sigma), CV_32F, BORDER_REFLECT_101 */
 void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize, double sigma);
