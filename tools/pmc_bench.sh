@@ -5,7 +5,7 @@ RAW=/tmp/pmc_bench_raw; rm -rf $RAW; mkdir -p $RAW; OUT=$GRAFT_REPO_ROOT/gpurun_
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $RAW/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-legs > $RAW/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $RAW/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --batch 1 --streams 1 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-legs > $RAW/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
 done
 python - <<'PY'
 import csv, glob, collections, os, re

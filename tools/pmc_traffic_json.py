@@ -21,9 +21,10 @@ def traffic(c):
     return rd, wr
 
 
-out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --steps 2); per-launch averages per kernel and grid",
+out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --batch 1 --streams 1 --steps 2: single-pair calls, so a launch "
+                 "is one pair's); per-launch averages per kernel and grid",
        "kernels": {}}
-want = {"iterate3f_kernel<true, 4, 8>": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
+want = {"iterate3f_kernel<true,": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
         "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
 for (name, grid), c in rows.items():
     for k, tag in want.items():
