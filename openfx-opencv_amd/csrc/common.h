@@ -45,8 +45,10 @@ struct ofxcv_ctx {
     hipStream_t prep = nullptr;     // Farneback: pyramid + polynomial expansion of all levels, ahead of the level walk
     hipStream_t coarse = nullptr;   // Farneback: the coarse (latency-bound) pyramid levels of the walk, at high priority (option below)
     hipEvent_t ev_fork = nullptr, ev_level[OFXCV_FB_MAX_LEVELS + 1] = {}, ev_coarse = nullptr;
-    int fb_priority = 1;            // environment OFXCV_STREAM_PRIORITY at context creation: 0 all streams alike; 1 (default) preparation stream
-                                    // at high priority; 2 also the coarse levels of the walk, on a high-priority stream of their own
+    int fb_priority = 0;            // environment OFXCV_STREAM_PRIORITY at context creation: 0 (default) all streams alike; 1 preparation stream
+                                    // at high priority; 2 also the coarse levels of the walk, on a high-priority stream of their own.
+                                    // Measured (profiles/r03_scheduling.txt): +1-3 % with several calls in flight, but single calls on a
+                                    // context with a high-priority stream were seen to run 3x slower (236 instead of 725 pairs/s): off.
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned fb_graph_next = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
