@@ -96,6 +96,10 @@ struct ofxcv_ctx {
     int ip_portion = 0;      // option "inpaint.portion": fill-order pixels per portion of the pipelined fill (0 = default)
     DevBuf ip_sched2; // level schedule of the fall-back fill
     int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)
+    int ip_parallel_march = 0;  // option "inpaint.parallel_march": 0 (default) serial front march, pipelined with the fill; 1 the hole's 4-connected
+                                // components marched side by side on host threads and merged into the exact fill order (from 8192 hole pixels; n > 1:
+                                // from n).  Measured at 1920x1080 (profiles/r03_inpaint_march.txt): the march itself 6.2 -> 2.9 + 2.6 ms, but the call
+                                // 11.7 -> 13.6 ms: the GPU fill (a dependency chain of ~8 ms) is the long pole and now starts 2.9 ms later.
     long ip_fallbacks = 0;   // fills that were repeated with the barrier-scheduled kernel
     DevBuf seg_work; // mean-shift pyramid (source + result per level) and mask
 

@@ -32,12 +32,12 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "telea_march.h"
 
 namespace {
 
-enum : uint8_t { KNOWN = 0, BAND = 1, INSIDE = 2, CHANGE = 3 };
+using namespace ofxcv_telea;            // flags, March, march_begin / march_advance (telea_march.h)
 constexpr int kFillWavesHost = 16;     // wavefronts per fill workgroup (kFillThreads / 64)
-constexpr int kNeverFilled = INT_MAX;  // hole pixel the march never reaches (image row / column 0)
 
 // ------------------------------------------------------------------ I0-I2 kernels
 
@@ -71,235 +71,7 @@ __global__ __launch_bounds__(256) void dilate_rect_kernel(const uint8_t *__restr
     dst[(ptrdiff_t)y * dst_step + x] = m;
 }
 
-// ------------------------------------------------------------------ I3/I4 front march (host)
-
-// Pop order of CvPriorityQueueFloat: smallest T first, equal T in push order.  T is never negative while it is queued,
-// so its bit pattern orders like its value: one 64-bit key (T bits << 32 | push number) replaces the two-field compare,
-// and the pixel is looked up by push number.
-struct FrontQueue {
-    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> q;
-    std::vector<int> pi, pj;
-    void push(int i, int j, float T) {
-        uint32_t bits;
-        std::memcpy(&bits, &T, 4);
-        q.push(((uint64_t)bits << 32) | (uint32_t)pi.size());
-        pi.push_back(i);
-        pj.push_back(j);
-    }
-    bool pop(int &i, int &j) {
-        if (q.empty()) return false;
-        const uint32_t seq = (uint32_t)q.top();
-        q.pop();
-        i = pi[seq];
-        j = pj[seq];
-        return true;
-    }
-};
-
-// photo/src/inpaint.cpp FastMarching_solve for the four quadrants (up|down x left|right) and their minimum; the four
-// neighbours are loaded once
-inline float front_value(int i, int j, const uint8_t *f, const float *t, int ec) {
-    const int c = i * ec + j;
-    const double tu = t[c - ec], td = t[c + ec], tl = t[c - 1], tr = t[c + 1];
-    const bool ku = f[c - ec] != INSIDE, kd = f[c + ec] != INSIDE, kl = f[c - 1] != INSIDE, kr = f[c + 1] != INSIDE;
-    auto solve = [](double a11, bool k1, double a22, bool k2) -> float {
-        double sol;
-        if (k1) {
-            if (k2) {
-                if (std::fabs(a11 - a22) >= 1.0) sol = 1 + std::min(a11, a22);
-                else sol = (a11 + a22 + std::sqrt((double)(2 - (a11 - a22) * (a11 - a22)))) * 0.5;
-            } else
-                sol = 1 + a11;
-        } else if (k2)
-            sol = 1 + a22;
-        else
-            sol = 1 + std::min(a11, a22);
-        return (float)sol;
-    };
-    const float a = solve(tu, ku, tl, kl), b = solve(td, kd, tl, kl), cc = solve(tu, ku, tr, kr), d = solve(td, kd, tr, kr);
-    return std::min(std::min(a, b), std::min(cc, d));
-}
-
-void dilate_host(const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, int rows, int cols, int r, bool cross) {
-    dst.assign(src.size(), 0);
-    for (int i = 0; i < rows; i++)
-        for (int j = 0; j < cols; j++) {
-            if (!src[i * cols + j]) continue;
-            for (int di = -r; di <= r; di++)
-                for (int dj = -r; dj <= r; dj++) {
-                    if (cross && di && dj) continue;
-                    int ii = i + di, jj = j + dj;
-                    if (ii < 0 || jj < 0 || ii >= rows || jj >= cols) continue;
-                    dst[ii * cols + jj] = std::max(dst[ii * cols + jj], src[i * cols + j]);
-                }
-        }
-}
-void zero_frame(std::vector<uint8_t> &m, int rows, int cols) {
-    for (int j = 0; j < cols; j++) m[j] = m[(rows - 1) * cols + j] = 0;
-    for (int i = 0; i < rows; i++) m[i * cols] = m[i * cols + cols - 1] = 0;
-}
-
-// Host state of the front march.  The maps are as large as the padded frame but only ever touched at hole pixels, their
-// band and the outward ring: they persist with the context and are reset sparsely (the lists of touched indices), so a call
-// costs time proportional to the hole, not to the frame (22 MB of fills per 1080p call otherwise).
-struct March {
-    int w = 0, h = 0, range = 1;
-    std::vector<float> t;      // (h+2)*(w+2) final distance map (negative outside the hole within `range`); default 1e6
-    std::vector<int> ord;      // (h+2)*(w+2): 0 = not a hole pixel, k >= 1 = filled k-th, kNeverFilled = hole not (yet) reached
-    std::vector<uint8_t> mask, band, ring;  // flag maps of the reference's set-up; default 0
-    std::vector<int> holes, seeds, ring_px; // indices set in mask / band / ring
-    std::vector<int> pix;      // fill order: padded linear index of the k-th filled pixel
-    std::vector<int> level;    // dependency level (>= 1) of the k-th filled pixel
-    std::vector<int> lvl_pix;  // pixels (padded linear index) sorted by (level, order)
-    std::vector<int> lvl_ord;  // their order numbers
-    std::vector<int> lvl_off;  // CSR offsets per (component, level) segment
-    std::vector<int> comp_off; // CSR offsets per component into lvl_off's segments
-    // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
-    std::vector<int> cmp_pix, cmp_ord, cmp_off;
-    std::vector<int> touched;  // scratch of the ring march
-    std::vector<int> cmp_wg;   // per workgroup: {first pixel, end, first wavefront slot, slots in total}
-    FrontQueue heap;           // the inward front
-    int filled = 0;
-    bool dirty = false;
-    std::vector<int> up_idx, up_ord, cell, stack;  // upload / scheduling scratch kept between calls
-    std::vector<float> up_t, up_ft;
-
-    void clear_sparse() {  // back to the defaults at every index a call touched
-        for (int p : holes) { t[p] = 1.0e6f; ord[p] = 0; mask[p] = 0; }
-        for (int p : seeds) { t[p] = 1.0e6f; band[p] = 0; }
-        for (int p : ring_px) { t[p] = 1.0e6f; ring[p] = 0; }
-        holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
-        heap = FrontQueue();
-        filled = 0;
-        dirty = false;
-    }
-    void prepare(int w_, int h_, int range_) {
-        const size_t en = (size_t)(w_ + 2) * (h_ + 2);
-        if (w_ != w || h_ != h || t.size() != en) {
-            w = w_; h = h_;
-            t.assign(en, 1.0e6f);
-            ord.assign(en, 0);
-            mask.assign(en, 0); band.assign(en, 0); ring.assign(en, 0);
-            holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
-            heap = FrontQueue(); filled = 0; dirty = false;
-        } else if (dirty) {
-            clear_sparse();
-        }
-        range = range_;
-    }
-};
-
-// cvInpaint set-up + icvCalcFMM(negate) (photo/src/inpaint.cpp): hole list, band seeds, outward ring (Telea) -- everything up
-// to the inward front, which march_advance() then moves on in portions.  Returns false when there is nothing to fill.
-bool march_begin(const uint8_t *mask_in, bool outside_ring, March &m) {
-    const int w = m.w, h = m.h, range = m.range, ec = w + 2, er = h + 2;
-    m.dirty = true;
-    uint8_t *mask = m.mask.data(), *band = m.band.data();
-    std::vector<int> &holes = m.holes, &seeds = m.seeds;
-    for (int i = 0; i < h; i++) {
-        const uint8_t *row = mask_in + (size_t)i * w;
-        for (int j = 0; j < w; j++)
-            if (row[j]) {
-                mask[(i + 1) * ec + j + 1] = INSIDE;
-                holes.push_back((i + 1) * ec + j + 1);
-            }
-    }
-    if (holes.empty()) return false;
-    // band = dilate(mask, 3x3 cross) - mask, frame zeroed; seeds in row-major order
-    const int d4[4] = {-ec, -1, 1, ec};
-    for (int p : holes)
-        for (int q = 0; q < 4; q++) {
-            const int n = p + d4[q];  // a hole pixel is never on the frame: its 4 neighbours are inside the map
-            const int ni = n / ec, nj = n - ni * ec;
-            if (!mask[n] && !band[n] && ni > 0 && nj > 0 && ni < er - 1 && nj < ec - 1) {
-                band[n] = INSIDE;
-                seeds.push_back(n);
-            }
-        }
-    std::sort(seeds.begin(), seeds.end());
-    FrontQueue outq;
-    for (int n : seeds) {
-        const int i = n / ec, j = n - i * ec;
-        m.heap.push(i, j, 0);
-        outq.push(i, j, 0);
-        m.t[n] = 0;
-    }
-    int ii, jj;
-    float *t = m.t.data();
-    if (outside_ring) {  // CV_INPAINT_TELEA only; CV_INPAINT_NS leaves T = 1e6 off the band
-        // ring = dilate(mask, (2r+1)^2 rect) - mask - band, frame zeroed.  A non-hole pixel within Chebyshev distance r of
-        // the hole is within r of a hole pixel that has a non-hole 8-neighbour, so only those spread the ring.
-        uint8_t *ring = m.ring.data();
-        bool any_ring = false;
-        for (int p : holes) {
-            const int pi = p / ec, pj = p - pi * ec;
-            bool edge = false;
-            for (int di = -1; di <= 1 && !edge; di++)
-                for (int dj = -1; dj <= 1 && !edge; dj++) edge = !mask[(pi + di) * ec + pj + dj];
-            if (!edge) continue;
-            any_ring = true;
-            for (int a = std::max(pi - range, 1); a <= std::min(pi + range, er - 2); a++)
-                for (int c = std::max(pj - range, 1); c <= std::min(pj + range, ec - 2); c++)
-                    if (!mask[a * ec + c] && !band[a * ec + c] && !ring[a * ec + c]) {
-                        ring[a * ec + c] = INSIDE;
-                        m.ring_px.push_back(a * ec + c);
-                    }
-        }
-        if (!any_ring) return false;  // Out->Init fails in the reference: cvInpaint returns without filling
-        uint8_t *f = ring;
-        while (outq.pop(ii, jj)) {
-            f[ii * ec + jj] = CHANGE;
-            const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
-            for (int q = 0; q < 4; q++) {
-                int i = ni[q], j = nj[q];
-                if (i <= 0 || j <= 0 || i > er || j > ec) continue;
-                if (f[i * ec + j] != INSIDE) continue;
-                float dist = front_value(i, j, f, t, ec);
-                t[i * ec + j] = dist;
-                f[i * ec + j] = BAND;
-                outq.push(i, j, dist);
-                m.touched.push_back(i * ec + j);
-            }
-        }
-        for (int n : seeds)
-            if (f[n] == CHANGE) t[n] = -t[n];
-        for (int n : m.touched)
-            if (f[n] == CHANGE) t[n] = -t[n];
-        m.touched.clear();
-        // the seeds were marked CHANGE in the ring map as they were popped: they are reset with the seeds
-        for (int n : seeds) ring[n] = 0;
-    }
-    // inward front over the hole; the reference passes `mask` ({KNOWN, INSIDE}) as the flag map
-    for (int p : holes) m.ord[p] = kNeverFilled;
-    m.filled = 0;
-    return true;
-}
-
-// the front recurrence of icvTeleaInpaintFMM: moves the inward front on until at least `want` more pixels have their
-// distance and order number (or the front is exhausted); returns how many were added to m.pix
-int march_advance(March &m, int want) {
-    const int ec = m.w + 2, er = m.h + 2;
-    uint8_t *f = m.mask.data();
-    float *t = m.t.data();
-    const size_t before = m.pix.size();
-    int ii, jj;
-    while ((int)(m.pix.size() - before) < want && m.heap.pop(ii, jj)) {
-        f[ii * ec + jj] = KNOWN;
-        const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
-        for (int q = 0; q < 4; q++) {
-            int i = ni[q], j = nj[q];
-            if (i <= 1 || j <= 1 || i > er - 1 || j > ec - 1) continue;
-            if (f[i * ec + j] != INSIDE) continue;
-            float dist = front_value(i, j, f, t, ec);
-            t[i * ec + j] = dist;
-            f[i * ec + j] = BAND;
-            m.heap.push(i, j, dist);
-            m.ord[i * ec + j] = ++m.filled;
-            m.pix.push_back(i * ec + j);
-        }
-    }
-    return (int)(m.pix.size() - before);
-}
+// ------------------------------------------------------------------ I3/I4 front march (host): telea_march.h
 
 // level(p) = 1 + max level of the pixels filled before p within Chebyshev distance range+2 (every pixel whose
 // colour p can read: window range, +1 for the image-gradient taps, +1 for the row/column-1 sample quirk).
@@ -934,6 +706,11 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     m.prepare(w, h, range);
     const bool dataflow = range <= kMaxLdsRange;
     const bool any = march_begin(mask.data(), !ns, m);
+    // large holes in several pieces: the pieces' fronts are marched side by side on host threads and their pop sequences merged
+    // into the exact sequential fill order (telea_march.h); march_advance() below hands that order out in the same portions
+    const double t_par0 = trace ? now() : 0;
+    if (any && ctx->ip_parallel_march) (void)march_parallel_run(m, ctx->ip_parallel_march > 1 ? ctx->ip_parallel_march : 8192);
+    if (trace && m.par_on) fprintf(stderr, "ofxcv inpaint: %zu components marched side by side in %.2f ms\n", m.par->comps.size(), now() - t_par0);
     const double t_setup = trace ? now() : 0;
 
     // every index the march touches outside the inward front: holes (order "not yet"), band seeds and ring (their distances)

@@ -1,0 +1,91 @@
+// CPU test of the component-parallel Telea front march (openfx-opencv_amd/csrc/telea_march.h): on random hole masks the merged
+// fill order and the distance map must equal the serial march's, pixel for pixel.  Built and run by tests/test_march_host.py.
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "telea_march.h"
+
+using namespace ofxcv_telea;
+
+static std::vector<uint8_t> random_mask(int w, int h, unsigned seed, int blobs, int rmax, bool touching) {
+    std::mt19937 rng(seed);
+    std::vector<uint8_t> m((size_t)w * h, 0);
+    for (int b = 0; b < blobs; b++) {
+        const int cx = rng() % w, cy = rng() % h, rx = 2 + rng() % rmax, ry = 2 + rng() % rmax;
+        for (int y = std::max(0, cy - ry); y <= std::min(h - 1, cy + ry); y++)
+            for (int x = std::max(0, cx - rx); x <= std::min(w - 1, cx + rx); x++) {
+                const double dx = (x - cx) / (double)rx, dy = (y - cy) / (double)ry;
+                if (dx * dx + dy * dy <= 1.0) m[(size_t)y * w + x] = 255;
+            }
+    }
+    if (touching) {  // thin walls: one-pixel gaps between holes (band seeds shared by two components), diagonal contacts
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                if ((x % 17 == 5 || y % 23 == 7) && m[(size_t)y * w + x]) m[(size_t)y * w + x] = 0;
+    }
+    return m;
+}
+
+static int run_case(int w, int h, unsigned seed, int blobs, int rmax, bool touching, bool ring, int range) {
+    const std::vector<uint8_t> mask = random_mask(w, h, seed, blobs, rmax, touching);
+    March a, b;
+    a.prepare(w, h, range);
+    b.prepare(w, h, range);
+    const bool any_a = march_begin(mask.data(), ring, a), any_b = march_begin(mask.data(), ring, b);
+    if (any_a != any_b) return 1;
+    if (!any_a) return 0;
+    while (march_advance(a, 1 << 30) > 0) {}
+    const bool par = march_parallel_run(b, 1);
+    int got = 0;
+    while ((got = march_advance(b, 1000 + seed % 777)) > 0) {}  // handed out in odd portions like the pipelined fill does
+    if (a.pix != b.pix) {
+        size_t k = 0;
+        while (k < a.pix.size() && k < b.pix.size() && a.pix[k] == b.pix[k]) k++;
+        std::printf("case %dx%d seed %u: fill order differs at %zu of %zu / %zu (parallel %d, components %zu)\n", w, h, seed, k, a.pix.size(), b.pix.size(),
+                    (int)par, b.par ? b.par->comps.size() : 0);
+        return 1;
+    }
+    // (the parallel form leaves the host order map at "not yet": the order is the position in pix)
+    if (a.t != b.t || a.filled != b.filled) {
+        std::printf("case %dx%d seed %u: maps differ\n", w, h, seed);
+        return 1;
+    }
+    return par ? 0 : -1;  // -1: one piece, the serial form ran
+}
+
+int main() {
+    int bad = 0, parallel = 0, cases = 0;
+    for (unsigned seed = 1; seed <= 60; seed++) {
+        const int w = 40 + (seed * 37) % 300, h = 30 + (seed * 53) % 200;
+        for (int touching = 0; touching < 2; touching++) {
+            const int r = run_case(w, h, seed, 3 + seed % 20, 4 + seed % 30, touching != 0, seed % 3 != 0, 1 + seed % 5);
+            cases++;
+            if (r > 0) bad++;
+            if (r == 0) parallel++;
+        }
+    }
+    // the second call on the same state (sparse resets) and a large frame
+    {
+        March m;
+        for (int rep = 0; rep < 3; rep++) {
+            const std::vector<uint8_t> mask = random_mask(640, 480, 100 + rep, 40, 30, rep == 1);
+            March ref;
+            ref.prepare(640, 480, 3);
+            m.prepare(640, 480, 3);
+            march_begin(mask.data(), true, ref);
+            march_begin(mask.data(), true, m);
+            while (march_advance(ref, 1 << 30) > 0) {}
+            march_parallel_run(m, 1);
+            while (march_advance(m, 8192) > 0) {}
+            cases++;
+            if (ref.pix != m.pix || ref.t != m.t) {
+                std::printf("repeat %d on one state differs\n", rep);
+                bad++;
+            } else
+                parallel++;
+        }
+    }
+    std::printf("%d cases, %d marched in parallel, %d failed\n", cases, parallel, bad);
+    return bad ? 1 : 0;
+}

@@ -260,3 +260,26 @@ def test_one_context_many_masks_and_sizes(oracle, ofxcv):
         assert np.array_equal(got.cpu().numpy(), ref), (case, kind)
     assert ctx.inpaint_fallback_count() == 0
     ctx.close()
+
+
+def test_parallel_front_march_option_gives_the_same_maps_and_colours(oracle, ofxcv):
+    """option inpaint.parallel_march: the hole's 4-connected components are marched on host threads and merged into the exact
+    sequential fill order (telea_march.h) -- distance map, order map and colours equal the serial form's and the oracle's"""
+    import torch
+    from openfx_opencv_amd import synth
+    fr = synth.inpaint_frame(640, 480)
+    d = torch.from_numpy(fr).cuda()
+    outs = []
+    for par in (0, 1):
+        c = ofxcv.Context(0)
+        c.set_option("inpaint.parallel_march", 2 if par else 0)   # (2: from two hole pixels on)
+        m = c.inpaint_mask(d, 1)
+        for _ in range(2):                                         # twice: the host state is reused
+            dst, t, order = c.inpaint_telea(d, m, 3.0, maps=True)
+        torch.cuda.synchronize()
+        outs.append((dst.cpu().numpy(), t.cpu().numpy(), order.cpu().numpy()))
+        c.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    ref = oracle.inpaint_render(fr, 3.0, 1.0)
+    assert np.array_equal(outs[1][0][..., :3], ref[..., :3])
