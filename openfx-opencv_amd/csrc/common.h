@@ -76,6 +76,8 @@ struct ofxcv_ctx {
     // 4-wavefront workgroups on the large levels too
     int fb_fold_min_tiles = 256, fb_fold_rows = 0;
     bool fb_fold_nw4 = false;
+    int fb_fold_nw = 0;          // option "farneback.fold_nw": wavefronts per workgroup of the folded kernel on the large levels: 0 (default) four of 8 or 9 rows, 4 four of 8 rows, 8 the eight-wavefront forms (4 / 5 rows)
+    int fb_solves_first = 0;     // A/B (option "farneback.solves_first"): folded kernel with all solves of a wavefront before its first gather
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one

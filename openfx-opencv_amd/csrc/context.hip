@@ -250,6 +250,14 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->fb_batch_mb = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.fold_nw")) {
+        ctx->fb_fold_nw = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.solves_first")) {
+        ctx->fb_solves_first = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.fold_strip")) {
         ctx->fb_fold_strip = value;
         return OFXCV_OK;

@@ -1785,12 +1785,14 @@ __global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restr
     fold_finish<NW>(M, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
 }
 
-template <bool UPDATE, int RW, int NW, bool VAR>
+// SF ("solves first"): the 2x2 solves of all rows of the wavefront run before the first gather is issued -- they only depend
+// on the column sums, so they are independent instruction chains the SIMD can interleave -- instead of row by row
+template <bool UPDATE, int RW, int NW, bool VAR, bool SF = false>
 __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                            const float *__restrict__ Min, float *__restrict__ Mout,
                                                            FlowTab flows, int w, int h, int pitch, double scale,
                                                            FoldArgs fa, size_t pair_stride) {
-    constexpr bool PIPE = RW < 8;  // with 8 rows per wavefront the second in-flight pixel record does not fit 128 registers
+    constexpr bool PIPE = RW < 8 || SF;  // with 8 rows per wavefront the second in-flight pixel record only fits 128 registers in the solves-first form
     static_assert(RW >= 3 && (!VAR || RW >= 4), "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
     __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
     __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
@@ -1877,10 +1879,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
             if (j >= 3) I[c] += (double)(mm.v[c] - mo[j - 3][c]);   // t = y-1: rows y, y-3, both in this wavefront
         }
     };
-#pragma unroll
-    for (int j = 0; j < RW; j++) {
-        const int y = a + j;
-        if (j >= nr || y >= h) break;  // wave-uniform
+    auto solve_row = [&](int j, float &fxv, float &fyv) {
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -1889,8 +1888,26 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
         }
         double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
         double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+        fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    };
+    float fxs[RW], fys[RW];
+    if (SF) {
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+            if (j < nr && a + j < h) solve_row(j, fxs[j], fys[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < RW; j++) {
+        const int y = a + j;
+        if (j >= nr || y >= h) break;  // wave-uniform
+        float fxv, fyv;
+        if (SF) {
+            fxv = fxs[j];
+            fyv = fys[j];
+        } else {
+            solve_row(j, fxv, fyv);
+        }
         if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
         if (UPDATE) {
             Px cur;
@@ -2258,6 +2275,33 @@ FoldGeom fold_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     if (large && (ctx->fb_fold_rows == 3 || ctx->fb_fold_rows == 8)) g.rw = ctx->fb_fold_rows;
     g.sh = g.rw * g.nw;
     g.var = false;
+    if (large && ctx->fb_fold_nw != 8) {
+        // Tall wavefronts (default on the bandwidth-bound levels): four wavefronts of 8 or 9 rows, all solves of a wavefront
+        // before its first gather.  Every wavefront re-reads three rows of M above / below its own (11 rows for 8 instead of
+        // 7 for 4) and pays the strip-sum exchange and the row-difference tail once: measured against the eight-wavefront
+        // form of 4 / 5 rows 38.5 -> 36.3 us per level-0 iteration at 1920x1080, 182 -> 167-173 us at 3840x2160, 980 ->
+        // 1000-1040 pairs/s with several calls in flight (profiles/r03_experiments.md).  Option farneback.fold_nw: 4 = 8 rows
+        // fixed, 8 = the eight-wavefront forms.
+        g.nw = 4;
+        g.rw = ctx->fb_fold_nw == 4 ? 8 : 9;
+        g.var = g.rw == 9;
+        g.sh = 32;
+        if (g.var) {  // strip height 33 .. 36 by the launch's rounds over the resident slots (four 4-wavefront workgroups per CU)
+            const double slots = 4.0 * ctx->num_cus;
+            double best_cost = 0;
+            for (int sh = 33; sh <= 36; sh++) {
+                if (ctx->fb_fold_strip >= 33 && ctx->fb_fold_strip <= 36 && sh != ctx->fb_fold_strip) continue;
+                const double r = (double)g.tiles_x * ofxcv_div_up(h, sh) * n / slots, full = std::floor(r), frac = r - full;
+                const double cost = sh * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0));
+                if (best_cost == 0 || cost < best_cost) {
+                    best_cost = cost;
+                    g.sh = sh;
+                }
+            }
+        }
+        g.nstrips = ofxcv_div_up(h, g.sh);
+        return g;
+    }
     if (large && g.nw == 8 && g.rw == 4 && ctx->fb_fold_strip != 32) {
         // Strip height 32 .. 40 (4 or 5 rows per wavefront) by the number of rounds the launch makes over the resident
         // workgroup slots (two 8-wavefront workgroups per CU): a round that is nearly empty costs almost a full one.
@@ -2301,7 +2345,11 @@ int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
     FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh};
     dim3 grid(g.tiles_x, g.nstrips, L.n);
     const int pitch = plane_pitch(w);
-    if (g.var) {
+    if (g.nw == 4 && g.rw == 8) {
+        hipLaunchKernelGGL((vsum_seed_kernel<8, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
+    } else if (g.nw == 4 && g.rw == 9) {
+        hipLaunchKernelGGL((vsum_seed_kernel<9, 4, true>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
+    } else if (g.var) {
         hipLaunchKernelGGL((vsum_seed_kernel<5, 8, true>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
     } else if (g.nw == 8) {
         if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
@@ -2335,8 +2383,23 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
         else                                                                                                                             \
             hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW, VAR>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
     } while (0)
-    if (g.var) {
+#define OFXCV_LAUNCH_TALL(RW, NW, VAR)                                                                                                   \
+    do {                                                                                                                                 \
+        if (update)                                                                                                                      \
+            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW, VAR, true>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW, VAR, false>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
+    } while (0)
+    if (g.nw == 4 && g.rw == 8) {  // four wavefronts of 8 rows
+        OFXCV_LAUNCH_TALL(8, 4, false);
+    } else if (g.nw == 4 && g.rw == 9) {  // ... of 8 or 9 rows
+        OFXCV_LAUNCH_TALL(9, 4, true);
+    } else if (g.var && update && ctx->fb_solves_first) {
+        hipLaunchKernelGGL((iterate3f_kernel<true, 5, 8, true, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes);
+    } else if (g.var) {
         OFXCV_LAUNCH_FOLD(5, 8, true);
+    } else if (g.nw == 8 && g.rw == 4 && update && ctx->fb_solves_first) {
+        hipLaunchKernelGGL((iterate3f_kernel<true, 4, 8, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes);
     } else if (g.nw == 8) {
         if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8, false);
         else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 8, false);

@@ -262,6 +262,16 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
         assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), fold
         outs.append(got)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+    # geometry of the folded kernel on the large levels: four wavefronts of 8 or 9 rows (default), of 8 rows, eight wavefronts
+    # of 4 / 5 rows with and without the solves-first order; fold_min 1 makes every level of these frames a "large" one
+    for opts in (dict(fold_nw=4), dict(fold_nw=8), dict(fold_nw=8, solves_first=1), dict(fold_nw=8, fold_strip=32), dict(fold_min=1),
+                 dict(fold_min=1, fold_nw=4), dict(fold_min=1, fold_nw=8), dict(fold_strip=35)):
+        ctx = ofxcv.Context(0)
+        for k, v in opts.items():
+            ctx.set_option("farneback." + k, v)
+        got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+        ctx.close()
+        assert np.array_equal(got, outs[0]), opts
 
 
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
