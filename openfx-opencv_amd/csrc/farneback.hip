@@ -1662,21 +1662,60 @@ __device__ __forceinline__ void fold_finish(const float *__restrict__ M, const F
 // flight at once), adds them up in ascending row order, the portion totals meet in LDS, and each wavefront then writes the
 // carries of its portion.  (With one wavefront per channel walking all boundaries in batches the launch took 9.9 us at
 // 1080p -- five dependent batches -- which is on the critical path when one pair is in flight.)
-constexpr int kScanQ = 4, kScanB = 9;  // portions per channel; boundaries per batch of loads
+constexpr int kScanQ = 8, kScanB = 8;  // portions per channel; boundaries per batch of loads
 __global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa,
                                                                 size_t pair_stride) {
     __shared__ double s_tot[kScanQ][64];
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int c = blockIdx.y;
-    M += (size_t)blockIdx.z * pair_stride;  // grid z = pair
-    fa.select_pair(blockIdx.z);
-    const int xr = blockIdx.x * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
+    int tbx, c, tbz;  // (tile column, channel, pair): neighbouring tile columns -- they read neighbouring 248-byte pieces of the same rows -- on one XCD
+    xcd_tile(tbx, c, tbz);
+    M += (size_t)tbz * pair_stride;
+    fa.select_pair(tbz);
+    const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
     const bool own = lane >= 1 && lane <= kSsW && xr < w;
     const size_t plane = (size_t)pitch * h;
     const float *m = M + c * plane + x;
     const size_t kst = (size_t)5 * pitch, kof = (size_t)c * pitch + x;
     const int nb = fa.nstrips - 1, per = (nb + kScanQ - 1) / kScanQ;  // boundaries s = 1 .. nstrips-1
     const int s_lo = 1 + q * per, s_hi = min(s_lo + per, fa.nstrips);
+    const float m_top = m[0];
+    if (per <= kScanB) {
+        // the usual case: the whole portion in one batch of loads, kept in registers for both passes (one memory round trip)
+        float r[kScanB][6];
+        double sp[kScanB];
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s_lo + i < s_hi) {
+                const int A = (s_lo + i) * sh;
+#pragma unroll
+                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
+                sp[i] = fa.Spart[(size_t)(s_lo + i - 1) * kst + kof];
+            }
+        double tot = 0.;
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s_lo + i < s_hi) {
+                tot += sp[i];
+                tot += (double)(r[i][3] - r[i][0]);
+                tot += (double)(r[i][4] - r[i][1]);
+                tot += (double)(r[i][5] - r[i][2]);
+            }
+        s_tot[q][lane] = tot;
+        __syncthreads();
+        double run = (double)(m_top * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
+        if (q == 0 && own) fa.Kout[kof] = run;
+        for (int u = 0; u < q; u++) run += s_tot[u][lane];
+#pragma unroll
+        for (int i = 0; i < kScanB; i++)
+            if (s_lo + i < s_hi) {
+                run += sp[i];                          // differences inside strip s-1
+                run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
+                if (own) fa.Kout[(size_t)(s_lo + i) * kst + kof] = run;
+                run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
+                run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
+            }
+        return;
+    }
     // pass 1: total of the portion (strip sums + the three boundary differences each)
     double tot = 0.;
     for (int s0 = s_lo; s0 < s_hi; s0 += kScanB) {
@@ -1701,7 +1740,7 @@ __global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__r
     }
     s_tot[q][lane] = tot;
     __syncthreads();
-    double run = (double)(m[0] * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
+    double run = (double)(m_top * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
     if (q == 0 && own) fa.Kout[kof] = run;
     for (int u = 0; u < q; u++) run += s_tot[u][lane];
     // pass 2: the carries of the portion (the same loads again: they hit in the cache)
