@@ -337,7 +337,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
-                     "kernel": ("iterate3f_kernel<true, 5, 8, true> (one blur+solve+update iteration in OpenCV's summation order, producing the column-sum carries "
+                     "kernel": ("iterate3f_kernel<true, 9, 4, true, true> (one blur+solve+update iteration in OpenCV's summation order, four wavefronts of 8 or 9 rows per workgroup, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
                                 "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
                      "bytes_per_launch": iter_bytes, "pairs_per_launch": ppl,
@@ -352,7 +352,7 @@ def main():
                                      "halo rows of M) at close to the achievable copy rate (6.3 TB/s); VALU issue is not the limit",
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
                      "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction) / launch time",
-                     "carry_kernel": ({"kernel": ("fold_scan_kernel (prefix of the f64 column sums over the 32-row strips from the strip sums the iteration kernel left "
+                     "carry_kernel": ({"kernel": ("fold_scan_kernel (prefix of the f64 column sums over the 33..36-row strips from the strip sums the iteration kernel left "
                                                   "and the six boundary rows per strip; one small launch per iteration)" if folded else
                                                   "vsum_carry_kernel<8> (f64 column-sum carries per 8-row strip from a pass over M; one launch per iteration)"),
                                        "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n,
