@@ -344,7 +344,7 @@ def main():
                      "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20) x %d x %d px x %d pairs "
                                               "per launch (grid z = pair)" % (W, H, ppl),
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
-                     "timing": "HIP event pairs on the launch stream, one batched call in flight (compare profiles/r03_bench_streams1_by_grid.txt)",
+                     "timing": "HIP event pairs on the launch stream, one batched call in flight (compare profiles/r03_bench_single_by_grid.txt)",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_note": "per launch of the batched kernel (PMC passes run the bench workload)",
