@@ -299,8 +299,8 @@ def main():
     alg = algorithmic_bytes_per_pair(W, H)
     pmc = pmc_kernels() if (W, H) == (1920, 1080) else {}
     folded = fold_mode != 0  # level 0 runs the folded-carry iteration kernel in modes 1..3
-    pm = pmc.get("opencv_order_folded_iteration_level0" if folded else "opencv_order_iteration_level0", {})
-    pc = pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
+    pm = pmc.get("opencv_order_halo_iteration_level0" if fold_mode >= 4 else "opencv_order_folded_iteration_level0" if folded else "opencv_order_iteration_level0", {})
+    pc = {} if fold_mode >= 4 else pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
     pf = pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes_pair = ITER_BYTES_PER_PX * W * H
     iter_bytes = iter_bytes_pair * ppl  # one launch of the dominant kernel carries `ppl` pairs of the batch
@@ -337,7 +337,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
-                     "kernel": ("iterate3f_kernel<true, 9, 4, true, true> (one blur+solve+update iteration in OpenCV's summation order, four wavefronts of 8 or 9 rows per workgroup, producing the column-sum carries "
+                     "kernel": ("iterate3h_kernel<kHaloIter, 9, 8, true> (one blur+solve+update iteration in OpenCV's summation order as ONE launch: overlapped strips of 65..72 computed rows, "
+                                "eight wavefronts of 8 or 9 rows per workgroup, the strip sums of its own output for the next launch's column-sum prefix; pyramid level 0, %dx%d)" if fold_mode >= 4 else
+                                "iterate3f_kernel<true, 9, 4, true, true> (one blur+solve+update iteration in OpenCV's summation order, four wavefronts of 8 or 9 rows per workgroup, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
                                 "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
                      "bytes_per_launch": iter_bytes, "pairs_per_launch": ppl,
@@ -358,7 +360,8 @@ def main():
                                        "avg_launch_us": carry_s * 1e6, "launches_timed": carry_n,
                                        "traffic": pc.get("traffic_bytes_per_launch"),
                                        "traffic_GBps": (pc["traffic_bytes_per_launch"] / carry_s / 1e9) if pc.get("traffic_bytes_per_launch") else None}
-                                      if carry_n else "none: the last workgroup of each tile column runs the prefix inside the iteration kernel"),
+                                      if carry_n else ("none: overlapped strips, the prefix over the strip sums is the iteration kernel's prologue" if fold_mode >= 4 else
+                                                       "none: the last workgroup of each tile column runs the prefix inside the iteration kernel")),
                      "fold_carries_mode": fold_mode,
                      "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
                                               "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes_pair,

@@ -67,8 +67,9 @@ struct ofxcv_ctx {
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
     int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
-    int fb_fold_carries = 3;  // OpenCV-order mode: 3 (default) = 2 on the bandwidth-bound levels (8-row wavefronts), 0 elsewhere; 0 carry pre-pass over all of M per iteration; 1 carries folded into the iteration kernel,
-                              // prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
+    int fb_fold_carries = 4;  // OpenCV-order mode: 4 (default) overlapped strips, ONE launch per iteration on every level (iterate3h_kernel); 5 = 4 on the bandwidth-bound
+                              // levels, 0 elsewhere; 3 (round-2 default) = 2 on the bandwidth-bound levels, 0 elsewhere; 0 carry pre-pass over all of M per iteration;
+                              // 1 carries folded into the iteration kernel, prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
     int fb_strict_variant = 0, fb_carry_groups = 0, fb_lds_pad = 0;  // A/B knobs of the strip-parallel form
     int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
     // A/B knobs of the folded form (options "farneback.fold_min" / "farneback.fold_rows" / "farneback.fold_nw4"): 62x64-pixel
@@ -78,6 +79,12 @@ struct ofxcv_ctx {
     bool fb_fold_nw4 = false;
     int fb_fold_nw = 0;          // option "farneback.fold_nw": wavefronts per workgroup of the folded kernel on the large levels: 0 (default) four of 8 or 9 rows, 4 four of 8 rows, 8 the eight-wavefront forms (4 / 5 rows)
     int fb_solves_first = 0;     // A/B (option "farneback.solves_first"): folded kernel with all solves of a wavefront before its first gather
+    // overlapped-strip form (fold_carries 4 / 5): option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
+    // 3 eight of 8 or 9; "farneback.halo_min8" / "halo_min4": workgroups from which the eight- / four-wavefront tall form is used;
+    // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
+    int fb_halo_geom = 0, fb_halo_min8 = 400, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
+    int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
+    int fb_halo_seed = 0;        // option "farneback.halo_seed" 1: the first M of a level from update_matrices_kernel + halo_seed_kernel instead of the iteration kernel's first forms
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one

@@ -238,6 +238,15 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_spin_limit = value;
         return OFXCV_OK;
     }
+    {
+        struct { const char *n; int *v; } knobs[] = {{"farneback.halo_geom", &ctx->fb_halo_geom}, {"farneback.halo_min8", &ctx->fb_halo_min8},
+                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_seed", &ctx->fb_halo_seed}, {"farneback.halo_deep", &ctx->fb_halo_deep}};
+        for (auto &k : knobs)
+            if (!std::strcmp(name, k.n)) {
+                *k.v = value;
+                return OFXCV_OK;
+            }
+    }
     if (!std::strcmp(name, "farneback.fold_rows")) {
         ctx->fb_fold_rows = value;
         return OFXCV_OK;
@@ -267,7 +276,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.fold_carries")) {
-        ctx->fb_fold_carries = value < 0 ? 0 : (value > 3 ? 3 : value);
+        ctx->fb_fold_carries = value < 0 ? 0 : (value > 5 ? 5 : value);
         return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.lds_pad")) {

@@ -812,6 +812,33 @@ __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, c
     return update_matrices_core(r0v, R1, x, y, w, h, pitch, plane, dx, dy);
 }
 
+// F6: the flow of the coarser level at pixel (x, y) of this one: resize INTER_LINEAR, then * 1/pyr_scale
+struct Prolong {
+    int pw, ph;                             // size of the coarser level
+    double inv_pyr_scale, scale_x, scale_y;  // scale = (double)pw / w, divided once on the host
+};
+__device__ __forceinline__ void prolong_flow(const float *__restrict__ flow, size_t flow_step, const Prolong &pr, int x, int y, float &dx, float &dy) {
+    int sx, sy;
+    float ax0, ax1, b0, b1;
+    lerp_coef_scaled(x, pr.pw, pr.scale_x, sx, ax0, ax1);
+    lerp_coef_scaled(y, pr.ph, pr.scale_y, sy, b0, b1);
+    int sy1 = min(sy + 1, pr.ph - 1);
+    const float2 *S0 = (const float2 *)((const char *)flow + (size_t)sy * flow_step);
+    const float2 *S1 = (const float2 *)((const char *)flow + (size_t)sy1 * flow_step);
+    float r0x, r0y, r1x, r1y;
+    if (sx + 1 < pr.pw) {
+        float2 a = S0[sx], b = S0[sx + 1], c = S1[sx], d = S1[sx + 1];
+        r0x = a.x * ax0 + b.x * ax1; r0y = a.y * ax0 + b.y * ax1;
+        r1x = c.x * ax0 + d.x * ax1; r1y = c.y * ax0 + d.y * ax1;
+    } else {
+        float2 a = S0[sx], c = S1[sx];
+        r0x = a.x * 1.f; r0y = a.y * 1.f;
+        r1x = c.x * 1.f; r1y = c.y * 1.f;
+    }
+    dx = (float)((double)(r0x * b0 + r1x * b1) * pr.inv_pyr_scale);
+    dy = (float)((double)(r0y * b0 + r1y * b1) * pr.inv_pyr_scale);
+}
+
 // F6 + first F4 of a level.  MODE 0: zero initial flow (coarsest level); MODE 1: flow prolongated from
 // the coarser level (resize INTER_LINEAR, then * 1/pyr_scale); MODE 2: explicit interleaved flow.
 template <int MODE>
@@ -831,25 +858,8 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
     const size_t flow_step = MODE ? flows.step[tbz] : 0;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
-        int sx, sy;
-        float ax0, ax1, b0, b1;
-        lerp_coef_scaled(x, pw, scale_x, sx, ax0, ax1);  // scale = (double)pw / w, divided once on the host
-        lerp_coef_scaled(y, ph, scale_y, sy, b0, b1);
-        int sy1 = min(sy + 1, ph - 1);
-        const float2 *S0 = (const float2 *)((const char *)flow + (size_t)sy * flow_step);
-        const float2 *S1 = (const float2 *)((const char *)flow + (size_t)sy1 * flow_step);
-        float r0x, r0y, r1x, r1y;
-        if (sx + 1 < pw) {
-            float2 a = S0[sx], b = S0[sx + 1], c = S1[sx], d = S1[sx + 1];
-            r0x = a.x * ax0 + b.x * ax1; r0y = a.y * ax0 + b.y * ax1;
-            r1x = c.x * ax0 + d.x * ax1; r1y = c.y * ax0 + d.y * ax1;
-        } else {
-            float2 a = S0[sx], c = S1[sx];
-            r0x = a.x * 1.f; r0y = a.y * 1.f;
-            r1x = c.x * 1.f; r1y = c.y * 1.f;
-        }
-        dx = (float)((double)(r0x * b0 + r1x * b1) * inv_pyr_scale);
-        dy = (float)((double)(r0y * b0 + r1y * b1) * inv_pyr_scale);
+        const Prolong pr = {pw, ph, inv_pyr_scale, scale_x, scale_y};
+        prolong_flow(flow, flow_step, pr, x, y, dx, dy);
     } else if (MODE == 2) {
         float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
         dx = f.x;
@@ -1992,6 +2002,301 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
     fold_finish<NW>(Mout, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
 }
 
+// ------------------------------------------------------------------ OpenCV-order window, overlapped strips: ONE launch per iteration
+//
+// The folded form above still needs a second launch per iteration (fold_scan_kernel) for the three row differences that
+// straddle a strip boundary: d_t = (float)(M'[t+1] - M'[t-2]) of the NEW field needs rows of two workgroups.  Here the strips
+// overlap instead: a workgroup that owns the output rows [A, A + SO) of the new M computes the rows [A - 2, A + SO] -- three
+// more, not stored -- so that every difference d_t with t in [A, A + SO) has both of its rows in this workgroup.  It leaves
+//     T_s  = sum of d_t over t in [A_s, A_s + SO)          (ascending t: wavefront sums, then the wavefronts in order)
+//     T'_s = the same without the last two (t < A_s + SO - 2)
+// and the next launch's strip s starts its column chain one row above ITS first computed row A_s - 2 with
+//     vsum(A_s - 3) = c0 + T_0 + ... + T_{s-2} + T'_{s-1},      c0 = (double)(3.f * M[0])
+// summed in that order in the kernel's prologue (<= 15 values per column and channel at 1080 rows with eight wavefronts per
+// strip, one channel per wavefront, while the rows of M are in flight).  No kernel reads what another workgroup of the same
+// launch wrote; nothing but f64 additions is re-associated, as in the other strip-parallel forms.  Price: SO + 3 rows are
+// computed for SO stored (4.3 % at 72-row strips), against one launch and ~18 MB of boundary rows per iteration saved.
+struct HaloArgs {
+    const double *Tin;    // [2][nstrips][5][pitch]  T (first half) and T' (second half) of Min
+    double *Tout;         // the same for Mout
+    int nstrips;
+    int so;               // output rows per strip (the strip computes so + 3)
+    size_t pair_vsum;     // batched calls: doubles between the T arrays of consecutive pairs
+    __device__ __forceinline__ void select_pair(int z) {
+        if (Tin) Tin += (size_t)z * pair_vsum;
+        Tout += (size_t)z * pair_vsum;
+    }
+};
+
+// T / T' of a field that already lies in memory (the first M of a pyramid level).  One workgroup per 64 columns, strip and
+// channel; its kSeedQ wavefronts take consecutive portions of at most kSeedR of the strip's differences (every load of a
+// portion in flight at once), the portion sums meet in LDS in ascending order.
+constexpr int kSeedQ = 8, kSeedR = 9;  // strips of up to 72 rows
+__global__ __launch_bounds__(64 * kSeedQ) void halo_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, HaloArgs ha, size_t pair_stride) {
+    __shared__ double s_t[kSeedQ][64], s_p[64];
+    const int z = blockIdx.z / 5, c = blockIdx.z - 5 * z;  // grid z = channel + 5 * pair
+    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), s = blockIdx.y;
+    M += (size_t)z * pair_stride;
+    ha.select_pair(z);
+    const float *m = M + (size_t)c * pitch * h + x;
+    const int A = s * ha.so, E = min(A + ha.so, h);           // differences t in [A, E): d_t = M[t+1] - M[t-2], rows clamped to the image
+    const int per = (ha.so + kSeedQ - 1) / kSeedQ;            // <= kSeedR
+    const int t0 = A + q * per, t1 = min(t0 + per, E), tp = A + ha.so - 2;  // T' stops before tp
+    float r[kSeedR + 3];  // rows t0-2 .. t0+per
+#pragma unroll
+    for (int i = 0; i < kSeedR + 3; i++) r[i] = i < per + 3 ? m[(size_t)clampi(t0 - 2 + i, 0, h - 1) * pitch] : 0.f;
+    double acc = 0., accp = 0.;
+#pragma unroll
+    for (int i = 0; i < kSeedR; i++) {
+        if (t0 + i == tp) accp = acc;
+        if (t0 + i < t1) acc += (double)(r[i + 3] - r[i]);
+    }
+    const int qp = (ha.so - 2) / per;  // the portion that holds difference tp (< kSeedQ)
+    s_t[q][lane] = acc;
+    if (q == qp) s_p[lane] = accp;
+    __syncthreads();
+    if (q == 0 && xr < w) {
+        double sum = 0., sump = 0.;
+        for (int u = 0; u < kSeedQ; u++) {
+            if (u == qp) sump = sum + s_p[lane];
+            sum += s_t[u][lane];
+        }
+        const size_t o = ((size_t)s * 5 + c) * pitch + xr, tq = (size_t)ha.nstrips * 5 * pitch;
+        ha.Tout[o] = sum;
+        ha.Tout[tq + o] = sump;
+    }
+}
+
+// KIND: what the flow of a row comes from, and what leaves the kernel
+//   kHaloLast    solve of box(Min); the flow of the stored rows goes to `flows` (last iteration of a level), no Mout
+//   kHaloIter    solve of box(Min); Mout = UpdateMatrices(R0, R1, flow) + T / T' of Mout
+//   kHaloZero / kHaloCoarse / kHaloGiven   the FIRST M of a level (+ its T / T'): zero flow (coarsest level), the coarser
+//                level's flow prolongated (F6, `flows` = that flow), the caller's flow (`flows`, USE_INITIAL_FLOW at level 0)
+enum { kHaloLast = 0, kHaloIter = 1, kHaloZero = 2, kHaloCoarse = 3, kHaloGiven = 4 };
+
+// DEEP: the gathers of ALL rows of the wavefront are in flight before the first row is finished (one memory latency per
+// wavefront instead of one per row; ~200 registers) -- the form of the small levels, whose launches have at most two
+// wavefronts per SIMD and are bound by their critical path, not by throughput
+template <int KIND, int RW, int NW, bool VAR, bool DEEP = false>
+__global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                               const float *__restrict__ Min, float *__restrict__ Mout,
+                                                               FlowTab flows, Prolong pr, int w, int h, int pitch, double scale,
+                                                               HaloArgs ha, size_t pair_stride) {
+    constexpr bool UPDATE = KIND != kHaloLast, SOLVE = KIND <= kHaloIter;
+    // the last two differences of a strip must be differences inside the last wavefront (T' is its sum without them)
+    static_assert(VAR ? RW >= 6 : RW >= 5, "at least five rows per wavefront");
+    __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
+    __shared__ double s_kin[5][64];          // vsum of Min one row above the strip's first computed row
+    __shared__ double s_ip[5][64];           // the last wavefront's sum without the strip's last two differences
+    __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    R0 += (size_t)tbz * pair_stride;
+    R1 += (size_t)tbz * pair_stride;
+    if (SOLVE) Min += (size_t)tbz * pair_stride;
+    if (UPDATE) Mout += (size_t)tbz * pair_stride;
+    ha.select_pair(tbz);
+    float *__restrict__ flow = flows.p[tbz];  // kHaloLast: out; kHaloCoarse / kHaloGiven: in; otherwise unused
+    const size_t flow_step = flows.step[tbz];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x0 = tbx * kSsW;
+    const int SC = VAR ? ha.so + 3 : RW * NW, SO = SC - 3;  // rows computed / stored per strip
+    int off, nr;  // this wavefront's rows inside the computed strip (wave-uniform)
+    wave_rows<RW, NW, VAR>(SC, wave, off, nr);
+    const int A = tby * SO, a = A - 2 + off;  // a < 0 only for the first wavefront of the top strip (a = -2)
+    const bool top = a < 0;
+    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
+    const bool own = lane >= 1 && lane <= kSsW && xr < w;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
+    const Buf bM = make_buf(Min, SOLVE ? 5 * plane * sizeof(float) : 0), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+    auto valid = [&](int j) { return j < nr && a + j >= 0 && a + j < h; };                  // a row of the image (wave-uniform)
+    auto stored = [&](int j) { return valid(j) && a + j >= A && a + j < A + SO; };         // ... that this strip owns
+
+    float fxs[RW], fys[RW];
+    if (SOLVE) {
+        // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
+        float m[RW + 3][5];
+#pragma unroll
+        for (int r = 0; r < RW + 3; r++) {
+            if (VAR && r == RW + 2 && nr < RW) {  // a short wavefront has no use for the last row
+#pragma unroll
+                for (int c = 0; c < 5; c++) m[r][c] = 0.f;
+                continue;
+            }
+            const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
+#pragma unroll
+            for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
+        }
+        // prologue: the chain's start value from the strip sums the previous launch left (one channel per wavefront)
+        for (int c = wave; c < 5; c += NW) {
+            double k = (double)(buf_ld(bM, vx, c * pb) * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
+            if (tby > 0) {
+                const size_t kst = (size_t)5 * pitch;
+                const double *T = ha.Tin + (size_t)c * pitch + x;
+                const int n = tby - 1;  // T of the strips 0 .. tby-2, then T' of strip tby-1
+                constexpr int CH = 16;  // one batch of loads up to 17 strips
+                const double tl = T[(size_t)(ha.nstrips + n) * kst];
+                for (int s0 = 0; s0 < n; s0 += CH) {
+                    double t[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; i++) t[i] = s0 + i < n ? T[(size_t)(s0 + i) * kst] : 0.;
+#pragma unroll
+                    for (int i = 0; i < CH; i++)
+                        if (s0 + i < n) k += t[i];
+                }
+                k += tl;
+            }
+            s_kin[c][lane] = k;
+        }
+        // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
+        float d[RW][5];
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) d[j][c] = m[j + 3][c] - m[j][c];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double t = 0.;
+#pragma unroll
+            for (int j = 0; j < RW; j++)
+                if (valid(j)) t += (double)d[j][c];
+            s_w[wave][c][lane] = t;
+        }
+        __syncthreads();
+        double D[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            D[c] = s_kin[c][lane];
+            for (int u = 0; u < wave; u++) D[c] += s_w[u][c][lane];  // vsum just above this wavefront's first row
+        }
+        __syncthreads();  // s_w is reused for the sums of Mout
+
+        // all solves of the wavefront first: they only depend on the column sums (independent chains the SIMD can interleave)
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            if (!valid(j)) continue;  // wave-uniform
+            double acc[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) D[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
+            if (!UPDATE && !stored(j)) continue;                   // the last iteration of a level has no use for the halo rows
+#pragma unroll
+            for (int c = 0; c < 5; c++) acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
+            double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+            double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+            fxs[j] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+            fys[j] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+            if (!UPDATE && flow && own) *(float2 *)((char *)flow + (size_t)(a + j) * flow_step + (size_t)xr * 8) = make_float2(fxs[j], fys[j]);
+        }
+        if (!UPDATE) return;
+    } else {
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            fxs[j] = fys[j] = 0.f;
+            if (KIND == kHaloZero || !valid(j)) continue;
+            if (KIND == kHaloCoarse) {
+                prolong_flow(flow, flow_step, pr, x, a + j, fxs[j], fys[j]);
+            } else {
+                const float2 f = *(const float2 *)((const char *)flow + (size_t)(a + j) * flow_step + (size_t)x * 8);
+                fxs[j] = f.x;
+                fys[j] = f.y;
+            }
+        }
+    }
+
+    struct Px {
+        Taps tp;
+        float r0v[5];
+        float fxv, fyv;
+    };
+    Px prev;
+    float mo[RW][5];   // rows of Mout as they are produced (only the last three finished ones stay live)
+    double I[5] = {0., 0., 0., 0., 0.};   // row differences of Mout with both rows in this wavefront, ascending t
+    double Ip[5] = {0., 0., 0., 0., 0.};  // last wavefront: I before the strip's last two differences
+    auto finish = [&](const Px &p, int j) {
+        const int y = a + j;
+        M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
+        const bool st = own && y >= A && y < A + SO;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            mo[j][c] = mm.v[c];
+            if (st) buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+            if (j < 3) s_first[wave][j][c][lane] = mm.v[c];
+            // rows above row 0 are row 0 (t = 0, 1 are row 1 - row 0, row 2 - row 0): the top wavefront's rows -2, -1
+            if (j == 2 && top) mo[0][c] = mo[1][c] = mm.v[c];
+            if (j >= 3) {   // t = y-1: rows y, y-3, both in this wavefront
+                if (wave == NW - 1 && j == nr - 2) Ip[c] = I[c];
+                I[c] += (double)(mm.v[c] - mo[j - 3][c]);
+            }
+        }
+    };
+    // the valid rows of a wavefront are consecutive (rows -2, -1 of the top wavefront, rows below the image and the missing
+    // row of a short wavefront lie at its ends); all conditions are wave-uniform
+    if (DEEP) {
+        Px all[RW];
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            if (!valid(j)) continue;
+            all[j].fxv = fxs[j];
+            all[j].fyv = fys[j];
+#pragma unroll
+            for (int c = 0; c < 5; c++) all[j].r0v[c] = buf_ld(bR0, vx, (unsigned)(a + j) * rb + c * pb);
+            all[j].tp = gather_taps(bR1, x, a + j, w, h, pitch, pb, fxs[j], fys[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+            if (valid(j)) finish(all[j], j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            if (!valid(j)) continue;
+            const int y = a + j;
+            Px cur;
+            cur.fxv = fxs[j];
+            cur.fyv = fys[j];
+#pragma unroll
+            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, cur.fxv, cur.fyv);
+            if (j > 0 && valid(j - 1)) finish(prev, j - 1);  // the gather of row j is in flight while the row before it is finished
+            prev = cur;
+        }
+#pragma unroll
+        for (int j = 0; j < RW; j++)
+            if (valid(j) && !(j + 1 < RW && valid(j + 1))) finish(prev, j);
+    }
+    __syncthreads();  // every wavefront's first three rows are in LDS
+    // the three differences across the boundary to the wavefront below (t = b-1, b, b+1 with b its first row): its rows
+    // 0..2 against this wavefront's last three
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        double sum = I[c];
+        if (wave < NW - 1) {
+            const bool full = !VAR || nr == RW;  // a short wavefront's last three rows are one index earlier
+            const float l0 = full ? mo[RW - 3][c] : mo[RW - 4][c], l1 = full ? mo[RW - 2][c] : mo[RW - 3][c],
+                        l2 = full ? mo[RW - 1][c] : mo[RW - 2][c];
+            sum += (double)(s_first[wave + 1][0][c][lane] - l0);
+            sum += (double)(s_first[wave + 1][1][c][lane] - l1);
+            sum += (double)(s_first[wave + 1][2][c][lane] - l2);
+        } else {
+            s_ip[c][lane] = Ip[c];
+        }
+        s_w[wave][c][lane] = sum;
+    }
+    __syncthreads();
+    if (wave < 2 && own) {  // wavefront 0 writes T, wavefront 1 T'
+        const size_t tq = (size_t)ha.nstrips * 5 * pitch;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            double sum = s_w[0][c][lane];
+            for (int u = 1; u < NW - 1; u++) sum += s_w[u][c][lane];
+            sum += wave == 0 ? s_w[NW - 1][c][lane] : s_ip[c][lane];
+            ha.Tout[(wave ? tq : 0) + ((size_t)tby * 5 + c) * pitch + xr] = sum;
+        }
+    }
+}
+
 
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
@@ -2046,10 +2351,12 @@ struct Layout {
 //   serial column scan / Gaussian vertical pass   5 * pitch * h values
 //   carry pre-pass                                (strips of >= 2 rows + up to 8 group totals + 1) * 5 * pitch
 //   folded carries                                3 * (strips of >= 12 rows + 1) * 5 * pitch
+//   overlapped strips                             4 * (strips of >= 17 rows + 1) * 5 * pitch
 size_t vsum_doubles(int w, int h) {
     const size_t pitch = (size_t)plane_pitch(w);
     const size_t a = 5 * pitch * h, b = (size_t)(ofxcv_div_up(h, 2) + 10) * 5 * pitch, c = 3 * (size_t)(ofxcv_div_up(h, 12) + 1) * 5 * pitch;
-    return round_up(std::max(a, std::max(b, c)), 32);
+    const size_t d = 4 * (size_t)(ofxcv_div_up(h, 17) + 1) * 5 * pitch;  // overlapped strips: T and T', two buffers
+    return round_up(std::max(std::max(a, d), std::max(b, c)), 32);
 }
 
 int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, int levels, Layout &L) {
@@ -2459,6 +2766,102 @@ int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     return OFXCV_OK;
 }
 
+// OpenCV-order window, overlapped strips (iterate3h_kernel): one launch per iteration.  Strip geometry by the number of
+// workgroups the launch has over the whole batch: eight wavefronts of 8 or 9 rows (65..72 computed rows per strip) where that
+// still fills the chip, four of 8 or 9 (33..36) below that, four of 5 rows on the small levels (their launches are latency-bound).
+struct HaloGeom {
+    int rw, nw, tiles_x, nstrips, so;  // so = output rows per strip (computed rows - 3)
+};
+HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
+    HaloGeom g;
+    g.tiles_x = ofxcv_div_up(w, kSsW);
+    const long t = (long)g.tiles_x * n;
+    int form = ctx->fb_halo_geom;  // 0 = by size, 1 small, 2 four tall wavefronts, 3 eight
+    if (form < 1 || form > 3) form = t * ofxcv_div_up(h, 69) >= ctx->fb_halo_min8 ? 3 : (t * ofxcv_div_up(h, 33) >= ctx->fb_halo_min4 ? 2 : 1);
+    if (form == 1) {
+        g.nw = 4;
+        g.rw = 5;
+        g.so = 17;
+    } else {
+        g.nw = form == 3 ? 8 : 4;
+        g.rw = 9;
+        // computed rows per strip: nw * 8 + 1 .. nw * 9, by the rounds the launch makes over the resident workgroup slots
+        // (16 wavefronts per CU): a round that is nearly empty costs almost a full one
+        const double slots = 16.0 / g.nw * ctx->num_cus;
+        double best_cost = 0;
+        int best = g.nw * 9;
+        for (int sc = g.nw * 8 + 1; sc <= g.nw * 9; sc++) {
+            if (ctx->fb_halo_strip > 0 && sc != ctx->fb_halo_strip && ctx->fb_halo_strip > g.nw * 8 && ctx->fb_halo_strip <= g.nw * 9) continue;
+            const double r = (double)t * ofxcv_div_up(h, sc - 3) / slots, full = std::floor(r), frac = r - full;
+            const double cost = sc * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0));
+            if (best_cost == 0 || cost <= best_cost) {
+                best_cost = cost;
+                best = sc;
+            }
+        }
+        g.so = best - 3;
+    }
+    g.nstrips = ofxcv_div_up(h, g.so);
+    return g;
+}
+struct HaloScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles further)
+    double *T[2];
+};
+size_t halo_scratch_doubles(int w0, int h0) {  // one buffer: T and T' for strips of >= 17 output rows
+    return 2 * (size_t)(ofxcv_div_up(h0, 17) + 1) * 5 * plane_pitch(w0);
+}
+HaloScratch halo_scratch(int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
+    HaloScratch hs;
+    hs.T[0] = L.vsum_ptr;
+    hs.T[1] = L.vsum_ptr + halo_scratch_doubles(w0, h0);
+    return hs;
+}
+int launch_halo_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const HaloScratch &hs, int slot, const Layout &L) {
+    const HaloGeom g = halo_geom(ctx, w, h, L.n);
+    HaloArgs ha = {nullptr, hs.T[slot], g.nstrips, g.so, L.vsum};
+    hipLaunchKernelGGL(halo_seed_kernel, dim3(ofxcv_div_up(w, 64), g.nstrips, 5 * L.n), dim3(64 * kSeedQ), 0, s, M, w, h, plane_pitch(w), ha, L.planes);
+    OFXCV_LAUNCH_CHECK(ctx, "halo_seed_kernel");
+    return OFXCV_OK;
+}
+// kind: kHaloLast / kHaloIter = one iteration (Min -> flows / Mout); kHaloZero / kHaloCoarse / kHaloGiven = the first M of a
+// level together with its strip sums (Min unused; `flows` = the coarser level's / the caller's flow)
+int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
+                          const Prolong &pr, int w, int h, int kind, const HaloScratch &hs, int slot, const Layout &L) {
+    const HaloGeom g = halo_geom(ctx, w, h, L.n);
+    HaloArgs ha = {hs.T[slot], hs.T[slot ^ 1], g.nstrips, g.so, L.vsum};
+    if (kind >= kHaloZero) {  // writes the strip sums of the M it produces into T[slot]
+        ha.Tin = nullptr;
+        ha.Tout = hs.T[slot];
+    }
+    dim3 grid(g.tiles_x, g.nstrips, L.n);
+    const int pitch = plane_pitch(w);
+    const double scale = 1. / 9.;
+    int rc;
+    const int mark = ctx->prof_now ? ctx->prof_on : 0;
+    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+#define OFXCV_LAUNCH_HALO_K(KIND, RW, NW, VAR, DEEP) \
+    hipLaunchKernelGGL((iterate3h_kernel<KIND, RW, NW, VAR, DEEP>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes)
+#define OFXCV_LAUNCH_HALO(RW, NW, VAR, DEEP)                                      \
+    do {                                                                          \
+        if (kind == kHaloIter) OFXCV_LAUNCH_HALO_K(kHaloIter, RW, NW, VAR, DEEP);  \
+        else if (kind == kHaloLast) OFXCV_LAUNCH_HALO_K(kHaloLast, RW, NW, VAR, false); \
+        else if (kind == kHaloZero) OFXCV_LAUNCH_HALO_K(kHaloZero, RW, NW, VAR, DEEP); \
+        else if (kind == kHaloCoarse) OFXCV_LAUNCH_HALO_K(kHaloCoarse, RW, NW, VAR, DEEP); \
+        else OFXCV_LAUNCH_HALO_K(kHaloGiven, RW, NW, VAR, DEEP);                   \
+    } while (0)
+    // small form: every gather of a wavefront in flight at once while the launch has at most two wavefronts per SIMD
+    const bool deep = g.rw == 5 && ctx->fb_halo_deep && (long)g.tiles_x * g.nstrips * L.n * 4 <= (long)ctx->fb_halo_deep * 4 * ctx->num_cus;
+    if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);
+    else if (g.rw == 5) OFXCV_LAUNCH_HALO(5, 4, false, false);
+    else if (g.nw == 4) OFXCV_LAUNCH_HALO(9, 4, true, false);
+    else OFXCV_LAUNCH_HALO(9, 8, true, false);
+#undef OFXCV_LAUNCH_HALO
+#undef OFXCV_LAUNCH_HALO_K
+    OFXCV_LAUNCH_CHECK(ctx, "iterate3h_kernel");
+    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+    return OFXCV_OK;
+}
+
 // two fused iterations M -> M'' (winsize 3, direct-window mode), pair by pair
 int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
                           bool level0, const Layout &L) {
@@ -2650,6 +3053,17 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             float *Mg[2] = {M0, M1};
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4), gn), block(64, 4);
             const FlowTab out_tab = sub_tab(out_all, z0, gn);
+            // OpenCV-order window with the carries folded into the iteration kernel (fold) / with overlapped strips (halo)
+            const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && ctx->fb_fold_carries < 4 &&
+                              (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, gn));  // 3: only the levels that are bandwidth-bound
+            const bool halo = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries >= 4 &&
+                              (ctx->fb_fold_carries != 5 || fold_level_is_large(ctx, w, h, gn));  // 5: only the bandwidth-bound levels
+            // halo: the level's first M and its strip sums come from the iteration kernel's "first" forms in one launch
+            // (option farneback.halo_seed 1: update_matrices_kernel + halo_seed_kernel, which re-reads M)
+            const bool halo_first = halo && !ctx->fb_halo_seed;
+            HaloScratch hs = {};
+            if (halo) hs = halo_scratch(width, height, G);
+            const Prolong no_pr = {0, 0, 1.0, 1.0, 1.0};
             if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
                 // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
                 FlowTab init = sub_tab(out, z0, gn);
@@ -2663,17 +3077,24 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                         OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
                     }
                 }
-                hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R0, R1, init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
-            } else if (!have_prev)
-                hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
-            else
-                hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R0, R1, sub_tab(prev_all, z0, gn), pw, ph, 1. / pyr_scale, (double)pw / w,
-                                   (double)ph / h, w, h, pitch, M0, L.planes);
+                if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, init, no_pr, w, h, kHaloGiven, hs, 0, G);
+                else hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R0, R1, init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+            } else if (!have_prev) {
+                if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, no_flow, no_pr, w, h, kHaloZero, hs, 0, G);
+                else hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+            } else {
+                const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
+                if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, sub_tab(prev_all, z0, gn), pr, w, h, kHaloCoarse, hs, 0, G);
+                else hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R0, R1, sub_tab(prev_all, z0, gn), pw, ph, pr.inv_pyr_scale, pr.scale_x,
+                                        pr.scale_y, w, h, pitch, M0, L.planes);
+            }
+            if (halo_first && rc) return rc;
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
             int cur = 0;
-            // OpenCV-order window with the carries folded into the iteration kernel: seed the carries of the level's first M
-            const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries &&
-                              (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, gn));  // 3: only the levels that are bandwidth-bound
+            if (halo && !halo_first) {
+                rc = launch_halo_seed(ctx, s, M0, w, h, hs, 0, G);
+                if (rc) return rc;
+            }
             FoldScratch fs = {};
             if (fold) {
                 fs = fold_scratch(ctx, width, height, G);
@@ -2698,6 +3119,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                     const FlowTab &ft = update ? no_flow : out_tab;
                     if (gaussian)
                         rc = launch_gauss_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
+                    else if (halo)
+                        rc = launch_halo_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, no_pr, w, h, update ? kHaloIter : kHaloLast, hs, cur, G);
                     else if (fold)
                         rc = launch_fold_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, update, fs, cur, G);
                     else

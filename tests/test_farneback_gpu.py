@@ -253,7 +253,7 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
     ga, gb = _gray_pair(oracle, w, h)
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
     outs = []
-    for fold in (0, 1, 2, 3):
+    for fold in (0, 1, 2, 3, 4, 5):
         ctx = ofxcv.Context(0)
         ctx.set_option("farneback.fold_carries", fold)
         for _ in range(2):   # twice: the tile-column counters must be back at zero after a call
@@ -261,17 +261,42 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
         ctx.close()
         assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), fold
         outs.append(got)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     # geometry of the folded kernel on the large levels: four wavefronts of 8 or 9 rows (default), of 8 rows, eight wavefronts
     # of 4 / 5 rows with and without the solves-first order; fold_min 1 makes every level of these frames a "large" one
     for opts in (dict(fold_nw=4), dict(fold_nw=8), dict(fold_nw=8, solves_first=1), dict(fold_nw=8, fold_strip=32), dict(fold_min=1),
-                 dict(fold_min=1, fold_nw=4), dict(fold_min=1, fold_nw=8), dict(fold_strip=35)):
+                 dict(fold_min=1, fold_nw=4), dict(fold_min=1, fold_nw=8), dict(fold_strip=35),
+                 # overlapped strips (one launch per iteration): four wavefronts of 5 rows, four / eight of 8 or 9, fixed strip heights
+                 dict(fold_carries=4, halo_geom=1), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3),
+                 dict(fold_carries=4, halo_geom=2, halo_strip=33), dict(fold_carries=4, halo_geom=2, halo_strip=35),
+                 dict(fold_carries=4, halo_geom=3, halo_strip=65), dict(fold_carries=4, halo_geom=3, halo_strip=70),
+                 dict(fold_carries=5, fold_min=1, halo_geom=2), dict(fold_carries=4, halo_seed=1), dict(fold_carries=4, halo_seed=1, halo_geom=3)):
         ctx = ofxcv.Context(0)
         for k, v in opts.items():
             ctx.set_option("farneback." + k, v)
         got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
         ctx.close()
         assert np.array_equal(got, outs[0]), opts
+
+
+@pytest.mark.parametrize("w,h,levels", [(333, 257, 3), (160, 120, 0), (640, 480, 2)])
+def test_opencv_order_mode_overlapped_strips_first_matrix_forms(oracle, ofxcv, w, h, levels):
+    """farneback.fold_carries 4: the first M of a level and its strip sums come out of the iteration kernel's "first" forms
+    (zero flow on the coarsest level, the prolongated coarser flow below it, the caller's flow with USE_INITIAL_FLOW) --
+    same result as the carry pre-pass form, with and without an initial flow, for 1 .. 3 iterations"""
+    ga, gb = _gray_pair(oracle, w, h)
+    rng = np.random.default_rng(5)
+    init = rng.normal(0, 2, size=(h, w, 2)).astype(np.float32)
+    for kw in (dict(iterations=1), dict(iterations=2), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
+        outs = []
+        for opts in (dict(fold_carries=0), dict(fold_carries=4), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_seed=1)):
+            ctx = ofxcv.Context(0)
+            for k, v in opts.items():
+                ctx.set_option("farneback." + k, v)
+            args = (_dev(init.copy()),) if "flags" in kw else ()
+            outs.append(ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), *args, levels=levels, **kw).cpu().numpy())
+            ctx.close()
+        assert all(np.array_equal(outs[0], o) for o in outs[1:]), kw
 
 
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
@@ -439,7 +464,7 @@ def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
     w, h = 333, 257
     (a, b), (_, c) = _pairs(oracle, w, h, (5, 6))
     da, db, dc = _dev(a), _dev(b), _dev(c)
-    cases = [dict(opts=dict(opencv_rounding=1, fold_carries=f)) for f in (0, 1, 2, 3)]
+    cases = [dict(opts=dict(opencv_rounding=1, fold_carries=f)) for f in (0, 1, 2, 3, 4, 5)]
     cases += [dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
               dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
               dict(opts=dict(opencv_rounding=1, fold_carries=2, fold_min=1)), dict(opts=dict(opencv_rounding=1, fold_carries=1, fold_min=1))]
@@ -464,7 +489,7 @@ def test_batch_launch_groups(oracle, ofxcv, mb):
     ctx = ofxcv.Context(0)
     singles = [ctx.calc_optical_flow_farneback(_dev(a), _dev(b)).cpu().numpy() for a, b in prs]
     ctx.set_option("farneback.batch_mb", mb)
-    for fold in (3, 2):
+    for fold in (3, 2, 4):
         ctx.set_option("farneback.fold_carries", fold)
         ctx.set_option("farneback.fold_min", 1 if fold == 2 else 256)
         flows = ctx.calc_optical_flow_farneback_batch([_dev(a) for a, _ in prs], [_dev(b) for _, b in prs])
