@@ -27,7 +27,7 @@ constexpr int kFbGraphSlots = 4;
 struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
     int n, width, height, levels, winsize, iterations, poly_n, flags;
     double pyr_scale, poly_sigma;
-    const void *planes, *tmp, *cflow, *vsum;  // scratch addresses baked into the graph
+    const void *planes, *tmp, *cflow, *vsum, *persist;  // scratch addresses baked into the graph
     const void *prev[OFXCV_FB_MAX_BATCH], *next[OFXCV_FB_MAX_BATCH], *flow[OFXCV_FB_MAX_BATCH];
     size_t prev_step[OFXCV_FB_MAX_BATCH], next_step[OFXCV_FB_MAX_BATCH], flow_step[OFXCV_FB_MAX_BATCH];
 };
@@ -84,6 +84,10 @@ struct ofxcv_ctx {
     // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
     int fb_halo_geom = 0, fb_halo_min8 = 400, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
+    int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
+    int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
+    int fb_persist_spin = 1 << 22;  // option "farneback.persist_spin": polls of one wait before the launch gives up (abort flag)
+    DevBuf fb_persist_buf;       // [0] abort flag; tickets and step / strip counters of the persistent launches of a call
     int fb_halo_seed = 0;        // option "farneback.halo_seed" 1: the first M of a level from update_matrices_kernel + halo_seed_kernel instead of the iteration kernel's first forms
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its

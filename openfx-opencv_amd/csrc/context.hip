@@ -174,7 +174,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
     if (ctx->coarse) (void)hipStreamDestroy(ctx->coarse);
     if (ctx->ev_coarse) (void)hipEventDestroy(ctx->ev_coarse);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_persist_buf, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
@@ -240,7 +240,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     {
         struct { const char *n; int *v; } knobs[] = {{"farneback.halo_geom", &ctx->fb_halo_geom}, {"farneback.halo_min8", &ctx->fb_halo_min8},
-                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_seed", &ctx->fb_halo_seed}, {"farneback.halo_deep", &ctx->fb_halo_deep}};
+                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_seed", &ctx->fb_halo_seed}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"farneback.persist", &ctx->fb_persist}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 *k.v = value;
@@ -322,6 +322,18 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
+    else if (!std::strcmp(name, "farneback.persist")) *value = ctx->fb_persist;
+    else if (!std::strcmp(name, "farneback.persist_aborts")) {
+        // the sticky abort flag of the persistent small-level launches (waits for the context's work first)
+        *value = 0;
+        if (ctx->fb_persist_buf.ptr) {
+            unsigned flag = 0;
+            if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(&flag, ctx->fb_persist_buf.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
+                return OFXCV_ERR_HIP;
+            *value = (int)flag;
+        }
+    }
     else return OFXCV_ERR_INVALID;
     return OFXCV_OK;
 }

@@ -2012,7 +2012,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 //     T'_s = the same without the last two (t < A_s + SO - 2)
 // and the next launch's strip s starts its column chain one row above ITS first computed row A_s - 2 with
 //     vsum(A_s - 3) = c0 + T_0 + ... + T_{s-2} + T'_{s-1},      c0 = (double)(3.f * M[0])
-// summed in that order in the kernel's prologue (<= 15 values per column and channel at 1080 rows with eight wavefronts per
+// summed in that order in the kernel's prologue (c0 + T_0 and c0 + T'_0 are what the top strip stores: it owns row 0) (<= 15 values per column and channel at 1080 rows with eight wavefronts per
 // strip, one channel per wavefront, while the rows of M are in flight).  No kernel reads what another workgroup of the same
 // launch wrote; nothing but f64 additions is re-associated, as in the other strip-parallel forms.  Price: SO + 3 rows are
 // computed for SO stored (4.3 % at 72-row strips), against one launch and ~18 MB of boundary rows per iteration saved.
@@ -2062,6 +2062,11 @@ __global__ __launch_bounds__(64 * kSeedQ) void halo_seed_kernel(const float *__r
             if (u == qp) sump = sum + s_p[lane];
             sum += s_t[u][lane];
         }
+        if (s == 0) {  // the top strip's sums carry vsum(-1) = srow0 * (m + 2), a float product
+            const double c0 = (double)(m[0] * 3.f);
+            sum = c0 + sum;
+            sump = c0 + sump;
+        }
         const size_t o = ((size_t)s * 5 + c) * pitch + xr, tq = (size_t)ha.nstrips * 5 * pitch;
         ha.Tout[o] = sum;
         ha.Tout[tq + o] = sump;
@@ -2078,20 +2083,36 @@ enum { kHaloLast = 0, kHaloIter = 1, kHaloZero = 2, kHaloCoarse = 3, kHaloGiven 
 // DEEP: the gathers of ALL rows of the wavefront are in flight before the first row is finished (one memory latency per
 // wavefront instead of one per row; ~200 registers) -- the form of the small levels, whose launches have at most two
 // wavefronts per SIMD and are bound by their critical path, not by throughput
-template <int KIND, int RW, int NW, bool VAR, bool DEEP = false>
-__global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                               const float *__restrict__ Min, float *__restrict__ Mout,
-                                                               FlowTab flows, Prolong pr, int w, int h, int pitch, double scale,
-                                                               HaloArgs ha, size_t pair_stride) {
+// LROWS (short wavefronts, RW < 5): every row of Mout goes through LDS and the row differences are taken from there after the
+// rows are complete -- no constraint on the rows per wavefront.  A launch of a small level has less than one wavefront per
+// SIMD and its duration is the instruction stream of ONE wavefront: two or three rows per wavefront instead of five.
+template <int RW, int NW, bool LROWS>
+struct HaloLds {
+    double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
+    double s_kin[5][64];          // vsum of Min one row above the strip's first computed row
+    double s_ip[5][64];           // the last wavefront's sum without the strip's last two differences
+    float s_first[LROWS ? 1 : NW][3][5][64];   // the first three rows of Mout of every wavefront (for the wavefront above)
+    float s_rows[LROWS ? NW * RW : 1][5][64];  // LROWS: all computed rows of Mout
+};
+__device__ __forceinline__ float buf_ld_dev(const Buf &b, unsigned voff_bytes, unsigned soff_bytes) {  // sc0 | sc1: not served from a non-coherent cache
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff_bytes, (int)soff_bytes, 17));
+}
+
+// One workgroup's tile (tile column tbx, strip tby, pair tbz).  COH: the tile runs inside the persistent kernel below, where
+// Min / Tin were written by other workgroups of the SAME launch: device-scope loads for them, write-through stores for
+// Mout / Tout (R0 / R1 and the flows are not touched by the launch and stay ordinary accesses).
+template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH>
+__device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const float *__restrict__ R0, const float *__restrict__ R1,
+                                          const float *__restrict__ Min, float *__restrict__ Mout, const FlowTab &flows, const Prolong &pr,
+                                          int w, int h, int pitch, double scale, HaloArgs ha, size_t pair_stride, int tbx, int tby, int tbz) {
     constexpr bool UPDATE = KIND != kHaloLast, SOLVE = KIND <= kHaloIter;
     // the last two differences of a strip must be differences inside the last wavefront (T' is its sum without them)
-    static_assert(VAR ? RW >= 6 : RW >= 5, "at least five rows per wavefront");
-    __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
-    __shared__ double s_kin[5][64];          // vsum of Min one row above the strip's first computed row
-    __shared__ double s_ip[5][64];           // the last wavefront's sum without the strip's last two differences
-    __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
-    int tbx, tby, tbz;
-    xcd_tile(tbx, tby, tbz);
+    static_assert(LROWS ? (!VAR && RW >= 2) : (VAR ? RW >= 6 : RW >= 5), "at least five rows per wavefront unless the rows go through LDS");
+    auto &s_w = lds.s_w;
+    auto &s_kin = lds.s_kin;
+    auto &s_ip = lds.s_ip;
+    auto &s_first = lds.s_first;
+    auto &s_rows = lds.s_rows;
     R0 += (size_t)tbz * pair_stride;
     R1 += (size_t)tbz * pair_stride;
     if (SOLVE) Min += (size_t)tbz * pair_stride;
@@ -2117,6 +2138,32 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const 
 
     float fxs[RW], fys[RW];
     if (SOLVE) {
+        // prologue: the chain's start value from the strip sums the previous launch left (one channel per wavefront); issued
+        // ahead of the rows of M (loads return in order: the sums are added up while the rows are still in flight)
+        for (int c = wave; c < 5; c += NW) {
+            // vsum(-1) = srow0 * (m + 2), a float product of row 0: the top strip reads it; for the others it is part of the top
+            // strip's sums (a tile of the persistent kernel must not read rows outside its own neighbourhood)
+            double k = 0.;
+            if (tby == 0) {
+                k = (double)((COH ? buf_ld_dev(bM, vx, c * pb) : buf_ld(bM, vx, c * pb)) * 3.f);
+            } else {
+                const size_t kst = (size_t)5 * pitch;
+                const double *T = ha.Tin + (size_t)c * pitch + x;
+                const int n = tby - 1;  // T of the strips 0 .. tby-2, then T' of strip tby-1
+                constexpr int CH = 16;  // one batch of loads up to 17 strips
+                const double tl = COH ? ld_dev(T + (size_t)(ha.nstrips + n) * kst) : T[(size_t)(ha.nstrips + n) * kst];
+                for (int s0 = 0; s0 < n; s0 += CH) {
+                    double t[CH];
+#pragma unroll
+                    for (int i = 0; i < CH; i++) t[i] = s0 + i < n ? (COH ? ld_dev(T + (size_t)(s0 + i) * kst) : T[(size_t)(s0 + i) * kst]) : 0.;
+#pragma unroll
+                    for (int i = 0; i < CH; i++)
+                        if (s0 + i < n) k += t[i];
+                }
+                k += tl;
+            }
+            s_kin[c][lane] = k;
+        }
         // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
         float m[RW + 3][5];
 #pragma unroll
@@ -2128,28 +2175,7 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const 
             }
             const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
-            for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
-        }
-        // prologue: the chain's start value from the strip sums the previous launch left (one channel per wavefront)
-        for (int c = wave; c < 5; c += NW) {
-            double k = (double)(buf_ld(bM, vx, c * pb) * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
-            if (tby > 0) {
-                const size_t kst = (size_t)5 * pitch;
-                const double *T = ha.Tin + (size_t)c * pitch + x;
-                const int n = tby - 1;  // T of the strips 0 .. tby-2, then T' of strip tby-1
-                constexpr int CH = 16;  // one batch of loads up to 17 strips
-                const double tl = T[(size_t)(ha.nstrips + n) * kst];
-                for (int s0 = 0; s0 < n; s0 += CH) {
-                    double t[CH];
-#pragma unroll
-                    for (int i = 0; i < CH; i++) t[i] = s0 + i < n ? T[(size_t)(s0 + i) * kst] : 0.;
-#pragma unroll
-                    for (int i = 0; i < CH; i++)
-                        if (s0 + i < n) k += t[i];
-                }
-                k += tl;
-            }
-            s_kin[c][lane] = k;
+            for (int c = 0; c < 5; c++) m[r][c] = COH ? buf_ld_dev(bM, vx, so + c * pb) : buf_ld(bM, vx, so + c * pb);
         }
         // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
         float d[RW][5];
@@ -2221,11 +2247,21 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const 
         const bool st = own && y >= A && y < A + SO;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
+            if (st) {
+                if (COH) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+                else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+            }
+            if (LROWS) {
+                s_rows[off + j][c][lane] = mm.v[c];
+                continue;
+            }
             mo[j][c] = mm.v[c];
-            if (st) buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
             if (j < 3) s_first[wave][j][c][lane] = mm.v[c];
             // rows above row 0 are row 0 (t = 0, 1 are row 1 - row 0, row 2 - row 0): the top wavefront's rows -2, -1
-            if (j == 2 && top) mo[0][c] = mo[1][c] = mm.v[c];
+            if (j == 2 && top) {
+                mo[0][c] = mo[1][c] = mm.v[c];
+                s_kin[c][lane] = (double)(mm.v[c] * 3.f);  // vsum(-1) of the NEW field: goes into the top strip's sums
+            }
             if (j >= 3) {   // t = y-1: rows y, y-3, both in this wavefront
                 if (wave == NW - 1 && j == nr - 2) Ip[c] = I[c];
                 I[c] += (double)(mm.v[c] - mo[j - 3][c]);
@@ -2266,13 +2302,30 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const 
         for (int j = 0; j < RW; j++)
             if (valid(j) && !(j + 1 < RW && valid(j + 1))) finish(prev, j);
     }
-    __syncthreads();  // every wavefront's first three rows are in LDS
+    __syncthreads();  // every wavefront's first three rows (LROWS: all rows) are in LDS
+    if (LROWS) {
+        // this wavefront's differences (later row = one of its rows, strip row q = off + j >= 3; in the top strip rows above
+        // row 0 are row 0 = strip row 2), ascending; the strip's last two are the last two of the last wavefront
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int q = off + j;
+            if (q < 3 || !valid(j)) continue;
+            const int qe = tby == 0 ? max(q - 3, 2) : q - 3;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                if (wave == NW - 1 && j == RW - 2) Ip[c] = I[c];
+                I[c] += (double)(s_rows[q][c][lane] - s_rows[qe][c][lane]);
+            }
+        }
+    }
     // the three differences across the boundary to the wavefront below (t = b-1, b, b+1 with b its first row): its rows
     // 0..2 against this wavefront's last three
 #pragma unroll
     for (int c = 0; c < 5; c++) {
         double sum = I[c];
-        if (wave < NW - 1) {
+        if (LROWS) {
+            if (wave == NW - 1) s_ip[c][lane] = Ip[c];
+        } else if (wave < NW - 1) {
             const bool full = !VAR || nr == RW;  // a short wavefront's last three rows are one index earlier
             const float l0 = full ? mo[RW - 3][c] : mo[RW - 4][c], l1 = full ? mo[RW - 2][c] : mo[RW - 3][c],
                         l2 = full ? mo[RW - 1][c] : mo[RW - 2][c];
@@ -2292,11 +2345,108 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : 4) void iterate3h_kernel(const 
             double sum = s_w[0][c][lane];
             for (int u = 1; u < NW - 1; u++) sum += s_w[u][c][lane];
             sum += wave == 0 ? s_w[NW - 1][c][lane] : s_ip[c][lane];
-            ha.Tout[(wave ? tq : 0) + ((size_t)tby * 5 + c) * pitch + xr] = sum;
+            if (tby == 0) sum = (LROWS ? (double)(s_rows[2][c][lane] * 3.f) : s_kin[c][lane]) + sum;  // the top strip's sums carry vsum(-1)
+            double *o = ha.Tout + (wave ? tq : 0) + ((size_t)tby * 5 + c) * pitch + xr;
+            if (COH) st_dev(o, sum);
+            else *o = sum;
         }
     }
 }
 
+
+template <int KIND, int RW, int NW, bool VAR, bool DEEP = false, bool LROWS = (RW < 5)>
+__global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                               const float *__restrict__ Min, float *__restrict__ Mout,
+                                                               FlowTab flows, Prolong pr, int w, int h, int pitch, double scale,
+                                                               HaloArgs ha, size_t pair_stride) {
+    __shared__ HaloLds<RW, NW, LROWS> lds;
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz);
+}
+
+// ------------------------------------------------------------------ OpenCV-order window: ALL iterations of a small level in ONE launch
+//
+// A launch of a small pyramid level is bound by its own start-up and tear-down and by two dependent memory round trips from
+// a cold L2, not by work (a 240x135 iteration occupies 28 workgroups for 10 us), and a level needs iterations + 1 of them
+// back to back.  Here the level is one launch: its workgroups draw TICKETS from a counter -- ticket = (step, strip, pair,
+// tile column), step-major; step 0 = the level's first M, steps 1 .. iterations-1 = iterate, step `iterations` = the last
+// iteration (flow out) -- and run halo_tile for each.  A tile of step i reads rows of M and strip sums that tiles of step
+// i-1 wrote: it waits until every tile of the strips 0 .. s+1 of step i-1 (its own pair) has signalled completion (one
+// counter per pair, step and strip).  That also covers the write-after-read on the M ping-pong buffer (the readers of what
+// it overwrites are the strips s-1 .. s+1 of step i-1); the strip sums have one slot per step.  Data handed from one
+// workgroup to another goes through write-through stores and device-scope loads (no cache is flushed).
+// No deadlock for any number of resident workgroups: a tile only waits for tiles with SMALLER ticket numbers, every drawn
+// ticket belongs to a running workgroup, so the smallest unfinished ticket never waits.  The polls are bounded all the same
+// (`spin_limit`): a wait that runs out raises `abort`, every workgroup drains, and the host sees the flag with the result.
+struct PersistArgs {
+    unsigned *ticket;      // next ticket (0 on entry)
+    unsigned *cnt;         // [pairs][nsteps][nstrips] tiles that have finished (0 on entry)
+    unsigned *abort_flag;  // sticky: a wait ran out of polls
+    double *T;             // [nsteps][2][nstrips][5][pitch] strip sums of every step's M; pair z lies pair_vsum doubles further
+    int nsteps;            // iterations + 1
+    unsigned spin_limit;
+};
+
+template <int FIRST, int RW, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void iterate3p_kernel(const float *__restrict__ R0, const float *__restrict__ R1, float *__restrict__ M0,
+                                                               float *__restrict__ M1, FlowTab fin, FlowTab fout, Prolong pr, int w, int h,
+                                                               int pitch, double scale, int nstrips, int so, int tiles_x, int npairs,
+                                                               size_t pair_stride, size_t pair_vsum, PersistArgs pa) {
+    __shared__ HaloLds<RW, NW, true> lds;
+    __shared__ unsigned s_ticket, s_abort;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned row = (unsigned)tiles_x * npairs, per_step = row * nstrips, total = per_step * pa.nsteps;
+    const size_t tstep = (size_t)2 * nstrips * 5 * pitch;
+    // thread 0 draws the NEXT ticket while the current tile is computed (the draw is a round trip to the device's atomics)
+    unsigned next = 0;
+    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(pa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        __syncthreads();  // the previous tile is done with the LDS
+        if (threadIdx.x == 0) {
+            s_ticket = next;
+            s_abort = 0;
+            if (next < total) next = __hip_atomic_fetch_add(pa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned t = s_ticket;
+        if (t >= total) break;
+        const int step = t / per_step, r = t - step * per_step, strip = r / row, r2 = r - strip * row, z = r2 / tiles_x, tbx = r2 - z * tiles_x;
+        if (step > 0) {
+            if (wave == 0) {  // lane l watches strip l of the step before
+                const unsigned *c = pa.cnt + ((size_t)z * pa.nsteps + (step - 1)) * nstrips;
+                const bool need = lane <= min(strip + 1, nstrips - 1);
+                unsigned polls = 0;
+                for (;;) {
+                    const unsigned v = need ? __hip_atomic_load(c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)tiles_x;
+                    if (__builtin_amdgcn_ballot_w64(v != (unsigned)tiles_x) == 0) break;
+                    if (++polls > pa.spin_limit || __hip_atomic_load(pa.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (lane == 0) {
+                            __hip_atomic_store(pa.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+        }
+        HaloArgs ha = {step > 0 ? pa.T + (size_t)(step - 1) * tstep : nullptr, pa.T + (size_t)step * tstep, nstrips, so, pair_vsum};
+        const float *Min = (step - 1) & 1 ? M1 : M0;
+        float *Mout = step & 1 ? M1 : M0;
+        if (step == 0) halo_tile<FIRST, RW, NW, false, true, true, true>(lds, R0, R1, nullptr, Mout, fin, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
+        else if (step < pa.nsteps - 1) halo_tile<kHaloIter, RW, NW, false, true, true, true>(lds, R0, R1, Min, Mout, fin, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
+        else halo_tile<kHaloLast, RW, NW, false, false, true, true>(lds, R0, R1, Min, nullptr, fout, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
+        if (step < pa.nsteps - 1) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wavefront's write-through stores (rows of M, strip sums) have completed
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(pa.cnt + ((size_t)z * pa.nsteps + step) * nstrips + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
@@ -2351,11 +2501,11 @@ struct Layout {
 //   serial column scan / Gaussian vertical pass   5 * pitch * h values
 //   carry pre-pass                                (strips of >= 2 rows + up to 8 group totals + 1) * 5 * pitch
 //   folded carries                                3 * (strips of >= 12 rows + 1) * 5 * pitch
-//   overlapped strips                             4 * (strips of >= 17 rows + 1) * 5 * pitch
+//   overlapped strips                             4 * (strips of >= 9 rows + 1) * 5 * pitch
 size_t vsum_doubles(int w, int h) {
     const size_t pitch = (size_t)plane_pitch(w);
     const size_t a = 5 * pitch * h, b = (size_t)(ofxcv_div_up(h, 2) + 10) * 5 * pitch, c = 3 * (size_t)(ofxcv_div_up(h, 12) + 1) * 5 * pitch;
-    const size_t d = 4 * (size_t)(ofxcv_div_up(h, 17) + 1) * 5 * pitch;  // overlapped strips: T and T', two buffers
+    const size_t d = 4 * (size_t)(ofxcv_div_up(h, 9) + 1) * 5 * pitch;  // overlapped strips: T and T', two buffers
     return round_up(std::max(std::max(a, d), std::max(b, c)), 32);
 }
 
@@ -2779,9 +2929,12 @@ HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     int form = ctx->fb_halo_geom;  // 0 = by size, 1 small, 2 four tall wavefronts, 3 eight
     if (form < 1 || form > 3) form = t * ofxcv_div_up(h, 69) >= ctx->fb_halo_min8 ? 3 : (t * ofxcv_div_up(h, 33) >= ctx->fb_halo_min4 ? 2 : 1);
     if (form == 1) {
-        g.nw = 4;
-        g.rw = 5;
-        g.so = 17;
+        // small levels: by default eight wavefronts of 3 rows (21 stored rows per strip); option farneback.halo_small 5 = four of 5
+        // rows, 2 = eight of 2, 4 = four of 3
+        const int f = ctx->fb_halo_small;
+        g.nw = (f == 5 || f == 4) ? 4 : 8;
+        g.rw = f == 5 ? 5 : (f == 2 ? 2 : 3);
+        g.so = g.nw * g.rw - 3;
     } else {
         g.nw = form == 3 ? 8 : 4;
         g.rw = 9;
@@ -2807,8 +2960,8 @@ HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
 struct HaloScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles further)
     double *T[2];
 };
-size_t halo_scratch_doubles(int w0, int h0) {  // one buffer: T and T' for strips of >= 17 output rows
-    return 2 * (size_t)(ofxcv_div_up(h0, 17) + 1) * 5 * plane_pitch(w0);
+size_t halo_scratch_doubles(int w0, int h0) {  // one buffer: T and T' for strips of >= 9 output rows
+    return 2 * (size_t)(ofxcv_div_up(h0, 9) + 1) * 5 * plane_pitch(w0);
 }
 HaloScratch halo_scratch(int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
     HaloScratch hs;
@@ -2851,7 +3004,10 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     } while (0)
     // small form: every gather of a wavefront in flight at once while the launch has at most two wavefronts per SIMD
     const bool deep = g.rw == 5 && ctx->fb_halo_deep && (long)g.tiles_x * g.nstrips * L.n * 4 <= (long)ctx->fb_halo_deep * 4 * ctx->num_cus;
-    if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);
+    if (g.rw == 3 && g.nw == 8) OFXCV_LAUNCH_HALO(3, 8, false, true);
+    else if (g.rw == 2) OFXCV_LAUNCH_HALO(2, 8, false, true);
+    else if (g.rw == 3) OFXCV_LAUNCH_HALO(3, 4, false, true);
+    else if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);
     else if (g.rw == 5) OFXCV_LAUNCH_HALO(5, 4, false, false);
     else if (g.nw == 4) OFXCV_LAUNCH_HALO(9, 4, true, false);
     else OFXCV_LAUNCH_HALO(9, 8, true, false);
@@ -2859,6 +3015,45 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 #undef OFXCV_LAUNCH_HALO_K
     OFXCV_LAUNCH_CHECK(ctx, "iterate3h_kernel");
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+    return OFXCV_OK;
+}
+
+// All steps of a small level in one launch (iterate3p_kernel).  Used where the overlapped-strip form would take its small
+// geometry of eight 3- or 2-row wavefronts, at most 64 strips (one lane of the waiting wavefront per strip) and the strip sums
+// of every step fit the pair's f64 scratch.
+bool persist_level(const ofxcv_ctx *ctx, const Layout &L, int w, int h, int gn, int iterations, bool halo) {
+    if (!halo || !ctx->fb_persist || ctx->prof_on || ctx->fb_halo_seed) return false;
+    const HaloGeom g = halo_geom(ctx, w, h, gn);
+    if (g.nw != 8 || (g.rw != 3 && g.rw != 2) || g.nstrips > 64) return false;
+    return (size_t)(iterations + 1) * 2 * g.nstrips * 5 * plane_pitch(w) <= L.vsum;
+}
+size_t persist_words(const ofxcv_ctx *ctx, int w, int h, int gn, int iterations) {  // ticket (+ padding) and the step / strip counters of one launch
+    const HaloGeom g = halo_geom(ctx, w, h, gn);
+    return 16 + round_up((size_t)gn * (iterations + 1) * g.nstrips, 16);
+}
+constexpr size_t kPersistHead = 16;  // unsigned words in front of the first launch's region: [0] = the abort flag (sticky)
+int launch_persistent_level(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, float *M0, float *M1, const FlowTab &fin, const FlowTab &fout,
+                            const Prolong &pr, int w, int h, int first_kind, int iterations, unsigned *words, const Layout &L) {
+    const HaloGeom g = halo_geom(ctx, w, h, L.n);
+    PersistArgs pa = {words, words + 16, (unsigned *)ctx->fb_persist_buf.ptr, L.vsum_ptr, iterations + 1, (unsigned)ctx->fb_persist_spin};
+    const int per_step = g.tiles_x * g.nstrips * L.n;
+    const int nwg = std::max(1, std::min(2 * per_step, 2 * ctx->num_cus));
+    const int pitch = plane_pitch(w);
+    const double scale = 1. / 9.;
+#define OFXCV_LAUNCH_P(FIRST, RW) \
+    hipLaunchKernelGGL((iterate3p_kernel<FIRST, RW, 8>), dim3(nwg), dim3(512), 0, s, R0, R1, M0, M1, fin, fout, pr, w, h, pitch, scale, g.nstrips, g.so, \
+                       g.tiles_x, L.n, L.planes, L.vsum, pa)
+    if (g.rw == 3) {
+        if (first_kind == kHaloZero) OFXCV_LAUNCH_P(kHaloZero, 3);
+        else if (first_kind == kHaloCoarse) OFXCV_LAUNCH_P(kHaloCoarse, 3);
+        else OFXCV_LAUNCH_P(kHaloGiven, 3);
+    } else {
+        if (first_kind == kHaloZero) OFXCV_LAUNCH_P(kHaloZero, 2);
+        else if (first_kind == kHaloCoarse) OFXCV_LAUNCH_P(kHaloCoarse, 2);
+        else OFXCV_LAUNCH_P(kHaloGiven, 2);
+    }
+#undef OFXCV_LAUNCH_P
+    OFXCV_LAUNCH_CHECK(ctx, "iterate3p_kernel");
     return OFXCV_OK;
 }
 
@@ -2972,6 +3167,11 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     float *I = T1 + L.t1;
     float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + L.cflow};
 
+    // tickets and counters of the persistent small-level launches (regions handed out in launch order; the abort flag in
+    // front of them is sticky)
+    size_t pwords = kPersistHead;
+    if (ctx->fb_persist_buf.bytes > kPersistHead * sizeof(unsigned))
+        OFXCV_HIP_CHECK(ctx, hipMemsetAsync((unsigned *)ctx->fb_persist_buf.ptr + kPersistHead, 0, ctx->fb_persist_buf.bytes - kPersistHead * sizeof(unsigned), s));
     // fork: the preparation stream starts once the inputs are ready on the main stream
     OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
     OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
@@ -3037,7 +3237,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->ev_level[k], 0));  // join (level 0's wait closes the fork)
         const int pitch = plane_pitch(w);
         const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)pitch * h;
-        const int per_group = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
+        const int fit = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
+        const int per_group = ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
         const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
@@ -3064,6 +3265,32 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             HaloScratch hs = {};
             if (halo) hs = halo_scratch(width, height, G);
             const Prolong no_pr = {0, 0, 1.0, 1.0, 1.0};
+            const bool persist = persist_level(ctx, L, w, h, gn, iterations, halo) && !profile;
+            if (persist && (pwords + persist_words(ctx, w, h, gn, iterations)) * sizeof(unsigned) <= ctx->fb_persist_buf.bytes) {
+                unsigned *words = (unsigned *)ctx->fb_persist_buf.ptr + pwords;
+                pwords += persist_words(ctx, w, h, gn, iterations);
+                if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
+                    FlowTab init = sub_tab(out, z0, gn);
+                    if (k > 0) {
+                        double scale = 1;
+                        for (int i = 0; i < k; i++) scale *= pyr_scale;
+                        init = sub_tab(coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8), z0, gn);
+                        for (int z = 0; z < gn; z++) {
+                            hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z0 + z], out.step[z0 + z], width, height,
+                                               init.p[z], w, h, scale);
+                            OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
+                        }
+                    }
+                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, init, out_tab, no_pr, w, h, kHaloGiven, iterations, words, G);
+                } else if (!have_prev) {
+                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, no_flow, out_tab, no_pr, w, h, kHaloZero, iterations, words, G);
+                } else {
+                    const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
+                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, sub_tab(prev_all, z0, gn), out_tab, pr, w, h, kHaloCoarse, iterations, words, G);
+                }
+                if (rc) return rc;
+                continue;
+            }
             if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
                 // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
                 FlowTab init = sub_tab(out, z0, gn);
@@ -3185,6 +3412,30 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
         rc = ofxcv_reserve(ctx, ctx->fb_vsum, L.vsum_bytes());
         if (rc) return rc;
     }
+    if (ctx->fb_persist && ctx->fb_opencv_rounding == 1 && winsize == 3 && ctx->fb_fold_carries >= 4 && !(flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
+        // tickets and counters of the persistent small-level launches: the same walk over levels and launch groups as enqueue_farneback
+        size_t words = kPersistHead;
+        const size_t budget = (size_t)std::max(1, ctx->fb_batch_mb) << 20;
+        for (int k = levels; k >= 0; k--) {
+            int w, h, ksz;
+            double sigma;
+            level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
+            const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)plane_pitch(w) * h;
+            const int fit = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
+            const int per_group = ofxcv_div_up(n, ofxcv_div_up(n, fit));
+            for (int z0 = 0; z0 < n; z0 += per_group) {
+                const int gn = std::min(per_group, n - z0);
+                const bool halo = ctx->fb_fold_carries != 5 || fold_level_is_large(ctx, w, h, gn);
+                if (persist_level(ctx, L, w, h, gn, iterations, halo)) words += persist_words(ctx, w, h, gn, iterations);
+            }
+        }
+        if (words > kPersistHead) {
+            const bool fresh = ctx->fb_persist_buf.bytes < words * sizeof(unsigned);
+            rc = ofxcv_reserve(ctx, ctx->fb_persist_buf, words * sizeof(unsigned));
+            if (rc) return rc;
+            if (fresh) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_persist_buf.ptr, 0, kPersistHead * sizeof(unsigned), s));  // the abort flag
+        }
+    }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;
     hipStream_t sp = ctx->fb_one_stream ? s : ctx->prep;
@@ -3211,7 +3462,7 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
     key.n = n;
     key.width = width; key.height = height; key.levels = levels; key.winsize = winsize; key.iterations = iterations; key.poly_n = poly_n; key.flags = flags;
     key.pyr_scale = pyr_scale; key.poly_sigma = poly_sigma;
-    key.planes = ctx->fb_planes.ptr; key.tmp = ctx->fb_tmp.ptr; key.cflow = ctx->fb_flow.ptr; key.vsum = need_vsum ? ctx->fb_vsum.ptr : nullptr;
+    key.planes = ctx->fb_planes.ptr; key.tmp = ctx->fb_tmp.ptr; key.cflow = ctx->fb_flow.ptr; key.vsum = need_vsum ? ctx->fb_vsum.ptr : nullptr; key.persist = ctx->fb_persist_buf.ptr;
     for (int z = 0; z < n; z++) {
         key.prev[z] = d_prev[z]; key.next[z] = d_next[z]; key.flow[z] = d_flow[z];
         key.prev_step[z] = prev_step[z]; key.next_step[z] = next_step[z]; key.flow_step[z] = flow_step[z];

@@ -299,6 +299,39 @@ def test_opencv_order_mode_overlapped_strips_first_matrix_forms(oracle, ofxcv, w
         assert all(np.array_equal(outs[0], o) for o in outs[1:]), kw
 
 
+@pytest.mark.parametrize("w,h,n", [(333, 257, 1), (640, 480, 2), (1920, 1080, 1), (125, 70, 3)])
+def test_opencv_order_mode_persistent_small_levels(oracle, ofxcv, w, h, n):
+    """farneback.persist 1 (default): every small pyramid level is ONE launch -- workgroups draw (step, strip, pair, tile) tickets
+    and wait on per-strip completion counters of the step before -- against one launch per iteration (persist 0): the same flow
+    bit for bit, for 1 / 2 / 15 iterations, with an initial flow, with two- and three-row wavefronts, with a single resident
+    workgroup's worth of tickets in flight (graph replay twice); no wait ever runs out of polls."""
+    prs = _pairs(oracle, w, h, range(7, 7 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    rng = np.random.default_rng(9)
+    inits = [rng.normal(0, 2, size=(h, w, 2)).astype(np.float32) for _ in prs]
+    for kw in (dict(), dict(iterations=1), dict(iterations=2, levels=2), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
+        outs = []
+        for opts in (dict(persist=0), dict(persist=1), dict(persist=1, halo_small=2), dict(persist=1, halo_geom=1)):
+            ctx = ofxcv.Context(0)
+            for k, v in opts.items():
+                ctx.set_option("farneback." + k, v)
+            for _ in range(2):
+                fl = [_dev(i0.copy()) for i0 in inits] if "flags" in kw else None
+                got = [f.cpu().numpy() for f in ctx.calc_optical_flow_farneback_batch(da, db, fl, **kw)]
+            assert ctx.get_option("farneback.persist_aborts") == 0
+            outs.append(got)
+            ctx.close()
+        for o in outs[1:]:
+            for z in range(n):
+                assert np.array_equal(outs[0][z], o[z]), (kw, z)
+    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL, iterations=1)
+    # the last case of outs[0] has an initial flow; check the plain one-iteration result against the oracle instead
+    ctx = ofxcv.Context(0)
+    got = ctx.calc_optical_flow_farneback(da[0], db[0], iterations=1).cpu().numpy()
+    ctx.close()
+    assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
+
+
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
     rng = np.random.default_rng(13)
     h, w = 119, 161
