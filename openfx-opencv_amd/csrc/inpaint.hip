@@ -696,6 +696,16 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     }
     float *d_t = (float *)ctx->ip_tmap.ptr;
     int *d_ord = (int *)ctx->ip_omap.ptr;
+    // The device maps are only reset (sparsely, at the indices this call touches) on the normal ways out.  Any other return
+    // below -- a failed reserve, a HIP error, a schedule that outgrows its scratch -- leaves them dirty: forget their size
+    // then, so that the next call on this context starts from map_init_kernel instead of stale distances and order numbers.
+    struct MapsGuard {
+        ofxcv_ctx *c;
+        bool clean = false;
+        ~MapsGuard() {
+            if (!clean) c->ip_map_w = c->ip_map_h = 0;
+        }
+    } maps_guard{ctx};
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the mask is on the host
 
     if (!ctx->ip_host_state) {
@@ -774,6 +784,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         if ((rc = write_maps())) return rc;
         if ((rc = reset_maps())) return rc;
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        maps_guard.clean = true;
         return OFXCV_OK;
     }
 
@@ -902,6 +913,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     if ((rc = write_maps())) return rc;
     if ((rc = reset_maps())) return rc;
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));  // the host arrays of the march must outlive the copies
+    maps_guard.clean = true;
     if (trace)
         fprintf(stderr, "ofxcv inpaint: %d hole pixels, %d filled: set-up + ring %.2f ms, inward march %.2f ms, schedules %.2f ms, %d fill launches, total %.2f ms\n",
                 n_holes, n, t_setup - t_begin, t_march, t_sched, launches, now() - t_begin);
