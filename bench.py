@@ -139,6 +139,8 @@ def main():
                     "pairs per step per GPU = batch x streams")
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-f7", action="store_true", help="A/B: flow -> RGBA as its own launch per pair (ofxcv_flow_to_rgba) instead of "
+                                                               "inside the Farneback call (ofxcv_calc_optical_flow_farneback_batch_rgba)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
     ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
                     "3840x2160 is configs[4] (64 pairs over 8 GPUs)")
@@ -211,9 +213,15 @@ def main():
                 for a, b, ga, gb in zip(t["a"], t["b"], t["ga"], t["gb"]):
                     c.to_byte_grayscale(a, ga)
                     c.to_byte_grayscale(b, gb)
-                c.calc_optical_flow_farneback_batch(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
-                for fl, o in zip(t["flow"], t["out"]):
-                    c.flow_to_rgba(fl, o, 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
+                if args.separate_f7:
+                    c.calc_optical_flow_farneback_batch(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
+                    for fl, o in zip(t["flow"], t["out"]):
+                        c.flow_to_rgba(fl, o, 0b0001, 0b0010)  # forward.u -> R, forward.v -> G (defaults :739,753)
+                else:
+                    # the same work through the entry point that carries F7: the flow field AND the RGBA image are written
+                    nb = len(t["ga"])
+                    c.calc_optical_flow_farneback_batch_rgba(t["ga"], t["gb"], t["flow"], t["out"], [0b0001] * nb, [0b0010] * nb, 1.0, 1.0,
+                                                             PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
 
     def timed_regions(cs, bufs, steps, warmup, repeats):
         """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; elapsed = max over ranks"""

@@ -129,6 +129,22 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
                                             int levels, int winsize, int iterations, int poly_n,
                                             double poly_sigma, int flags, void *stream);
 
+/* The batched call with F7 (below) fused in: pair i additionally writes flow[i] / render scale into the mapped channels of the
+ * RGBA f32 image d_rgba[i] (NULL entry or NULL table: no image for that pair), exactly as ofxcv_flow_to_rgba would from
+ * d_flow[i] afterwards -- in the default mode the last level-0 launch of the flow stores the pixels from its registers (no
+ * second pass over the flow field, no extra launch); in the other window modes the library appends the F7 launches itself.
+ * Replaces VectorGenerator/VectorGenerator.cpp:403 + :494-519 in one call.  Pairs that share a destination image must map
+ * disjoint channels (forward flow -> R,G and backward flow -> B,A of one output frame, VectorGenerator.cpp:597-638). */
+int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const uint8_t *const *d_prev,
+                                                 const size_t *prev_step, const uint8_t *const *d_next,
+                                                 const size_t *next_step, float *const *d_flow,
+                                                 const size_t *flow_step, int width, int height, double pyr_scale,
+                                                 int levels, int winsize, int iterations, int poly_n,
+                                                 double poly_sigma, int flags, float *const *d_rgba,
+                                                 const ptrdiff_t *rgba_row_bytes, const unsigned *chan_u_mask,
+                                                 const unsigned *chan_v_mask, double render_scale_x,
+                                                 double render_scale_y, void *stream);
+
 /* ---- F7: flow -> RGBA write-back ----------------------------------------------------------
  * replaces the loop at VectorGenerator/VectorGenerator.cpp:494-519.  chan_u_mask/chan_v_mask:
  * bit c set = RGBA channel c receives flow.x / flow.y (divided by the render scale); channels

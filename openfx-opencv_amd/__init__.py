@@ -58,7 +58,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -197,6 +197,28 @@ class Context:
                    vp(*[f.data_ptr() for f in flows]), sz(*[f.stride(0) * 4 for f in flows]),
                    C.c_int(w), C.c_int(h), C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n),
                    C.c_double(poly_sigma), C.c_int(flags))
+        return flows
+
+    def calc_optical_flow_farneback_batch_rgba(self, prevs, nxts, flows, dsts, chan_u_masks, chan_v_masks, rs_x=1.0, rs_y=1.0, pyr_scale=0.5, levels=3,
+                                               winsize=3, iterations=15, poly_n=5, poly_sigma=1.1, flags=0):
+        """the batched call with F7 fused in (ofxcv_calc_optical_flow_farneback_batch_rgba): pair i also writes flow / render scale
+        into the mapped channels of the HxWx4 float32 image dsts[i] (None: no image for that pair)"""
+        import torch
+        n = len(prevs)
+        h, w = prevs[0].shape
+        if flows is None:
+            flows = [torch.empty((h, w, 2), dtype=torch.float32, device=prevs[0].device) for _ in range(n)]
+        for d in dsts:
+            assert d is None or (d.is_cuda and d.dtype == torch.float32 and d.shape[0] == h and d.shape[1] == w and d.shape[2] == 4 and d.stride(2) == 1 and d.stride(1) == 4)
+        vp, sz, pd, un = (C.c_void_p * n), (C.c_size_t * n), (C.c_ssize_t * n), (C.c_uint * n)
+        self._call(lib().ofxcv_calc_optical_flow_farneback_batch_rgba, C.c_int(n),
+                   vp(*[p.data_ptr() for p in prevs]), sz(*[p.stride(0) for p in prevs]),
+                   vp(*[q.data_ptr() for q in nxts]), sz(*[q.stride(0) for q in nxts]),
+                   vp(*[f.data_ptr() for f in flows]), sz(*[f.stride(0) * 4 for f in flows]),
+                   C.c_int(w), C.c_int(h), C.c_double(pyr_scale), C.c_int(levels), C.c_int(winsize), C.c_int(iterations), C.c_int(poly_n),
+                   C.c_double(poly_sigma), C.c_int(flags),
+                   vp(*[(d.data_ptr() if d is not None else None) for d in dsts]), pd(*[(d.stride(0) * 4 if d is not None else 0) for d in dsts]),
+                   un(*chan_u_masks), un(*chan_v_masks), C.c_double(rs_x), C.c_double(rs_y))
         return flows
 
     # ---- F7 ----

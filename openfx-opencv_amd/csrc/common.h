@@ -30,6 +30,10 @@ struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
     const void *planes, *tmp, *cflow, *vsum, *persist;  // scratch addresses baked into the graph
     const void *prev[OFXCV_FB_MAX_BATCH], *next[OFXCV_FB_MAX_BATCH], *flow[OFXCV_FB_MAX_BATCH];
     size_t prev_step[OFXCV_FB_MAX_BATCH], next_step[OFXCV_FB_MAX_BATCH], flow_step[OFXCV_FB_MAX_BATCH];
+    const void *rgba[OFXCV_FB_MAX_BATCH];  // F7 fused into the call (ofxcv_calc_optical_flow_farneback_batch_rgba)
+    ptrdiff_t rgba_step[OFXCV_FB_MAX_BATCH];
+    unsigned rgba_mu[OFXCV_FB_MAX_BATCH], rgba_mv[OFXCV_FB_MAX_BATCH];
+    double rsx, rsy;
 };
 struct FbGraph {
     FbGraphKey key;
@@ -88,6 +92,7 @@ struct ofxcv_ctx {
     int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
     int fb_persist_spin = 1 << 22;  // option "farneback.persist_spin": polls of one wait before the launch gives up (abort flag)
     DevBuf fb_persist_buf;       // [0] abort flag; tickets and step / strip counters of the persistent launches of a call
+    int fb_halo_mshare = 1;      // option "farneback.halo_mshare": eight-wavefront tall form: rows of M shared between the wavefronts of a strip through LDS (1) or every wavefront loads its three neighbour rows itself (0)
     int fb_halo_seed = 0;        // option "farneback.halo_seed" 1: the first M of a level from update_matrices_kernel + halo_seed_kernel instead of the iteration kernel's first forms
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
@@ -185,6 +190,9 @@ int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation 
 
 // measurement hook helpers (context.hip)
 int ofxcv_prof_mark(ofxcv_ctx *ctx, hipStream_t s);  // records one event of a start/stop pair
+// F7 as a launch of its own on stream s (lut.hip); capture-safe
+int ofxcv_launch_flow_to_rgba(ofxcv_ctx *ctx, hipStream_t s, const float *d_flow, size_t flow_step, int width, int height, float *d_dst,
+                              ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask, double render_scale_x, double render_scale_y);
 int ofxcv_prof_drain(ofxcv_ctx *ctx);
 
 // host-side cvRound (round half to even) / cvFloor, shared by geometry helpers

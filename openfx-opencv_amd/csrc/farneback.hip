@@ -40,6 +40,12 @@ struct ImgTab {   // 8-bit source images: entry 2 * pair + {0 = prev, 1 = next}
     const uint8_t *p[2 * kMaxBatch];
     size_t step[2 * kMaxBatch];
 };
+struct RgbaTab {  // F7 fused into the last iteration of level 0: per pair an RGBA f32 image that receives flow / render scale in the mapped channels
+    float *p[kMaxBatch];        // null: no image for this pair
+    ptrdiff_t step[kMaxBatch];  // row bytes
+    unsigned mu[kMaxBatch], mv[kMaxBatch];  // bit c: channel c <- flow.x / flow.y (y wins where both are set, as in the reference loop)
+    double rsx, rsy;            // render scale
+};
 struct FlowTab {  // 2-channel flow fields, one per pair (the caller's at level 0, scratch on the coarser levels)
     float *p[kMaxBatch];
     size_t step[kMaxBatch];
@@ -2101,13 +2107,15 @@ __device__ __forceinline__ float buf_ld_dev(const Buf &b, unsigned voff_bytes, u
 // One workgroup's tile (tile column tbx, strip tby, pair tbz).  COH: the tile runs inside the persistent kernel below, where
 // Min / Tin were written by other workgroups of the SAME launch: device-scope loads for them, write-through stores for
 // Mout / Tout (R0 / R1 and the flows are not touched by the launch and stay ordinary accesses).
-template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH>
+template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH, bool MSHARE = false>
 __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const float *__restrict__ R0, const float *__restrict__ R1,
                                           const float *__restrict__ Min, float *__restrict__ Mout, const FlowTab &flows, const Prolong &pr,
-                                          int w, int h, int pitch, double scale, HaloArgs ha, size_t pair_stride, int tbx, int tby, int tbz) {
+                                          int w, int h, int pitch, double scale, HaloArgs ha, size_t pair_stride, int tbx, int tby, int tbz,
+                                          const RgbaTab *rg = nullptr) {
     constexpr bool UPDATE = KIND != kHaloLast, SOLVE = KIND <= kHaloIter;
     // the last two differences of a strip must be differences inside the last wavefront (T' is its sum without them)
     static_assert(LROWS ? (!VAR && RW >= 2) : (VAR ? RW >= 6 : RW >= 5), "at least five rows per wavefront unless the rows go through LDS");
+    static_assert(!MSHARE || (!LROWS && !COH), "the M-row exchange uses the s_first rows of the tall forms");
     auto &s_w = lds.s_w;
     auto &s_kin = lds.s_kin;
     auto &s_ip = lds.s_ip;
@@ -2164,8 +2172,12 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             }
             s_kin[c][lane] = k;
         }
-        // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
+        // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start.
+        // MSHARE: a wavefront loads its OWN rows only (r = 2 .. nr+1; the first one also the two above the strip, the last one the
+        // row below it) and takes the two rows above / the row below from its neighbours through LDS: 75 instead of 96 rows of M
+        // per 72-row strip, for one more barrier.
         float m[RW + 3][5];
+        const bool full = !VAR || nr == RW;
 #pragma unroll
         for (int r = 0; r < RW + 3; r++) {
             if (VAR && r == RW + 2 && nr < RW) {  // a short wavefront has no use for the last row
@@ -2173,9 +2185,34 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
                 for (int c = 0; c < 5; c++) m[r][c] = 0.f;
                 continue;
             }
+            if (MSHARE) {
+                const bool mine = (r >= 2 && r < nr + 2) || (wave == 0 && r < 2) || (wave == NW - 1 && r == nr + 2);
+                if (!mine) continue;  // wave-uniform; filled from LDS below
+            }
             const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
             for (int c = 0; c < 5; c++) m[r][c] = COH ? buf_ld_dev(bM, vx, so + c * pb) : buf_ld(bM, vx, so + c * pb);
+        }
+        if (MSHARE) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                s_first[wave][0][c][lane] = m[2][c];                            // first own row
+                s_first[wave][1][c][lane] = full ? m[RW][c] : m[RW - 1][c];     // last two own rows (r = nr, nr + 1)
+                s_first[wave][2][c][lane] = full ? m[RW + 1][c] : m[RW][c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                if (wave > 0) {
+                    m[0][c] = s_first[wave - 1][1][c][lane];
+                    m[1][c] = s_first[wave - 1][2][c][lane];
+                }
+                if (wave < NW - 1) {
+                    const float below = s_first[wave + 1][0][c][lane];
+                    if (full) m[RW + 2][c] = below;
+                    else m[RW + 1][c] = below;
+                }
+            }
         }
         // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
         float d[RW][5];
@@ -2215,6 +2252,24 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             fxs[j] = (float)((g11_ * h2_ - g12_ * h1_) * idet);
             fys[j] = (float)((g22_ * h1_ - g12_ * h2_) * idet);
             if (!UPDATE && flow && own) *(float2 *)((char *)flow + (size_t)(a + j) * flow_step + (size_t)xr * 8) = make_float2(fxs[j], fys[j]);
+            if (!UPDATE && rg && rg->p[tbz] && own) {  // F7 (VectorGenerator.cpp:494-519) on the flow still in registers
+                const float u = (float)(fxs[j] / rg->rsx), v = (float)(fys[j] / rg->rsy);
+                const unsigned mu = rg->mu[tbz], mv = rg->mv[tbz];
+                float *d = (float *)((char *)rg->p[tbz] + (ptrdiff_t)(a + j) * rg->step[tbz]) + (size_t)xr * 4;
+                if (((mu | mv) & 15u) == 15u && (((uintptr_t)d) & 15) == 0) {
+                    *(float4 *)d = make_float4((mv & 1u) ? v : u, (mv & 2u) ? v : u, (mv & 4u) ? v : u, (mv & 8u) ? v : u);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c += 2) {  // channel pairs: one 8-byte store where both are mapped
+                        const unsigned m2 = ((mu | mv) >> c) & 3u;
+                        if (m2 == 3u && (((uintptr_t)d) & 7) == 0) *(float2 *)(d + c) = make_float2((mv >> c) & 1u ? v : u, (mv >> (c + 1)) & 1u ? v : u);
+                        else {
+                            if (m2 & 1u) d[c] = (mv >> c) & 1u ? v : u;
+                            if (m2 & 2u) d[c + 1] = (mv >> (c + 1)) & 1u ? v : u;
+                        }
+                    }
+                }
+            }
         }
         if (!UPDATE) return;
     } else {
@@ -2354,15 +2409,16 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
 }
 
 
-template <int KIND, int RW, int NW, bool VAR, bool DEEP = false, bool LROWS = (RW < 5)>
+template <int KIND, int RW, int NW, bool VAR, bool DEEP = false, bool LROWS = (RW < 5), bool MSHARE = false>
 __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                                const float *__restrict__ Min, float *__restrict__ Mout,
                                                                FlowTab flows, Prolong pr, int w, int h, int pitch, double scale,
-                                                               HaloArgs ha, size_t pair_stride) {
+                                                               HaloArgs ha, size_t pair_stride, RgbaTab rg) {
     __shared__ HaloLds<RW, NW, LROWS> lds;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
-    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz);
+    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false, MSHARE>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz,
+                                                             KIND == kHaloLast ? &rg : nullptr);
 }
 
 // ------------------------------------------------------------------ OpenCV-order window: ALL iterations of a small level in ONE launch
@@ -2979,7 +3035,9 @@ int launch_halo_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h
 // kind: kHaloLast / kHaloIter = one iteration (Min -> flows / Mout); kHaloZero / kHaloCoarse / kHaloGiven = the first M of a
 // level together with its strip sums (Min unused; `flows` = the coarser level's / the caller's flow)
 int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
-                          const Prolong &pr, int w, int h, int kind, const HaloScratch &hs, int slot, const Layout &L) {
+                          const Prolong &pr, int w, int h, int kind, const HaloScratch &hs, int slot, const Layout &L, const RgbaTab *rgba = nullptr) {
+    RgbaTab rg = {};
+    if (rgba && kind == kHaloLast) rg = *rgba;
     const HaloGeom g = halo_geom(ctx, w, h, L.n);
     HaloArgs ha = {hs.T[slot], hs.T[slot ^ 1], g.nstrips, g.so, L.vsum};
     if (kind >= kHaloZero) {  // writes the strip sums of the M it produces into T[slot]
@@ -2993,7 +3051,7 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     const int mark = ctx->prof_now ? ctx->prof_on : 0;
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
 #define OFXCV_LAUNCH_HALO_K(KIND, RW, NW, VAR, DEEP) \
-    hipLaunchKernelGGL((iterate3h_kernel<KIND, RW, NW, VAR, DEEP>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes)
+    hipLaunchKernelGGL((iterate3h_kernel<KIND, RW, NW, VAR, DEEP>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes, rg)
 #define OFXCV_LAUNCH_HALO(RW, NW, VAR, DEEP)                                      \
     do {                                                                          \
         if (kind == kHaloIter) OFXCV_LAUNCH_HALO_K(kHaloIter, RW, NW, VAR, DEEP);  \
@@ -3010,6 +3068,10 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     else if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);
     else if (g.rw == 5) OFXCV_LAUNCH_HALO(5, 4, false, false);
     else if (g.nw == 4) OFXCV_LAUNCH_HALO(9, 4, true, false);
+    else if (ctx->fb_halo_mshare && kind == kHaloIter)
+        hipLaunchKernelGGL((iterate3h_kernel<kHaloIter, 9, 8, true, false, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes, rg);
+    else if (ctx->fb_halo_mshare && kind == kHaloLast)
+        hipLaunchKernelGGL((iterate3h_kernel<kHaloLast, 9, 8, true, false, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes, rg);
     else OFXCV_LAUNCH_HALO(9, 8, true, false);
 #undef OFXCV_LAUNCH_HALO
 #undef OFXCV_LAUNCH_HALO_K
@@ -3156,7 +3218,7 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
 // every launch of the walk carries all n pairs in its grid's z dimension.
 static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, const Layout &L, const ImgTab &imgs, const FlowTab &out,
                              int width, int height, double pyr_scale, int levels, int winsize,
-                             int iterations, int poly_n, double poly_sigma, int flags, bool profile) {
+                             int iterations, int poly_n, double poly_sigma, int flags, bool profile, const RgbaTab *rgba = nullptr) {
     int rc;
     const int n = L.n;
     // scratch carving (sizes were reserved by the caller); pointers are pair 0's
@@ -3220,6 +3282,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     bool have_prev = false;
     int pw = 0, ph = 0;
     bool counters_clear = false;
+    bool rgba_fused[kMaxBatch] = {};  // F7 of the pair was done by the last level-0 launch (overlapped-strip form); otherwise it follows as its own launch
     hipStream_t s_main = s;
     const bool use_coarse = ctx->coarse && levels > 0 && sp != s && !profile;
     for (int k = levels; k >= 0; k--) {
@@ -3346,9 +3409,23 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                     const FlowTab &ft = update ? no_flow : out_tab;
                     if (gaussian)
                         rc = launch_gauss_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
-                    else if (halo)
-                        rc = launch_halo_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, no_pr, w, h, update ? kHaloIter : kHaloLast, hs, cur, G);
-                    else if (fold)
+                    else if (halo) {
+                        // F7 rides on the level-0 launch that produces the final flow
+                        RgbaTab rg = {};
+                        const bool sink = rgba && k == 0 && !update;
+                        if (sink) {
+                            rg.rsx = rgba->rsx;
+                            rg.rsy = rgba->rsy;
+                            for (int z = 0; z < gn; z++) {
+                                rg.p[z] = rgba->p[z0 + z];
+                                rg.step[z] = rgba->step[z0 + z];
+                                rg.mu[z] = rgba->mu[z0 + z];
+                                rg.mv[z] = rgba->mv[z0 + z];
+                                rgba_fused[z0 + z] = true;
+                            }
+                        }
+                        rc = launch_halo_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, no_pr, w, h, update ? kHaloIter : kHaloLast, hs, cur, G, sink ? &rg : nullptr);
+                    } else if (fold)
                         rc = launch_fold_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, update, fs, cur, G);
                     else
                         rc = launch_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
@@ -3365,6 +3442,13 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         pw = w;
         ph = h;
     }
+    if (rgba) {
+        for (int z = 0; z < n; z++) {
+            if (!rgba->p[z] || rgba_fused[z]) continue;
+            rc = ofxcv_launch_flow_to_rgba(ctx, s_main, out.p[z], out.step[z], width, height, rgba->p[z], rgba->step[z], rgba->mu[z], rgba->mv[z], rgba->rsx, rgba->rsy);
+            if (rc) return rc;
+        }
+    }
     return OFXCV_OK;
 }
 
@@ -3372,6 +3456,16 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
                                             const uint8_t *const *d_next, const size_t *next_step, float *const *d_flow,
                                             const size_t *flow_step, int width, int height, double pyr_scale, int levels, int winsize,
                                             int iterations, int poly_n, double poly_sigma, int flags, void *stream) {
+    return ofxcv_calc_optical_flow_farneback_batch_rgba(ctx, n, d_prev, prev_step, d_next, next_step, d_flow, flow_step, width, height, pyr_scale, levels,
+                                                        winsize, iterations, poly_n, poly_sigma, flags, nullptr, nullptr, nullptr, nullptr, 1.0, 1.0, stream);
+}
+
+int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const uint8_t *const *d_prev, const size_t *prev_step,
+                                                 const uint8_t *const *d_next, const size_t *next_step, float *const *d_flow,
+                                                 const size_t *flow_step, int width, int height, double pyr_scale, int levels, int winsize,
+                                                 int iterations, int poly_n, double poly_sigma, int flags, float *const *d_rgba,
+                                                 const ptrdiff_t *rgba_row_bytes, const unsigned *chan_u_mask, const unsigned *chan_v_mask,
+                                                 double render_scale_x, double render_scale_y, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (n < 1 || n > kMaxBatch) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: batch of %d pairs outside 1..%d", n, kMaxBatch);
@@ -3390,6 +3484,25 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
         return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "calc_optical_flow_farneback: frames above %d pixels exceed the 32-bit buffer offsets",
                           (int)(((size_t)1 << 31) / 20));
     if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
+    RgbaTab rgba = {};
+    bool have_rgba = false;
+    if (d_rgba) {
+        if (!rgba_row_bytes || !chan_u_mask || !chan_v_mask || render_scale_x == 0 || render_scale_y == 0)
+            return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad RGBA argument");
+        rgba.rsx = render_scale_x;
+        rgba.rsy = render_scale_y;
+        for (int z = 0; z < n; z++) {
+            if (!d_rgba[z]) continue;
+            if ((((uintptr_t)d_rgba[z]) & 3) || (rgba_row_bytes[z] & 3))
+                return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: RGBA image of pair %d is not float-aligned", z);
+            rgba.p[z] = d_rgba[z];
+            rgba.step[z] = rgba_row_bytes[z];
+            rgba.mu[z] = chan_u_mask[z] & 15u;
+            rgba.mv[z] = chan_v_mask[z] & 15u;
+            have_rgba = true;
+        }
+    }
+    const RgbaTab *rgba_p = have_rgba ? &rgba : nullptr;
     hipStream_t s = ofxcv_stream(ctx, stream);
     levels = num_levels(width, height, pyr_scale, levels);
     if (levels > kMaxLevels) levels = kMaxLevels;
@@ -3456,7 +3569,7 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
     const bool use_graph = !ctx->prof_on && !ctx->fb_no_graph;
     if (!use_graph)
         return enqueue_farneback(ctx, s, sp, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags,
-                                 ctx->prof_on != 0);
+                                 ctx->prof_on != 0, rgba_p);
     FbGraphKey key;
     std::memset(&key, 0, sizeof(key));
     key.n = n;
@@ -3466,7 +3579,9 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
     for (int z = 0; z < n; z++) {
         key.prev[z] = d_prev[z]; key.next[z] = d_next[z]; key.flow[z] = d_flow[z];
         key.prev_step[z] = prev_step[z]; key.next_step[z] = next_step[z]; key.flow_step[z] = flow_step[z];
+        key.rgba[z] = rgba.p[z]; key.rgba_step[z] = rgba.step[z]; key.rgba_mu[z] = rgba.mu[z]; key.rgba_mv[z] = rgba.mv[z];
     }
+    key.rsx = rgba.rsx; key.rsy = rgba.rsy;
     FbGraph *g = nullptr;
     for (FbGraph &c : ctx->fb_graphs)
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
@@ -3486,7 +3601,7 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
         }
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
-            rc = enqueue_farneback(ctx, s, sp, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false);
+            rc = enqueue_farneback(ctx, s, sp, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false, rgba_p);
             ok = hipStreamEndCapture(s, &graph) == hipSuccess && rc == OFXCV_OK && graph != nullptr;
             if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
@@ -3500,7 +3615,7 @@ int ofxcv_calc_optical_flow_farneback_batch(ofxcv_ctx *ctx, int n, const uint8_t
             ctx->fb_no_graph = true;
             ctx->fb_one_stream = true;
             ctx->err[0] = 0;
-            return enqueue_farneback(ctx, s, s, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false);
+            return enqueue_farneback(ctx, s, s, L, imgs, out, width, height, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags, false, rgba_p);
         }
         slot->key = key;
         g = slot;

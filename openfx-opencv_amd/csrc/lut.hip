@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void flow_to_rgba_kernel(const float *__restri
 
 }  // namespace
 
+int ofxcv_launch_flow_to_rgba(ofxcv_ctx *ctx, hipStream_t s, const float *d_flow, size_t flow_step, int width, int height, float *d_dst,
+                              ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask, double render_scale_x, double render_scale_y) {
+    dim3 block(256), grid(ofxcv_div_up(width, 256), height);
+    hipLaunchKernelGGL(flow_to_rgba_kernel, grid, block, 0, s, d_flow, flow_step, width, height, d_dst, dst_row_bytes,
+                       chan_u_mask & 15u, chan_v_mask & 15u, render_scale_x, render_scale_y);
+    OFXCV_LAUNCH_CHECK(ctx, "flow_to_rgba_kernel");
+    return OFXCV_OK;
+}
+
 extern "C" {
 
 int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_row_bytes, int ncomp, int width,
@@ -154,12 +163,8 @@ int ofxcv_flow_to_rgba(ofxcv_ctx *ctx, const float *d_flow, size_t flow_step, in
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_flow || !d_dst || width <= 0 || height <= 0 || (flow_step & 7) || render_scale_x == 0 || render_scale_y == 0)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "flow_to_rgba: bad argument");
-    hipStream_t s = ofxcv_stream(ctx, stream);
-    dim3 block(256), grid(ofxcv_div_up(width, 256), height);
-    hipLaunchKernelGGL(flow_to_rgba_kernel, grid, block, 0, s, d_flow, flow_step, width, height, d_dst, dst_row_bytes,
-                       chan_u_mask & 15u, chan_v_mask & 15u, render_scale_x, render_scale_y);
-    OFXCV_LAUNCH_CHECK(ctx, "flow_to_rgba_kernel");
-    return OFXCV_OK;
+    return ofxcv_launch_flow_to_rgba(ctx, ofxcv_stream(ctx, stream), d_flow, flow_step, width, height, d_dst, dst_row_bytes, chan_u_mask, chan_v_mask,
+                                     render_scale_x, render_scale_y);
 }
 
 }  // extern "C"

@@ -270,7 +270,8 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
                  dict(fold_carries=4, halo_geom=1), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3),
                  dict(fold_carries=4, halo_geom=2, halo_strip=33), dict(fold_carries=4, halo_geom=2, halo_strip=35),
                  dict(fold_carries=4, halo_geom=3, halo_strip=65), dict(fold_carries=4, halo_geom=3, halo_strip=70),
-                 dict(fold_carries=5, fold_min=1, halo_geom=2), dict(fold_carries=4, halo_seed=1), dict(fold_carries=4, halo_seed=1, halo_geom=3)):
+                 dict(fold_carries=5, fold_min=1, halo_geom=2), dict(fold_carries=4, halo_seed=1), dict(fold_carries=4, halo_seed=1, halo_geom=3),
+                 dict(halo_geom=3, halo_mshare=0), dict(halo_geom=3, halo_mshare=1), dict(halo_geom=3, halo_mshare=1, halo_strip=67)):
         ctx = ofxcv.Context(0)
         for k, v in opts.items():
             ctx.set_option("farneback." + k, v)
@@ -528,6 +529,40 @@ def test_batch_launch_groups(oracle, ofxcv, mb):
         flows = ctx.calc_optical_flow_farneback_batch([_dev(a) for a, _ in prs], [_dev(b) for _, b in prs])
         for f, s in zip(flows, singles):
             assert np.array_equal(f.cpu().numpy(), s)
+    ctx.close()
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(fold_carries=3), dict(opencv_rounding=0), dict(persist=1)])
+def test_flow_to_rgba_fused_into_the_call(oracle, ofxcv, opts):
+    """ofxcv_calc_optical_flow_farneback_batch_rgba: F7 rides on the last level-0 launch (default mode) or is appended by the
+    library (other window modes) -- the RGBA images equal ofxcv_flow_to_rgba applied to the returned flows bit for bit: all
+    four channels mapped, two, one, none; render scales; a pair without an image; forward + backward flow of one output frame
+    written into ONE image with disjoint channels; unmapped channels keep their content.  Twice (graph replay)."""
+    w, h = 333, 257
+    prs = _pairs(oracle, w, h, (21, 22, 23, 24))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    ctx = ofxcv.Context(0)
+    for k, v in opts.items():
+        ctx.set_option("farneback." + k, v)
+    rng = np.random.default_rng(2)
+    base = [rng.normal(size=(h, w, 4)).astype(np.float32) for _ in range(4)]
+    mus, mvs = [0b0001, 0b0101, 0b0100, 0b0000], [0b0010, 0b1010, 0b0000, 0b0000]
+    for rs in ((1.0, 1.0), (0.5, 0.25)):
+        for _ in range(2):
+            dsts = [_dev(b.copy()) for b in base]
+            dsts[3] = None
+            flows = ctx.calc_optical_flow_farneback_batch_rgba(da, db, None, dsts, mus, mvs, *rs)
+            for z in range(3):
+                ref = ctx.flow_to_rgba(flows[z], _dev(base[z].copy()), mus[z], mvs[z], *rs).cpu().numpy()
+                assert np.array_equal(dsts[z].cpu().numpy(), ref), (opts, rs, z)
+    # one output frame: forward flow -> R,G, backward flow -> B,A of the same image
+    shared = _dev(base[0].copy())
+    flows = ctx.calc_optical_flow_farneback_batch_rgba([da[0], da[0]], [db[0], db[1]], None, [shared, shared], [0b0001, 0b0100], [0b0010, 0b1000])
+    ref = ctx.flow_to_rgba(flows[0], _dev(base[0].copy()), 0b0001, 0b0010)
+    ref = ctx.flow_to_rgba(flows[1], ref, 0b0100, 0b1000).cpu().numpy()
+    assert np.array_equal(shared.cpu().numpy(), ref)
+    plain = ctx.calc_optical_flow_farneback_batch([da[0], da[0]], [db[0], db[1]])
+    assert all(np.array_equal(a.cpu().numpy(), b.cpu().numpy()) for a, b in zip(flows, plain))
     ctx.close()
 
 
