@@ -345,8 +345,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
-                     "kernel": ("iterate3h_kernel<kHaloIter, 9, 8, true> (one blur+solve+update iteration in OpenCV's summation order as ONE launch: overlapped strips of 65..72 computed rows, "
-                                "eight wavefronts of 8 or 9 rows per workgroup, the strip sums of its own output for the next launch's column-sum prefix; pyramid level 0, %dx%d)" if fold_mode >= 4 else
+                     "kernel": ("iterate3h_kernel<kHaloIter, 9, 8, var, mshare> (one blur+solve+update iteration in OpenCV's summation order as ONE launch: overlapped strips of 65..72 computed rows, "
+                                "eight wavefronts of 8 or 9 rows per workgroup that share their boundary rows of M through LDS, the strip sums of its own output for the next launch's column-sum prefix; "
+                                "pyramid level 0, %dx%d)" if fold_mode >= 4 else
                                 "iterate3f_kernel<true, 9, 4, true, true> (one blur+solve+update iteration in OpenCV's summation order, four wavefronts of 8 or 9 rows per workgroup, producing the column-sum carries "
                                 "of its own output; pyramid level 0, %dx%d)" if folded else
                                 "iterate3s_kernel<true, 8, 1> (one blur+solve+update iteration in OpenCV's summation order; pyramid level 0, %dx%d)") % (W, H),
@@ -354,7 +355,8 @@ def main():
                      "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20) x %d x %d px x %d pairs "
                                               "per launch (grid z = pair)" % (W, H, ppl),
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
-                     "timing": "HIP event pairs on the launch stream, one batched call in flight (compare profiles/r03_bench_single_by_grid.txt)",
+                     "timing": "HIP event pairs on the launch stream, one batched call in flight; the pairs include the dependent-launch gap -- the rocprofv3 "
+                               "durations of the same launches are profiles/r03_bench_single_by_grid.txt (alone) and r03_bench_default_kernel_stats.csv (timed workload)",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_note": "per launch of the batched kernel (PMC passes run the bench workload)",

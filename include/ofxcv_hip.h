@@ -68,25 +68,36 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n   A/B: fill-order pixels per portion of the pipelined fill (8192) and
  *                                    per workgroup of a component (256);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
- *   "farneback.fold_carries" 0..3    OpenCV-order mode, where the carries of the f64 column sums come from: 0 a pre-pass over M
- *                                    per iteration; 1 / 2 the iteration kernel produces the carries of its own output (prefix
- *                                    over the strips by the last workgroup of a tile column / by a small launch of its own);
- *                                    3 (default) = 2 on the bandwidth-bound pyramid levels, 0 on the small ones.  Identical
- *                                    results; timings in DESIGN.md section 4;
- *   "farneback.fold_rows" 3|8, "farneback.fold_min" n, "farneback.fold_nw4" 0|1   A/B: rows per wavefront of the folded kernel on
- *                                    the large levels (default 4); number of 62x64-pixel tiles (over the whole batch) from which a
- *                                    level counts as large (default 256); 4-wavefront workgroups on the large levels too;
+ *   "farneback.fold_carries" 0..5    OpenCV-order mode, how the f64 column sums are carried from strip to strip:
+ *                                    4 (default) overlapped strips -- a workgroup computes three rows more than it stores, leaves the sums of
+ *                                    its strip's row differences, and the next launch adds them up in its prologue: ONE launch per iteration
+ *                                    on every pyramid level (iterate3h_kernel), the first M of a level from the same kernel; 5 = 4 on the
+ *                                    bandwidth-bound levels, 0 elsewhere; 0 a carry pre-pass over M per iteration; 1 / 2 the iteration kernel
+ *                                    produces the carries of its own output (prefix over the strips by the last workgroup of a tile column /
+ *                                    by a small launch of its own); 3 (first half of round 3) = 2 on the bandwidth-bound levels, 0 on the
+ *                                    small ones.  Identical results; timings in DESIGN.md section 4 and profiles/r03_exp09_overlapped_strips.txt;
+ *   "farneback.halo_geom" 0..3, "farneback.halo_min8" n, "farneback.halo_min4" n, "farneback.halo_strip" rows, "farneback.halo_small" 2|3|4|5,
+ *   "farneback.halo_deep" n, "farneback.halo_mshare" 0|1, "farneback.halo_seed" 0|1   A/B knobs of the overlapped-strip form: wavefronts per
+ *                                    workgroup and rows per wavefront by level size, computed rows per strip, rows of M shared through LDS,
+ *                                    first M of a level from update_matrices + a seed pass (csrc/common.h has one line per knob);
+ *   "farneback.persist" 0|1          all iterations of a small pyramid level in ONE launch (workgroups draw tickets and wait on per-strip
+ *                                    completion counters; default 0: measured slower than a launch per iteration);
+ *                                    ofxcv_ctx_get_option("farneback.persist_aborts") = 1 if a wait of such a launch ever ran out of polls;
+ *   "farneback.fold_rows" 3|8, "farneback.fold_min" n, "farneback.fold_nw4" 0|1, "farneback.fold_nw" 0|4|8, "farneback.fold_strip" rows,
+ *   "farneback.solves_first" 0|1     A/B knobs of the folded forms 1..3 (rows / wavefronts per workgroup, strip height, level-size threshold);
+ *   "farneback.batch_mb" MiB         a pyramid level is walked with as many pairs per launch as keep its working set under this (160);
  *   "farneback.strict_rows" 0|2|4|8|16, "farneback.strict_variant" (1 unpipelined gather, 2 rows in pairs), "farneback.carry_groups",
  *   "farneback.lds_pad" bytes: A/B knobs of the pre-pass form of the OpenCV-order kernels. */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
-/* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register" */
+/* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register",
+ * "farneback.batch_mb", "farneback.persist", "farneback.persist_aborts" (synchronises the device: a test hook) */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
  * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of one kernel at pyramid level 0
  * with a hipEvent pair on the stream it is launched on.  enable = 1: the dominant kernel (OpenCV-order mode: the
- * blur+solve+update kernel of one iteration, iterate3f_kernel / iterate3s_kernel; direct-window mode: the fused
- * two-iteration kernel, iterate3x2_kernel); enable = 2: the carry kernel of the OpenCV-order mode (fold_scan_kernel /
+ * blur+solve+update kernel of one iteration, iterate3h_kernel (iterate3f_kernel / iterate3s_kernel in the other carry forms); direct-window mode: the fused
+ * two-iteration kernel, iterate3x2_kernel); enable = 2: the carry kernel of the OpenCV-order carry forms 0..3 (fold_scan_kernel /
  * vsum_carry_kernel).  ofxcv_profile_read synchronises, adds up the pairs and returns the total kernel time and the
  * number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);

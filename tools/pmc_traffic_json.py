@@ -24,7 +24,7 @@ def traffic(c):
 out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --batch 1 --streams 1 --steps 2: single-pair calls, so a launch "
                  "is one pair's); per-launch averages per kernel and grid",
        "kernels": {}}
-want = {"iterate3f_kernel<true,": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
+want = {"iterate3h_kernel<1, 9, 8": "opencv_order_halo_iteration_level0", "iterate3f_kernel<true,": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
         "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
 for (name, grid), c in rows.items():
     for k, tag in want.items():
@@ -47,15 +47,15 @@ def total(spec):
     return sum(mult * sum(per_level(prefix)) for prefix, mult in spec)
 
 
-shared = [("update_matrices_kernel", 1), ("polyexp_persistent_kernel", 2), ("pyr_", 2), ("gray_lut_kernel", 2), ("flow_to_rgba_kernel", 1)]
+prep = [("polyexp_persistent_kernel", 1), ("pyr_", 1), ("gray_lut_kernel", 2)]  # one pyramid / polynomial-expansion launch per level carries both frames of the pair
 out["per_pair_traffic_bytes"] = {
-    # every iteration / carry kernel of the mode as it ran (folded-carry kernels on the large levels, pre-pass form on the small ones)
-    "opencv_order": total(shared + [("iterate3s_kernel<true", 14), ("iterate3s_kernel<false", 1), ("vsum_carry_kernel", 15), ("iterate3f_kernel<true", 14),
-                                    ("iterate3f_kernel<false", 1), ("fold_scan_kernel", 15), ("vsum_seed_kernel", 1)]),
-    "direct_window": total(shared + [("iterate3x2_kernel", 7), ("iterate3_kernel<false", 1)]),
-    "note": "sum over kernels of (bytes per launch from the PMC passes) x (launches per 1920x1080 pair: 14 updating iterations + 1 final per level "
-            "and 15 carry pre-passes in the OpenCV-order mode, 7 fused pairs + 1 final in the direct-window mode; 2 pyramid images + 2 polynomial "
-            "expansions + 1 first update per level; 2 gray LUTs, 1 flow -> RGBA)"}
+    # OpenCV-order mode (default): the overlapped-strip kernel does everything on the main stream -- per level one "first" launch (kind 2 on
+    # the coarsest level, 3 below it), 14 iterating launches (kind 1) and the last one (kind 0, which also stores the RGBA pixels)
+    "opencv_order": total(prep + [("iterate3h_kernel<1,", 14), ("iterate3h_kernel<0,", 1), ("iterate3h_kernel<2,", 1), ("iterate3h_kernel<3,", 1)]),
+    "direct_window": total(prep + [("update_matrices_kernel", 1), ("flow_to_rgba_kernel", 1), ("iterate3x2_kernel", 7), ("iterate3_kernel<false", 1)]),
+    "note": "sum over kernels of (bytes per launch from the PMC passes) x (launches per 1920x1080 pair: per level 1 first + 14 iterating + 1 last "
+            "launch of iterate3h_kernel in the OpenCV-order mode, 1 first update + 7 fused pairs + 1 final in the direct-window mode + 1 flow -> RGBA; "
+            "1 pyramid-image launch + 1 polynomial-expansion launch per level (both frames each), 2 gray LUTs)"}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print("per pair: OpenCV order %.0f MB, direct window %.0f MB" % (out["per_pair_traffic_bytes"]["opencv_order"] / 1e6, out["per_pair_traffic_bytes"]["direct_window"] / 1e6))
 for k, v in out["kernels"].items():
