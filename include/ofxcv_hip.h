@@ -77,9 +77,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    by a small launch of its own); 3 (first half of round 3) = 2 on the bandwidth-bound levels, 0 on the
  *                                    small ones.  Identical results; timings in DESIGN.md section 4 and profiles/r03_exp09_overlapped_strips.txt;
  *   "farneback.halo_geom" 0..3, "farneback.halo_min8" n, "farneback.halo_min4" n, "farneback.halo_strip" rows, "farneback.halo_small" 2|3|4|5,
- *   "farneback.halo_deep" n, "farneback.halo_mshare" 0|1, "farneback.halo_seed" 0|1   A/B knobs of the overlapped-strip form: wavefronts per
- *                                    workgroup and rows per wavefront by level size, computed rows per strip, rows of M shared through LDS,
- *                                    first M of a level from update_matrices + a seed pass (csrc/common.h has one line per knob);
+ *   "farneback.halo_deep" n          A/B knobs of the overlapped-strip form: wavefronts per workgroup and rows per wavefront by level size,
+ *                                    computed rows per strip (csrc/common.h has one line per knob);
  *   "farneback.persist" 0|1          all iterations of a small pyramid level in ONE launch (workgroups draw tickets and wait on per-strip
  *                                    completion counters; default 0: measured slower than a launch per iteration);
  *                                    ofxcv_ctx_get_option("farneback.persist_aborts") = 1 if a wait of such a launch ever ran out of polls;

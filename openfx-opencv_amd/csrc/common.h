@@ -92,8 +92,6 @@ struct ofxcv_ctx {
     int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
     int fb_persist_spin = 1 << 22;  // option "farneback.persist_spin": polls of one wait before the launch gives up (abort flag)
     DevBuf fb_persist_buf;       // [0] abort flag; tickets and step / strip counters of the persistent launches of a call
-    int fb_halo_mshare = 1;      // option "farneback.halo_mshare": eight-wavefront tall form: rows of M shared between the wavefronts of a strip through LDS (1) or every wavefront loads its three neighbour rows itself (0)
-    int fb_halo_seed = 0;        // option "farneback.halo_seed" 1: the first M of a level from update_matrices_kernel + halo_seed_kernel instead of the iteration kernel's first forms
     int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one

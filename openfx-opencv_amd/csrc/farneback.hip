@@ -2023,65 +2023,30 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 // launch wrote; nothing but f64 additions is re-associated, as in the other strip-parallel forms.  Price: SO + 3 rows are
 // computed for SO stored (4.3 % at 72-row strips), against one launch and ~18 MB of boundary rows per iteration saved.
 struct HaloArgs {
-    const double *Tin;    // [2][nstrips][5][pitch]  T (first half) and T' (second half) of Min
-    double *Tout;         // the same for Mout
+    const double *Tin;    // [2][nstrips][5][pitch]  T (first half) and T' (second half) of the field the launch reads
+    double *Tout;         // the same for the field it writes
+    const float *Ein;     // [3][5][pitch]  edge rows of M: row 0, row max(h-3, 0), row h-1 (see halo_tile)
+    float *Eout;
     int nstrips;
     int so;               // output rows per strip (the strip computes so + 3)
-    size_t pair_vsum;     // batched calls: doubles between the T arrays of consecutive pairs
+    size_t pair_vsum;     // batched calls: doubles between the T / edge arrays of consecutive pairs
     __device__ __forceinline__ void select_pair(int z) {
         if (Tin) Tin += (size_t)z * pair_vsum;
         Tout += (size_t)z * pair_vsum;
+        if (Ein) Ein += (size_t)z * pair_vsum * 2;
+        Eout += (size_t)z * pair_vsum * 2;
     }
 };
 
-// T / T' of a field that already lies in memory (the first M of a pyramid level).  One workgroup per 64 columns, strip and
-// channel; its kSeedQ wavefronts take consecutive portions of at most kSeedR of the strip's differences (every load of a
-// portion in flight at once), the portion sums meet in LDS in ascending order.
-constexpr int kSeedQ = 8, kSeedR = 9;  // strips of up to 72 rows
-__global__ __launch_bounds__(64 * kSeedQ) void halo_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, HaloArgs ha, size_t pair_stride) {
-    __shared__ double s_t[kSeedQ][64], s_p[64];
-    const int z = blockIdx.z / 5, c = blockIdx.z - 5 * z;  // grid z = channel + 5 * pair
-    const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), s = blockIdx.y;
-    M += (size_t)z * pair_stride;
-    ha.select_pair(z);
-    const float *m = M + (size_t)c * pitch * h + x;
-    const int A = s * ha.so, E = min(A + ha.so, h);           // differences t in [A, E): d_t = M[t+1] - M[t-2], rows clamped to the image
-    const int per = (ha.so + kSeedQ - 1) / kSeedQ;            // <= kSeedR
-    const int t0 = A + q * per, t1 = min(t0 + per, E), tp = A + ha.so - 2;  // T' stops before tp
-    float r[kSeedR + 3];  // rows t0-2 .. t0+per
-#pragma unroll
-    for (int i = 0; i < kSeedR + 3; i++) r[i] = i < per + 3 ? m[(size_t)clampi(t0 - 2 + i, 0, h - 1) * pitch] : 0.f;
-    double acc = 0., accp = 0.;
-#pragma unroll
-    for (int i = 0; i < kSeedR; i++) {
-        if (t0 + i == tp) accp = acc;
-        if (t0 + i < t1) acc += (double)(r[i + 3] - r[i]);
-    }
-    const int qp = (ha.so - 2) / per;  // the portion that holds difference tp (< kSeedQ)
-    s_t[q][lane] = acc;
-    if (q == qp) s_p[lane] = accp;
-    __syncthreads();
-    if (q == 0 && xr < w) {
-        double sum = 0., sump = 0.;
-        for (int u = 0; u < kSeedQ; u++) {
-            if (u == qp) sump = sum + s_p[lane];
-            sum += s_t[u][lane];
-        }
-        if (s == 0) {  // the top strip's sums carry vsum(-1) = srow0 * (m + 2), a float product
-            const double c0 = (double)(m[0] * 3.f);
-            sum = c0 + sum;
-            sump = c0 + sump;
-        }
-        const size_t o = ((size_t)s * 5 + c) * pitch + xr, tq = (size_t)ha.nstrips * 5 * pitch;
-        ha.Tout[o] = sum;
-        ha.Tout[tq + o] = sump;
-    }
-}
-
 // KIND: what the flow of a row comes from, and what leaves the kernel
-//   kHaloLast    solve of box(Min); the flow of the stored rows goes to `flows` (last iteration of a level), no Mout
-//   kHaloIter    solve of box(Min); Mout = UpdateMatrices(R0, R1, flow) + T / T' of Mout
+//   kHaloLast    solve of box(M_in); the flow of the stored rows goes to `flows` (last iteration of a level), no M_out
+//   kHaloIter    solve of box(M_in); M_out = UpdateMatrices(R0, R1, flow) + T / T' of M_out
+// What travels between launches is not M but its ROW DIFFERENCES: row t of the field `Min` / `Mout` holds
+//     d_t = (float)(M[min(t+1, h-1)] - M[max(t-2, 0)])          (the reference's srow1[x] - srow0[x])
+// -- all an iteration ever uses of M besides vsum(-1).  The producer has every d_t of its strip anyway (it sums them for T);
+// the consumer reads ITS OWN rows only (no three neighbour rows per wavefront to re-read or exchange) and starts its chain
+// directly.  d_{h-1} = M[h-1] - M[max(h-3, 0)] has no row below it to be computed from three rows later, and vsum(-1) needs
+// row 0 itself: those three rows of M travel in a small side array (`Ein` / `Eout`).
 //   kHaloZero / kHaloCoarse / kHaloGiven   the FIRST M of a level (+ its T / T'): zero flow (coarsest level), the coarser
 //                level's flow prolongated (F6, `flows` = that flow), the caller's flow (`flows`, USE_INITIAL_FLOW at level 0)
 enum { kHaloLast = 0, kHaloIter = 1, kHaloZero = 2, kHaloCoarse = 3, kHaloGiven = 4 };
@@ -2107,15 +2072,18 @@ __device__ __forceinline__ float buf_ld_dev(const Buf &b, unsigned voff_bytes, u
 // One workgroup's tile (tile column tbx, strip tby, pair tbz).  COH: the tile runs inside the persistent kernel below, where
 // Min / Tin were written by other workgroups of the SAME launch: device-scope loads for them, write-through stores for
 // Mout / Tout (R0 / R1 and the flows are not touched by the launch and stay ordinary accesses).
-template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH, bool MSHARE = false>
+template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH>
 __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const float *__restrict__ R0, const float *__restrict__ R1,
                                           const float *__restrict__ Min, float *__restrict__ Mout, const FlowTab &flows, const Prolong &pr,
                                           int w, int h, int pitch, double scale, HaloArgs ha, size_t pair_stride, int tbx, int tby, int tbz,
                                           const RgbaTab *rg = nullptr) {
     constexpr bool UPDATE = KIND != kHaloLast, SOLVE = KIND <= kHaloIter;
+    // DF: the field between launches holds the row differences (tall forms).  The short-wavefront forms keep M itself: their
+    // differences only exist after the workgroup's last barrier, and stores issued that late lengthen a launch whose duration
+    // IS its critical path (measured +0.9 us on 10-12 us at 480x270 / 240x135); their wavefronts re-read the three neighbour rows.
+    constexpr bool DF = !LROWS;
     // the last two differences of a strip must be differences inside the last wavefront (T' is its sum without them)
     static_assert(LROWS ? (!VAR && RW >= 2) : (VAR ? RW >= 6 : RW >= 5), "at least five rows per wavefront unless the rows go through LDS");
-    static_assert(!MSHARE || (!LROWS && !COH), "the M-row exchange uses the s_first rows of the tall forms");
     auto &s_w = lds.s_w;
     auto &s_kin = lds.s_kin;
     auto &s_ip = lds.s_ip;
@@ -2141,6 +2109,8 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
     const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
     const Buf bM = make_buf(Min, SOLVE ? 5 * plane * sizeof(float) : 0), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
               bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
+    const Buf bEi = make_buf(ha.Ein, SOLVE ? (size_t)15 * pitch * sizeof(float) : 0), bEo = make_buf(ha.Eout, UPDATE ? (size_t)15 * pitch * sizeof(float) : 0);
+    const unsigned eb = (unsigned)pitch * 20u;  // bytes between the edge rows (5 channels each)
     auto valid = [&](int j) { return j < nr && a + j >= 0 && a + j < h; };                  // a row of the image (wave-uniform)
     auto stored = [&](int j) { return valid(j) && a + j >= A && a + j < A + SO; };         // ... that this strip owns
 
@@ -2152,8 +2122,9 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             // vsum(-1) = srow0 * (m + 2), a float product of row 0: the top strip reads it; for the others it is part of the top
             // strip's sums (a tile of the persistent kernel must not read rows outside its own neighbourhood)
             double k = 0.;
-            if (tby == 0) {
-                k = (double)((COH ? buf_ld_dev(bM, vx, c * pb) : buf_ld(bM, vx, c * pb)) * 3.f);
+            if (tby == 0) {  // row 0 of M
+                if (DF) k = (double)((COH ? buf_ld_dev(bEi, vx, c * rb) : buf_ld(bEi, vx, c * rb)) * 3.f);
+                else k = (double)((COH ? buf_ld_dev(bM, vx, c * pb) : buf_ld(bM, vx, c * pb)) * 3.f);
             } else {
                 const size_t kst = (size_t)5 * pitch;
                 const double *T = ha.Tin + (size_t)c * pitch + x;
@@ -2172,54 +2143,38 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             }
             s_kin[c][lane] = k;
         }
-        // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start.
-        // MSHARE: a wavefront loads its OWN rows only (r = 2 .. nr+1; the first one also the two above the strip, the last one the
-        // row below it) and takes the two rows above / the row below from its neighbours through LDS: 75 instead of 96 rows of M
-        // per 72-row strip, for one more barrier.
-        float m[RW + 3][5];
-        const bool full = !VAR || nr == RW;
-#pragma unroll
-        for (int r = 0; r < RW + 3; r++) {
-            if (VAR && r == RW + 2 && nr < RW) {  // a short wavefront has no use for the last row
-#pragma unroll
-                for (int c = 0; c < 5; c++) m[r][c] = 0.f;
-                continue;
-            }
-            if (MSHARE) {
-                const bool mine = (r >= 2 && r < nr + 2) || (wave == 0 && r < 2) || (wave == NW - 1 && r == nr + 2);
-                if (!mine) continue;  // wave-uniform; filled from LDS below
-            }
-            const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
-#pragma unroll
-            for (int c = 0; c < 5; c++) m[r][c] = COH ? buf_ld_dev(bM, vx, so + c * pb) : buf_ld(bM, vx, so + c * pb);
-        }
-        if (MSHARE) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                s_first[wave][0][c][lane] = m[2][c];                            // first own row
-                s_first[wave][1][c][lane] = full ? m[RW][c] : m[RW - 1][c];     // last two own rows (r = nr, nr + 1)
-                s_first[wave][2][c][lane] = full ? m[RW + 1][c] : m[RW][c];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 5; c++) {
-                if (wave > 0) {
-                    m[0][c] = s_first[wave - 1][1][c][lane];
-                    m[1][c] = s_first[wave - 1][2][c][lane];
-                }
-                if (wave < NW - 1) {
-                    const float below = s_first[wave + 1][0][c][lane];
-                    if (full) m[RW + 2][c] = below;
-                    else m[RW + 1][c] = below;
-                }
-            }
-        }
-        // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
+        // this wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]); the wavefront that holds the last
+        // image row takes d_{h-1} from the edge rows
         float d[RW][5];
+        if (!DF) {
+            // rows a-2 .. a+nr of M (index r <-> image row clamp(a - 2 + r)): d_t = row[t+1] - row[t-2]
+            float m[RW + 3][5];
 #pragma unroll
-        for (int j = 0; j < RW; j++)
+            for (int r = 0; r < RW + 3; r++) {
+                const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
-            for (int c = 0; c < 5; c++) d[j][c] = m[j + 3][c] - m[j][c];
+                for (int c = 0; c < 5; c++) m[r][c] = COH ? buf_ld_dev(bM, vx, so + c * pb) : buf_ld(bM, vx, so + c * pb);
+            }
+#pragma unroll
+            for (int j = 0; j < RW; j++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) d[j][c] = m[j + 3][c] - m[j][c];
+        }
+#pragma unroll
+        for (int j = 0; DF && j < RW; j++) {
+            const int y = a + j;
+            if (!valid(j)) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) d[j][c] = 0.f;
+            } else if (y == h - 1) {
+#pragma unroll
+                for (int c = 0; c < 5; c++)  // rows h-1 and max(h-3, 0) of M
+                    d[j][c] = COH ? buf_ld_dev(bEi, vx, 2 * eb + c * rb) - buf_ld_dev(bEi, vx, eb + c * rb) : buf_ld(bEi, vx, 2 * eb + c * rb) - buf_ld(bEi, vx, eb + c * rb);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 5; c++) d[j][c] = COH ? buf_ld_dev(bM, vx, (unsigned)y * rb + c * pb) : buf_ld(bM, vx, (unsigned)y * rb + c * pb);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             double t = 0.;
@@ -2293,18 +2248,32 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
         float fxv, fyv;
     };
     Px prev;
+    auto st_e = [&](float v, unsigned soff) {  // an edge row of M_out (own lanes: `st`)
+        if (COH) buf_st_dev(bEo, v, vx, soff);
+        else buf_st(bEo, v, vx, soff);
+    };
+    auto st_d = [&](float dv, int t, int c) {  // row t of the difference field of M_out
+        if (!DF || !own) return;
+        if (COH) buf_st_dev(bMo, dv, vx, (unsigned)t * rb + c * pb);
+        else buf_st(bMo, dv, vx, (unsigned)t * rb + c * pb);
+    };
     float mo[RW][5];   // rows of Mout as they are produced (only the last three finished ones stay live)
     double I[5] = {0., 0., 0., 0., 0.};   // row differences of Mout with both rows in this wavefront, ascending t
     double Ip[5] = {0., 0., 0., 0., 0.};  // last wavefront: I before the strip's last two differences
     auto finish = [&](const Px &p, int j) {
         const int y = a + j;
         M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
-        const bool st = own && y >= A && y < A + SO;
+        const bool st = own && y >= A && y < A + SO;  // this strip owns the row: its edge rows
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            if (st) {
+            if (!DF && st) {
                 if (COH) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
                 else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+            }
+            if (DF && st && (y == 0 || y == h - 1 || y == max(h - 3, 0))) {
+                if (y == 0) st_e(mm.v[c], c * rb);
+                if (y == max(h - 3, 0)) st_e(mm.v[c], eb + c * rb);
+                if (y == h - 1) st_e(mm.v[c], 2 * eb + c * rb);
             }
             if (LROWS) {
                 s_rows[off + j][c][lane] = mm.v[c];
@@ -2319,7 +2288,9 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             }
             if (j >= 3) {   // t = y-1: rows y, y-3, both in this wavefront
                 if (wave == NW - 1 && j == nr - 2) Ip[c] = I[c];
-                I[c] += (double)(mm.v[c] - mo[j - 3][c]);
+                const float dv = mm.v[c] - mo[j - 3][c];
+                I[c] += (double)dv;
+                st_d(dv, y - 1, c);
             }
         }
     };
@@ -2369,7 +2340,9 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 if (wave == NW - 1 && j == RW - 2) Ip[c] = I[c];
-                I[c] += (double)(s_rows[q][c][lane] - s_rows[qe][c][lane]);
+                const float dv = s_rows[q][c][lane] - s_rows[qe][c][lane];
+                I[c] += (double)dv;
+                st_d(dv, a + j - 1, c);
             }
         }
     }
@@ -2384,9 +2357,14 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             const bool full = !VAR || nr == RW;  // a short wavefront's last three rows are one index earlier
             const float l0 = full ? mo[RW - 3][c] : mo[RW - 4][c], l1 = full ? mo[RW - 2][c] : mo[RW - 3][c],
                         l2 = full ? mo[RW - 1][c] : mo[RW - 2][c];
-            sum += (double)(s_first[wave + 1][0][c][lane] - l0);
-            sum += (double)(s_first[wave + 1][1][c][lane] - l1);
-            sum += (double)(s_first[wave + 1][2][c][lane] - l2);
+            const float dv0 = s_first[wave + 1][0][c][lane] - l0, dv1 = s_first[wave + 1][1][c][lane] - l1, dv2 = s_first[wave + 1][2][c][lane] - l2;
+            sum += (double)dv0;
+            sum += (double)dv1;
+            sum += (double)dv2;
+            const int yb = a + nr;  // first row of the wavefront below: the differences t = yb-1, yb, yb+1 (where its rows exist)
+            if (yb < h) st_d(dv0, yb - 1, c);
+            if (yb + 1 < h) st_d(dv1, yb, c);
+            if (yb + 2 < h) st_d(dv2, yb + 1, c);
         } else {
             s_ip[c][lane] = Ip[c];
         }
@@ -2409,7 +2387,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
 }
 
 
-template <int KIND, int RW, int NW, bool VAR, bool DEEP = false, bool LROWS = (RW < 5), bool MSHARE = false>
+template <int KIND, int RW, int NW, bool VAR, bool DEEP = false, bool LROWS = (RW < 5)>
 __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                                const float *__restrict__ Min, float *__restrict__ Mout,
                                                                FlowTab flows, Prolong pr, int w, int h, int pitch, double scale,
@@ -2417,8 +2395,8 @@ __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_ker
     __shared__ HaloLds<RW, NW, LROWS> lds;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
-    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false, MSHARE>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz,
-                                                             KIND == kHaloLast ? &rg : nullptr);
+    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz,
+                                                     KIND == kHaloLast ? &rg : nullptr);
 }
 
 // ------------------------------------------------------------------ OpenCV-order window: ALL iterations of a small level in ONE launch
@@ -2439,7 +2417,7 @@ struct PersistArgs {
     unsigned *ticket;      // next ticket (0 on entry)
     unsigned *cnt;         // [pairs][nsteps][nstrips] tiles that have finished (0 on entry)
     unsigned *abort_flag;  // sticky: a wait ran out of polls
-    double *T;             // [nsteps][2][nstrips][5][pitch] strip sums of every step's M; pair z lies pair_vsum doubles further
+    double *T;             // [nsteps] x { [2][nstrips][5][pitch] strip sums, [3][5][pitch] edge rows (floats) } of every step's M; pair z lies pair_vsum doubles further
     int nsteps;            // iterations + 1
     unsigned spin_limit;
 };
@@ -2453,7 +2431,7 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3p_kernel(const float *__re
     __shared__ unsigned s_ticket, s_abort;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned row = (unsigned)tiles_x * npairs, per_step = row * nstrips, total = per_step * pa.nsteps;
-    const size_t tstep = (size_t)2 * nstrips * 5 * pitch;
+    const size_t estep = 8 * (size_t)pitch, tstep = (size_t)2 * nstrips * 5 * pitch + estep;  // doubles per step: T, T', edge rows
     // thread 0 draws the NEXT ticket while the current tile is computed (the draw is a round trip to the device's atomics)
     unsigned next = 0;
     if (threadIdx.x == 0) next = __hip_atomic_fetch_add(pa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2489,7 +2467,9 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3p_kernel(const float *__re
             __syncthreads();
             if (s_abort) break;
         }
-        HaloArgs ha = {step > 0 ? pa.T + (size_t)(step - 1) * tstep : nullptr, pa.T + (size_t)step * tstep, nstrips, so, pair_vsum};
+        HaloArgs ha = {step > 0 ? pa.T + (size_t)(step - 1) * tstep : nullptr, pa.T + (size_t)step * tstep,
+                       step > 0 ? (const float *)(pa.T + (size_t)step * tstep - estep) : nullptr, (float *)(pa.T + (size_t)(step + 1) * tstep - estep),
+                       nstrips, so, pair_vsum};
         const float *Min = (step - 1) & 1 ? M1 : M0;
         float *Mout = step & 1 ? M1 : M0;
         if (step == 0) halo_tile<FIRST, RW, NW, false, true, true, true>(lds, R0, R1, nullptr, Mout, fin, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
@@ -2561,7 +2541,7 @@ struct Layout {
 size_t vsum_doubles(int w, int h) {
     const size_t pitch = (size_t)plane_pitch(w);
     const size_t a = 5 * pitch * h, b = (size_t)(ofxcv_div_up(h, 2) + 10) * 5 * pitch, c = 3 * (size_t)(ofxcv_div_up(h, 12) + 1) * 5 * pitch;
-    const size_t d = 4 * (size_t)(ofxcv_div_up(h, 9) + 1) * 5 * pitch;  // overlapped strips: T and T', two buffers
+    const size_t d = 4 * (size_t)(ofxcv_div_up(h, 9) + 1) * 5 * pitch + 16 * pitch;  // overlapped strips: T, T' and the edge rows, two buffers
     return round_up(std::max(std::max(a, d), std::max(b, c)), 32);
 }
 
@@ -3015,22 +2995,20 @@ HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
 }
 struct HaloScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles further)
     double *T[2];
+    float *E[2];  // edge rows of M ([3][5][pitch] floats each)
 };
-size_t halo_scratch_doubles(int w0, int h0) {  // one buffer: T and T' for strips of >= 9 output rows
-    return 2 * (size_t)(ofxcv_div_up(h0, 9) + 1) * 5 * plane_pitch(w0);
+size_t halo_edge_doubles(int w) { return 8 * (size_t)plane_pitch(w); }  // 15 * pitch floats, rounded up
+size_t halo_scratch_doubles(int w0, int h0) {  // one buffer: T and T' for strips of >= 9 output rows + the edge rows
+    return 2 * (size_t)(ofxcv_div_up(h0, 9) + 1) * 5 * plane_pitch(w0) + halo_edge_doubles(w0);
 }
 HaloScratch halo_scratch(int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
     HaloScratch hs;
-    hs.T[0] = L.vsum_ptr;
-    hs.T[1] = L.vsum_ptr + halo_scratch_doubles(w0, h0);
+    const size_t n = halo_scratch_doubles(w0, h0), e = halo_edge_doubles(w0);
+    for (int i = 0; i < 2; i++) {
+        hs.T[i] = L.vsum_ptr + i * n;
+        hs.E[i] = (float *)(hs.T[i] + (n - e));
+    }
     return hs;
-}
-int launch_halo_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const HaloScratch &hs, int slot, const Layout &L) {
-    const HaloGeom g = halo_geom(ctx, w, h, L.n);
-    HaloArgs ha = {nullptr, hs.T[slot], g.nstrips, g.so, L.vsum};
-    hipLaunchKernelGGL(halo_seed_kernel, dim3(ofxcv_div_up(w, 64), g.nstrips, 5 * L.n), dim3(64 * kSeedQ), 0, s, M, w, h, plane_pitch(w), ha, L.planes);
-    OFXCV_LAUNCH_CHECK(ctx, "halo_seed_kernel");
-    return OFXCV_OK;
 }
 // kind: kHaloLast / kHaloIter = one iteration (Min -> flows / Mout); kHaloZero / kHaloCoarse / kHaloGiven = the first M of a
 // level together with its strip sums (Min unused; `flows` = the coarser level's / the caller's flow)
@@ -3039,8 +3017,10 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     RgbaTab rg = {};
     if (rgba && kind == kHaloLast) rg = *rgba;
     const HaloGeom g = halo_geom(ctx, w, h, L.n);
-    HaloArgs ha = {hs.T[slot], hs.T[slot ^ 1], g.nstrips, g.so, L.vsum};
-    if (kind >= kHaloZero) {  // writes the strip sums of the M it produces into T[slot]
+    HaloArgs ha = {hs.T[slot], hs.T[slot ^ 1], hs.E[slot], hs.E[slot ^ 1], g.nstrips, g.so, L.vsum};
+    if (kind >= kHaloZero) {  // writes the strip sums / edge rows of the M it produces into slot `slot`
+        ha.Ein = nullptr;
+        ha.Eout = hs.E[slot];
         ha.Tin = nullptr;
         ha.Tout = hs.T[slot];
     }
@@ -3068,10 +3048,6 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     else if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);
     else if (g.rw == 5) OFXCV_LAUNCH_HALO(5, 4, false, false);
     else if (g.nw == 4) OFXCV_LAUNCH_HALO(9, 4, true, false);
-    else if (ctx->fb_halo_mshare && kind == kHaloIter)
-        hipLaunchKernelGGL((iterate3h_kernel<kHaloIter, 9, 8, true, false, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes, rg);
-    else if (ctx->fb_halo_mshare && kind == kHaloLast)
-        hipLaunchKernelGGL((iterate3h_kernel<kHaloLast, 9, 8, true, false, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, L.planes, rg);
     else OFXCV_LAUNCH_HALO(9, 8, true, false);
 #undef OFXCV_LAUNCH_HALO
 #undef OFXCV_LAUNCH_HALO_K
@@ -3084,10 +3060,10 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 // geometry of eight 3- or 2-row wavefronts, at most 64 strips (one lane of the waiting wavefront per strip) and the strip sums
 // of every step fit the pair's f64 scratch.
 bool persist_level(const ofxcv_ctx *ctx, const Layout &L, int w, int h, int gn, int iterations, bool halo) {
-    if (!halo || !ctx->fb_persist || ctx->prof_on || ctx->fb_halo_seed) return false;
+    if (!halo || !ctx->fb_persist || ctx->prof_on) return false;
     const HaloGeom g = halo_geom(ctx, w, h, gn);
     if (g.nw != 8 || (g.rw != 3 && g.rw != 2) || g.nstrips > 64) return false;
-    return (size_t)(iterations + 1) * 2 * g.nstrips * 5 * plane_pitch(w) <= L.vsum;
+    return (size_t)(iterations + 1) * (2 * (size_t)g.nstrips * 5 * plane_pitch(w) + halo_edge_doubles(w)) <= L.vsum;
 }
 size_t persist_words(const ofxcv_ctx *ctx, int w, int h, int gn, int iterations) {  // ticket (+ padding) and the step / strip counters of one launch
     const HaloGeom g = halo_geom(ctx, w, h, gn);
@@ -3322,9 +3298,8 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                               (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, gn));  // 3: only the levels that are bandwidth-bound
             const bool halo = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries >= 4 &&
                               (ctx->fb_fold_carries != 5 || fold_level_is_large(ctx, w, h, gn));  // 5: only the bandwidth-bound levels
-            // halo: the level's first M and its strip sums come from the iteration kernel's "first" forms in one launch
-            // (option farneback.halo_seed 1: update_matrices_kernel + halo_seed_kernel, which re-reads M)
-            const bool halo_first = halo && !ctx->fb_halo_seed;
+            // halo: the level's first field, its strip sums and edge rows come from the iteration kernel's "first" forms in one launch
+            const bool halo_first = halo;
             HaloScratch hs = {};
             if (halo) hs = halo_scratch(width, height, G);
             const Prolong no_pr = {0, 0, 1.0, 1.0, 1.0};
@@ -3381,10 +3356,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             if (halo_first && rc) return rc;
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
             int cur = 0;
-            if (halo && !halo_first) {
-                rc = launch_halo_seed(ctx, s, M0, w, h, hs, 0, G);
-                if (rc) return rc;
-            }
             FoldScratch fs = {};
             if (fold) {
                 fs = fold_scratch(ctx, width, height, G);

@@ -270,8 +270,8 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
                  dict(fold_carries=4, halo_geom=1), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3),
                  dict(fold_carries=4, halo_geom=2, halo_strip=33), dict(fold_carries=4, halo_geom=2, halo_strip=35),
                  dict(fold_carries=4, halo_geom=3, halo_strip=65), dict(fold_carries=4, halo_geom=3, halo_strip=70),
-                 dict(fold_carries=5, fold_min=1, halo_geom=2), dict(fold_carries=4, halo_seed=1), dict(fold_carries=4, halo_seed=1, halo_geom=3),
-                 dict(halo_geom=3, halo_mshare=0), dict(halo_geom=3, halo_mshare=1), dict(halo_geom=3, halo_mshare=1, halo_strip=67)):
+                 dict(fold_carries=5, fold_min=1, halo_geom=2),
+                 dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=72), dict(halo_small=2), dict(halo_small=4), dict(halo_small=5)):
         ctx = ofxcv.Context(0)
         for k, v in opts.items():
             ctx.set_option("farneback." + k, v)
@@ -290,7 +290,7 @@ def test_opencv_order_mode_overlapped_strips_first_matrix_forms(oracle, ofxcv, w
     init = rng.normal(0, 2, size=(h, w, 2)).astype(np.float32)
     for kw in (dict(iterations=1), dict(iterations=2), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
         outs = []
-        for opts in (dict(fold_carries=0), dict(fold_carries=4), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_seed=1)):
+        for opts in (dict(fold_carries=0), dict(fold_carries=4), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3), dict(fold_carries=4, halo_small=5)):
             ctx = ofxcv.Context(0)
             for k, v in opts.items():
                 ctx.set_option("farneback." + k, v)
