@@ -2041,14 +2041,14 @@ struct HaloArgs {
 // KIND: what the flow of a row comes from, and what leaves the kernel
 //   kHaloLast    solve of box(M_in); the flow of the stored rows goes to `flows` (last iteration of a level), no M_out
 //   kHaloIter    solve of box(M_in); M_out = UpdateMatrices(R0, R1, flow) + T / T' of M_out
-// What travels between launches is not M but its ROW DIFFERENCES: row t of the field `Min` / `Mout` holds
+//   kHaloZero / kHaloCoarse / kHaloGiven   the FIRST M of a level (+ its T / T'): zero flow (coarsest level), the coarser
+//                level's flow prolongated (F6, `flows` = that flow), the caller's flow (`flows`, USE_INITIAL_FLOW at level 0)
+// In the tall forms what travels between launches is not M but its ROW DIFFERENCES: row t of the field `Min` / `Mout` holds
 //     d_t = (float)(M[min(t+1, h-1)] - M[max(t-2, 0)])          (the reference's srow1[x] - srow0[x])
 // -- all an iteration ever uses of M besides vsum(-1).  The producer has every d_t of its strip anyway (it sums them for T);
 // the consumer reads ITS OWN rows only (no three neighbour rows per wavefront to re-read or exchange) and starts its chain
 // directly.  d_{h-1} = M[h-1] - M[max(h-3, 0)] has no row below it to be computed from three rows later, and vsum(-1) needs
 // row 0 itself: those three rows of M travel in a small side array (`Ein` / `Eout`).
-//   kHaloZero / kHaloCoarse / kHaloGiven   the FIRST M of a level (+ its T / T'): zero flow (coarsest level), the coarser
-//                level's flow prolongated (F6, `flows` = that flow), the caller's flow (`flows`, USE_INITIAL_FLOW at level 0)
 enum { kHaloLast = 0, kHaloIter = 1, kHaloZero = 2, kHaloCoarse = 3, kHaloGiven = 4 };
 
 // DEEP: the gathers of ALL rows of the wavefront are in flight before the first row is finished (one memory latency per

@@ -246,10 +246,11 @@ def test_opencv_order_mode_strip_heights_and_serial_scan_agree(oracle, ofxcv, ro
 
 @pytest.mark.parametrize("w,h", [(125, 70), (333, 257), (640, 480), (1920, 1080)])
 def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
-    """the carries of the f64 column sums from a pre-pass over M (default) or produced by the iteration kernel itself
-    (farneback.fold_carries 1: prefix over the strips by the last workgroup of a tile column, an atomic counter, device-scope
-    loads; 2: by a small launch of its own; 3, the default: 2 on the large pyramid levels, the pre-pass on the small ones):
-    the same flow, within tolerance of the faithful oracle at every sample"""
+    """the carries of the f64 column sums from a pre-pass over M (farneback.fold_carries 0), produced by the iteration kernel
+    itself (1: prefix over the strips by the last workgroup of a tile column, an atomic counter, device-scope loads; 2: by a small
+    launch of its own; 3: 2 on the large pyramid levels, the pre-pass on the small ones) or from overlapped strips whose sums the
+    next launch adds up in its prologue (4, the default: one launch per iteration; 5: 4 on the large levels only): the same flow
+    bit for bit, within tolerance of the faithful oracle at every sample"""
     ga, gb = _gray_pair(oracle, w, h)
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
     outs = []
