@@ -86,7 +86,7 @@ struct ofxcv_ctx {
     // overlapped-strip form (fold_carries 4 / 5): option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
     // 3 eight of 8 or 9; "farneback.halo_min8" / "halo_min4": workgroups from which the eight- / four-wavefront tall form is used;
     // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
-    int fb_halo_geom = 0, fb_halo_min8 = 400, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
+    int fb_halo_geom = 0, fb_halo_min8 = 250, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
