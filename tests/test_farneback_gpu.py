@@ -334,6 +334,29 @@ def test_opencv_order_mode_persistent_small_levels(oracle, ofxcv, w, h, n):
     assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
 
 
+@pytest.mark.parametrize("w,h", [(1, 1), (2, 3), (3, 2), (7, 5), (17, 4), (64, 1), (1, 64), (130, 9), (9, 130), (63, 22), (33, 24)])
+def test_opencv_order_mode_tiny_frames(oracle, ofxcv, w, h):
+    """frames smaller than a strip, a tile, the three-row reach of a row difference: every carry form gives the same flow as
+    the faithful oracle's (levels clip to 0 below 32 pixels), scratch reservations hold (column-sum scratch of
+    one-row images)"""
+    rng = np.random.default_rng(w * 131 + h)
+    ga = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    gb = np.roll(ga, 1, axis=1) if w > 1 else ga.copy()
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, iterations=3)
+    outs = []
+    for fold in (0, 2, 4):
+        ctx = ofxcv.Context(0)
+        ctx.set_option("farneback.fold_carries", fold)
+        if fold == 2:
+            ctx.set_option("farneback.fold_min", 1)
+        for _ in range(2):
+            got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), iterations=3).cpu().numpy()
+        ctx.close()
+        assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), (fold, np.abs(got - ref).max())
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_opencv_order_mode_single_step(oracle, ofxcv, strict_ctx):
     rng = np.random.default_rng(13)
     h, w = 119, 161

@@ -1,2 +1,8 @@
 cd /root/repo
-for m8 in 120 250 350; do for bs in "1 1" "2 4" "3 4" "6 2" "4 3"; do set -- $bs; BENCH_CTX_OPTIONS=farneback.halo_min8=$m8 timeout 300 python bench.py --batch $1 --streams $2 --steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('min8 $m8 batch $1 streams $2', round(d['value'],1), round(d['value_one_pair_in_flight'],1))"; done; done
+timeout 120 python tools/ab_iter.py --size 3840x552 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 3840x276 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 3840x1104 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 3840x2160 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 1920x276 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 1920x552 "" 2>&1 | grep pairs
+timeout 120 python tools/ab_iter.py --size 1920x1080 "" 2>&1 | grep pairs
