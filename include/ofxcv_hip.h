@@ -89,7 +89,7 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.lds_pad" bytes: A/B knobs of the pre-pass form of the OpenCV-order kernels. */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
 /* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register",
- * "farneback.batch_mb", "farneback.persist", "farneback.persist_aborts" (synchronises the device: a test hook) */
+ * "farneback.batch_mb", "farneback.persist", "farneback.persist_aborts" (waits for the context's streams: a test hook) */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------

@@ -324,11 +324,11 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else if (!std::strcmp(name, "farneback.persist")) *value = ctx->fb_persist;
     else if (!std::strcmp(name, "farneback.persist_aborts")) {
-        // the sticky abort flag of the persistent small-level launches (waits for the context's work first)
+        // the sticky abort flag of the persistent small-level launches (waits for the context's streams first)
         *value = 0;
         if (ctx->fb_persist_buf.ptr) {
             unsigned flag = 0;
-            if (hipSetDevice(ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK ||
                 hipMemcpy(&flag, ctx->fb_persist_buf.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
                 return OFXCV_ERR_HIP;
             *value = (int)flag;
