@@ -134,8 +134,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4, help="frame pairs per batched Farneback call (ofxcv_calc_optical_flow_farneback_batch)")
-    ap.add_argument("--streams", type=int, default=3, help="batched calls in flight per GPU, each on its own context/stream; "
+    ap.add_argument("--batch", type=int, default=8, help="frame pairs per batched Farneback call (ofxcv_calc_optical_flow_farneback_batch_rgba); "
+                    "8 = BASELINE configs[4]'s pairs per GPU")
+    ap.add_argument("--streams", type=int, default=1, help="batched calls in flight per GPU, each on its own context/stream (one: a single pair's "
+                    "level 0 then stays in the Infinity Cache; measured against 4 x 3 and others in profiles/r03_exp09_overlapped_strips.txt); "
                     "pairs per step per GPU = batch x streams")
     ap.add_argument("--repeats", type=int, default=10, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -13,8 +13,8 @@ if [ -z "$SKIP_PMC" ]; then
 fi
 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 # kernel trace of the timed workload (defaults: batched calls on several streams) and of one single-pair call at a time
-for cfg in "default" "single"; do
-  if [ $cfg = default ]; then ARGS=""; else ARGS="--batch 1 --streams 1"; fi
+for cfg in "default" "single" "b4s3"; do
+  if [ $cfg = default ]; then ARGS=""; elif [ $cfg = b4s3 ]; then ARGS="--batch 4 --streams 3"; else ARGS="--batch 1 --streams 1"; fi
   RAW=/tmp/prof_$cfg; rm -rf $RAW
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o b -- python $R/bench.py $ARGS --steps 40 --warmup 10 --repeats 2 --no-cpu-baseline --no-extra-legs > $OUT/prof_$cfg.log 2>&1
   cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_${cfg}_kernel_stats.csv
