@@ -2967,9 +2967,12 @@ HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     if (form == 1) {
         // small levels: by default eight wavefronts of 3 rows (21 stored rows per strip); option farneback.halo_small 5 = four of 5
         // rows, 2 = eight of 2, 4 = four of 3
-        const int f = ctx->fb_halo_small;
+        // ... and eight of 5 rows (difference field, no rows through LDS) on a level in between: 960x540 of a single pair, 240 such
+        // workgroups (16.2 against 17.3 us; on the levels below it the longer wavefronts lose: 12.9 / 14.0 against 10.4 / 12.0 us)
+        int f = ctx->fb_halo_small;  // 6 forces that form
+        if (f == 3 && t * ofxcv_div_up(h, 37) >= ctx->fb_halo_min5) f = 6;
         g.nw = (f == 5 || f == 4) ? 4 : 8;
-        g.rw = f == 5 ? 5 : (f == 2 ? 2 : 3);
+        g.rw = (f == 5 || f == 6) ? 5 : (f == 2 ? 2 : 3);
         g.so = g.nw * g.rw - 3;
     } else {
         g.nw = form == 3 ? 8 : 4;
@@ -3042,7 +3045,8 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
     } while (0)
     // small form: every gather of a wavefront in flight at once while the launch has at most two wavefronts per SIMD
     const bool deep = g.rw == 5 && ctx->fb_halo_deep && (long)g.tiles_x * g.nstrips * L.n * 4 <= (long)ctx->fb_halo_deep * 4 * ctx->num_cus;
-    if (g.rw == 3 && g.nw == 8) OFXCV_LAUNCH_HALO(3, 8, false, true);
+    if (g.rw == 5 && g.nw == 8) OFXCV_LAUNCH_HALO(5, 8, false, false);
+    else if (g.rw == 3 && g.nw == 8) OFXCV_LAUNCH_HALO(3, 8, false, true);
     else if (g.rw == 2) OFXCV_LAUNCH_HALO(2, 8, false, true);
     else if (g.rw == 3) OFXCV_LAUNCH_HALO(3, 4, false, true);
     else if (g.rw == 5 && deep) OFXCV_LAUNCH_HALO(5, 4, false, true);

@@ -272,7 +272,7 @@ def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
                  dict(fold_carries=4, halo_geom=2, halo_strip=33), dict(fold_carries=4, halo_geom=2, halo_strip=35),
                  dict(fold_carries=4, halo_geom=3, halo_strip=65), dict(fold_carries=4, halo_geom=3, halo_strip=70),
                  dict(fold_carries=5, fold_min=1, halo_geom=2),
-                 dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=72), dict(halo_small=2), dict(halo_small=4), dict(halo_small=5)):
+                 dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=72), dict(halo_small=2), dict(halo_small=4), dict(halo_small=5), dict(halo_small=6), dict(halo_min5=1)):
         ctx = ofxcv.Context(0)
         for k, v in opts.items():
             ctx.set_option("farneback." + k, v)
