@@ -58,6 +58,7 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                      Also selected by the environment variable OFXCV_FARNEBACK_WINDOW=direct.
  *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
  *                                    Window sizes other than the reference's 3 always use direct sums.
+ *   "lut.four"                  0|1  gray LUT with four pixels per lane where the images are aligned for it (default 1);
  *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);

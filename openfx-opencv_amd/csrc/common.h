@@ -88,6 +88,7 @@ struct ofxcv_ctx {
     // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
     int fb_halo_geom = 0, fb_halo_min8 = 250, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
+    int lut4 = 1;                // option "lut.four": gray LUT with four pixels per lane where the images are aligned for it
     int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)

@@ -99,6 +99,21 @@ __global__ __launch_bounds__(256) void gray_lut_kernel(const float *__restrict__
     }
 }
 
+// Four consecutive RGBA pixels per lane: four independent 16-byte loads in flight, the four gray bytes leave as one dword
+// (a wavefront stores 256 contiguous bytes).  Needs 16-byte aligned source rows, a 4-byte aligned destination and a width
+// that is a multiple of 4; everything else takes gray_lut_kernel.
+__global__ __launch_bounds__(256) void gray_lut4_kernel(const float *__restrict__ src, ptrdiff_t src_row_bytes, int width, int height,
+                                                        uint8_t *__restrict__ dst, ptrdiff_t dst_row_bytes, const uint16_t *__restrict__ lut) {
+    const int y = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // group of four pixels
+    if (q * 4 >= width) return;
+    const float4 *srow = (const float4 *)((const char *)src + (ptrdiff_t)y * src_row_bytes) + (size_t)q * 4;
+    const float4 p0 = srow[0], p1 = srow[1], p2 = srow[2], p3 = srow[3];
+    const unsigned b0 = lut_byte(lut, p0.x, p0.y, p0.z), b1 = lut_byte(lut, p1.x, p1.y, p1.z), b2 = lut_byte(lut, p2.x, p2.y, p2.z),
+                   b3 = lut_byte(lut, p3.x, p3.y, p3.z);
+    *(unsigned *)(dst + (ptrdiff_t)y * dst_row_bytes + (size_t)q * 4) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
 __global__ __launch_bounds__(256) void flow_to_rgba_kernel(const float *__restrict__ flow, size_t flow_step, int width,
                                                            int height, float *__restrict__ dst, ptrdiff_t dst_row_bytes,
                                                            unsigned mu, unsigned mv, double rsx, double rsy) {
@@ -148,7 +163,10 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
     // one pixel per thread measured best (9.6 us per 1080p RGBA frame; 2 / 4 / 8 pixels per thread: 10.4 / 11.6 / 10.8 us)
     constexpr int kSeg = 1;
     dim3 block(256), grid(ofxcv_div_up(width, 256 * kSeg), height);
-    if (ncomp == 4)
+    if (ncomp == 4 && ctx->lut4 && !(width & 3) && !(((uintptr_t)d_src) & 15) && !(src_row_bytes & 15) && !(((uintptr_t)d_dst) & 3) && !(dst_row_bytes & 3))
+        hipLaunchKernelGGL(gray_lut4_kernel, dim3(ofxcv_div_up(width / 4, 256), height), block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes,
+                           ctx->d_srgb_lut);
+    else if (ncomp == 4)
         hipLaunchKernelGGL((gray_lut_kernel<4, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
     else
         hipLaunchKernelGGL((gray_lut_kernel<3, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);

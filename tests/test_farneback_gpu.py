@@ -179,6 +179,14 @@ def test_gray_lut_and_scatter(oracle, ofxcv, direct_ctx):
     rgb[0, 0] = 0.5
     rgb[0, 1] = 0.25
     assert np.array_equal(direct_ctx.to_byte_grayscale(_dev(rgb)).cpu().numpy(), oracle.to_byte_grayscale(rgb))
+    # widths that are a multiple of four take the four-pixels-per-lane kernel (53 above does not): both against the oracle
+    wide = rng.uniform(-0.2, 1.3, size=(37, 256 + 52, 4)).astype(np.float32)
+    wide[3, 5] = (np.nan, np.inf, -np.inf, 0)
+    one = ofxcv.Context(0)
+    one.set_option("lut.four", 0)
+    for c in (direct_ctx, one):
+        assert np.array_equal(c.to_byte_grayscale(_dev(wide)).cpu().numpy(), oracle.to_byte_grayscale(wide))
+    one.close()
     flow = rng.normal(0, 3, size=(37, 53, 2)).astype(np.float32)
     for mu, mv, rs in [(0b0011, 0b1100, (1.0, 1.0)), (0b0001, 0b0010, (0.5, 0.25)), (0b0101, 0b0100, (1.0, 2.0)), (0, 0, (1.0, 1.0))]:
         base = rng.normal(size=(37, 53, 4)).astype(np.float32)
