@@ -2018,8 +2018,9 @@ __global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__re
 //     T'_s = the same without the last two (t < A_s + SO - 2)
 // and the next launch's strip s starts its column chain one row above ITS first computed row A_s - 2 with
 //     vsum(A_s - 3) = c0 + T_0 + ... + T_{s-2} + T'_{s-1},      c0 = (double)(3.f * M[0])
-// summed in that order in the kernel's prologue (c0 + T_0 and c0 + T'_0 are what the top strip stores: it owns row 0) (<= 15 values per column and channel at 1080 rows with eight wavefronts per
-// strip, one channel per wavefront, while the rows of M are in flight).  No kernel reads what another workgroup of the same
+// summed in that order in the kernel's prologue (c0 + T_0 and c0 + T'_0 are what the top strip stores: it owns row 0; <= 15
+// values per column and channel at 1080 rows with eight wavefronts per strip, one channel per wavefront, while the rows of
+// the field are in flight).  No kernel reads what another workgroup of the same
 // launch wrote; nothing but f64 additions is re-associated, as in the other strip-parallel forms.  Price: SO + 3 rows are
 // computed for SO stored (4.3 % at 72-row strips), against one launch and ~18 MB of boundary rows per iteration saved.
 struct HaloArgs {
