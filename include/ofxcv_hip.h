@@ -66,8 +66,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "host.register"           0|1|2  how ofxcv_vectorgen_flow(s)_host moves host images: 1 (default) asynchronous copies straight from / into
  *                                    the host's pageable images; 2 the host's buffers registered (hipHostRegister) for the duration of the
  *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
- *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n   A/B: fill-order pixels per portion of the pipelined fill (8192) and
- *                                    per workgroup of a component (256);
+ *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   A/B: fill-order pixels per portion of the
+ *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
  *   "farneback.fold_carries" 0..5    OpenCV-order mode, how the f64 column sums are carried from strip to strip:
  *                                    4 (default) overlapped strips -- a workgroup computes three rows more than it stores, leaves the sums of

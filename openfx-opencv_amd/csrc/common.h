@@ -111,6 +111,7 @@ struct ofxcv_ctx {
     void *ip_pinned = nullptr;   // pinned mirror of the per-pixel upload arrays of the pipelined fill
     size_t ip_pinned_bytes = 0;
     int ip_per_wg = 0;       // option "inpaint.pixels_per_workgroup" (A/B)
+    int ip_max_wg = 0;       // option "inpaint.max_workgroups": workgroups per component and portion of the pipelined fill (0 = 8)
     int ip_portion = 0;      // option "inpaint.portion": fill-order pixels per portion of the pipelined fill (0 = default)
     DevBuf ip_sched2; // level schedule of the fall-back fill
     int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)

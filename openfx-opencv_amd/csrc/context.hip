@@ -226,6 +226,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_per_wg = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "inpaint.max_workgroups")) {
+        ctx->ip_max_wg = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "inpaint.portion")) {
         ctx->ip_portion = value;
         return OFXCV_OK;

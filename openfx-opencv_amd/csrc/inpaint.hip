@@ -183,7 +183,7 @@ void build_levels(March &m, bool dataflow) {
 // launch starts (stream order), later ones still carry kNeverFilled in the order map: the polls only ever wait inside
 // the portion.
 int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
-                           std::vector<int> &cell, std::vector<int> &stack, int per_wg) {
+                           std::vector<int> &cell, std::vector<int> &stack, int per_wg, int max_wg) {
     const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
     const int cs = 2 * R + 1, gw = (ec + cs - 1) / cs, gh = (er + cs - 1) / cs;
     const int n = k1 - k0;
@@ -235,7 +235,7 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
     int nwg = 0;
     for (int c = 0; c < ncomp; c++) {
         const int nc = off[c + 1] - off[c];
-        const int g = std::min(8, std::max(1, (nc + per_wg - 1) / per_wg));
+        const int g = std::min(max_wg, std::max(1, (nc + per_wg - 1) / per_wg));
         for (int r = 0; r < g; r++) {
             const int rec[4] = {base + off[c], base + off[c + 1], r * kFillWavesHost, g * kFillWavesHost};
             sched_wg.insert(sched_wg.end(), rec, rec + 4);
@@ -858,7 +858,8 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             if (got <= 0) break;
             const int k1 = k0 + got;
             const size_t wg0 = sw.size() / 4;
-            const int nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256);
+            const int nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256,
+                                                   ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8);
             t_sched += trace ? now() - tb : 0;
             if ((rc = scatter_front(k0, k1))) return rc;
             std::memcpy(hp + off_pix + (size_t)k0 * 4, sp.data() + k0, (size_t)got * 4);
