@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <queue>
 #include <thread>
@@ -74,6 +75,7 @@ inline float front_value(int i, int j, const uint8_t *f, const float *t, int ec)
 // costs time proportional to the hole, not to the frame (22 MB of fills per 1080p call otherwise).
 struct Par;
 void par_free(Par *);
+void par_wait(Par *);  // joins component marches that may still be running on the pool
 
 struct March {
     int w = 0, h = 0, range = 1;
@@ -114,6 +116,7 @@ struct March {
         dirty = false;
     }
     void prepare(int w_, int h_, int range_) {
+        par_wait(par);  // a call that ended early may have left component marches running: they write t / mask
         par_on = false;
         const size_t en = (size_t)(w_ + 2) * (h_ + 2);
         if (w_ != w || h_ != h || t.size() != en) {
@@ -272,6 +275,18 @@ struct Par {
         int next = 0;                   // merge cursor: next local pop
         int size = 0;                   // hole pixels of the component
     };
+    // What a marching thread publishes to the merging thread while it is still at work (streamed merge): the number of local
+    // pops whose children are complete, that the children of its seeds are complete, that it has finished.  The vectors of a
+    // Comp are reserved to their final size before the march starts (no reallocation), so everything below a published
+    // count may be read while the rest is still being appended.
+    struct Sync {
+        alignas(64) std::atomic<int> closed{0};
+        std::atomic<int> seeds_done{0}, finished{0};
+    };
+    std::unique_ptr<Sync[]> sync;
+    bool async = false;                 // component marches may still be running on the pool
+    bool seeds_merged = false;
+    std::vector<int> waiting;           // components whose next pop the merge has to wait for
     std::vector<Comp> comps;
     std::vector<int> label;             // padded map: component of a hole pixel (reset sparsely)
     std::vector<int> labelled;
@@ -291,7 +306,7 @@ struct Par {
     int nseeds = 0, next_rank = 0;
     bool heads_ready = false;
 };
-inline void par_free(Par *p) { delete p; }
+
 
 // a few helper threads shared by all contexts (created on first use, never joined: no static destructor while a host unloads us)
 class MarchPool {
@@ -326,7 +341,37 @@ class MarchPool {
         for (int i = 0; i < nworkers_; i++) std::thread([this] { worker(); }).detach();
     }
 
+    std::unique_lock<std::mutex> async_user_;
+    std::function<void(int)> held_;
+
 public:
+    // tasks 0..n-1 on the workers only; the caller goes on (to merge what they produce) and calls finish() afterwards.
+    // false: the pool is in use or has no workers -- the caller runs the tasks itself.
+    bool start(int n, std::function<void(int)> fn) {
+        std::unique_lock<std::mutex> user(user_, std::try_to_lock);
+        if (!user.owns_lock() || nworkers_ == 0 || n <= 0) return false;
+        async_user_ = std::move(user);
+        held_ = std::move(fn);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &held_;
+            ntasks_ = n;
+            next_.store(0);
+            active_ = nworkers_;
+            ++gen_;
+        }
+        cv_job_.notify_all();
+        return true;
+    }
+    void finish() {
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return active_ == 0; });
+            job_ = nullptr;
+        }
+        async_user_.unlock();
+        async_user_ = std::unique_lock<std::mutex>();
+    }
     static MarchPool &get() {
         static MarchPool *p = new MarchPool();  // intentionally leaked
         return *p;
@@ -355,9 +400,21 @@ public:
     }
 };
 
+inline void par_wait(Par *p) {
+    if (p && p->async) {
+        MarchPool::get().finish();
+        p->async = false;
+    }
+}
+inline void par_free(Par *p) {
+    par_wait(p);
+    delete p;
+}
+
 // the inward march of one component (everything icvTeleaInpaintFMM's front does to this component's pixels)
 inline void par_march_component(March &m, Par &P, int ci) {
     Par::Comp &C = P.comps[ci];
+    Par::Sync &S = P.sync[ci];
     const int ec = m.w + 2, er = m.h + 2;
     uint8_t *f = m.mask.data();
     float *t = m.t.data();
@@ -389,10 +446,14 @@ inline void par_march_component(March &m, Par &P, int ci) {
             ii = n / ec;
             jj = n - ii * ec;
             f[n] = KNOWN;
-            if (C.pop_push.empty()) C.seed_child_begin.push_back((int)C.pushes.size());  // the seeds (T = 0) have all popped: end of the last one's children
+            if (C.pop_push.empty()) {
+                C.seed_child_begin.push_back((int)C.pushes.size());  // the seeds (T = 0) have all popped: end of the last one's children
+                S.seeds_done.store(1, std::memory_order_release);
+            }
             parent = (int)C.pop_push.size();
             C.pop_push.push_back(wh);
             C.child_begin.push_back((int)C.pushes.size());
+            S.closed.store(parent, std::memory_order_release);  // the pops before this one have all their children
         }
         const int ni[4] = {ii - 1, ii, ii + 1, ii}, nj[4] = {jj, jj - 1, jj, jj + 1};
         for (int k = 0; k < 4; k++) {
@@ -412,7 +473,9 @@ inline void par_march_component(March &m, Par &P, int ci) {
     }
     C.child_begin.push_back((int)C.pushes.size());
     if (C.pop_push.empty()) C.seed_child_begin.push_back((int)C.pushes.size());
-    C.grank.assign(C.pop_push.size(), 0);
+    S.closed.store((int)C.pop_push.size(), std::memory_order_release);
+    S.seeds_done.store(1, std::memory_order_release);
+    S.finished.store(1, std::memory_order_release);
 }
 
 // After march_begin(): labels the 4-connected components of the hole, marches them on the pool and prepares the merge;
@@ -474,12 +537,34 @@ inline bool march_parallel_run(March &m, int min_pixels = 8192) {
             }
         }
     }
-    // largest components first (dynamic scheduling over the pool)
+    // largest components first (dynamic scheduling over the pool).  The marches run on the pool's threads while this thread
+    // merges what they have produced so far (par_advance): the first portion of the fill order leaves after a fraction of a
+    // millisecond instead of after the largest component's whole march.
     std::vector<int> order(P.comps.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
     std::sort(order.begin(), order.end(), [&](int a, int b) { return P.comps[a].size > P.comps[b].size; });
-    MarchPool::get().run((int)order.size(), [&](int i) { par_march_component(m, P, order[i]); });
-    // merge, seed phase: the children of the seeds in (seed, neighbour) order
+    P.sync.reset(new Par::Sync[P.comps.size()]);
+    for (Par::Comp &C : P.comps) C.grank.assign(C.size, 0);
+    Par *pp = &P;
+    March *mp = &m;
+    P.async = MarchPool::get().start((int)order.size(), [mp, pp, order](int i) { par_march_component(*mp, *pp, order[i]); });
+    if (!P.async)
+        for (int ci : order) par_march_component(m, P, ci);
+    P.seed_order.clear();
+    P.seeds_merged = false;
+    P.waiting.clear();
+    P.seed_cursor = 0;
+    P.next_rank = P.nseeds;
+    P.heads = decltype(P.heads)();
+    P.heads_ready = false;
+    m.par_on = true;
+    return true;
+}
+
+// merge, seed phase: the children of the seeds in (seed, neighbour) order (every component has popped its seeds by then)
+inline void par_merge_seeds(Par &P) {
+    for (size_t ci = 0; ci < P.comps.size(); ci++)
+        while (!P.sync[ci].seeds_done.load(std::memory_order_acquire)) std::this_thread::yield();
     P.seed_order.clear();
     for (size_t ci = 0; ci < P.comps.size(); ci++) {
         const Par::Comp &C = P.comps[ci];
@@ -501,12 +586,7 @@ inline bool march_parallel_run(March &m, int min_pixels = 8192) {
         for (size_t i = 0; i < n; i++) std::memcpy(&sorted[i * 4], &P.seed_order[idx[i] * 4], 16);
         P.seed_order.swap(sorted);
     }
-    P.seed_cursor = 0;
-    P.next_rank = P.nseeds;
-    P.heads = decltype(P.heads)();
-    P.heads_ready = false;
-    m.par_on = true;
-    return true;
+    P.seeds_merged = true;
 }
 
 // hands out the merged fill order: at least `want` more pixels (or all that are left); same contract as march_advance
@@ -519,6 +599,7 @@ inline int par_advance(March &m, int want) {
         ++m.filled;
         m.pix.push_back(pixel);
     };
+    if (!P.seeds_merged) par_merge_seeds(P);
     const size_t nseed_children = P.seed_order.size() / 4;
     while (P.seed_cursor < nseed_children && (int)(m.pix.size() - before) < want) {
         const int *r = &P.seed_order[P.seed_cursor * 4];
@@ -536,20 +617,39 @@ inline int par_advance(March &m, int want) {
         h.comp = ci;
         return h;
     };
+    // the next pop of component ci for the merge: waits until its thread has closed it (all its children pushed) or finished
+    auto fetch = [&](int ci) {
+        Par::Comp &C = P.comps[ci];
+        Par::Sync &S = P.sync[ci];
+        for (;;) {
+            if (C.next < S.closed.load(std::memory_order_acquire)) {
+                P.heads.push(head_of(ci));
+                return;
+            }
+            if (S.finished.load(std::memory_order_acquire)) {
+                if (C.next < S.closed.load(std::memory_order_acquire)) P.heads.push(head_of(ci));
+                return;
+            }
+            std::this_thread::yield();
+        }
+    };
     if (!P.heads_ready) {
-        for (size_t ci = 0; ci < P.comps.size(); ci++)
-            if (!P.comps[ci].pop_push.empty()) P.heads.push(head_of((int)ci));
+        for (size_t ci = 0; ci < P.comps.size(); ci++) P.waiting.push_back((int)ci);
         P.heads_ready = true;
     }
-    while ((int)(m.pix.size() - before) < want && !P.heads.empty()) {
+    while ((int)(m.pix.size() - before) < want) {
+        for (int ci : P.waiting) fetch(ci);  // the smallest key can only be chosen among ALL components' next pops
+        P.waiting.clear();
+        if (P.heads.empty()) break;
         const int ci = P.heads.top().comp;
         P.heads.pop();
         Par::Comp &C = P.comps[ci];
         const int k = C.next++;
         C.grank[k] = P.next_rank++;
         for (int u = C.child_begin[k]; u < C.child_begin[k + 1]; u++) emit(C.pushes[u].pixel);
-        if (C.next < (int)C.pop_push.size()) P.heads.push(head_of(ci));
+        P.waiting.push_back(ci);
     }
+    if (P.heads.empty() && P.waiting.empty()) par_wait(&P);  // everything is merged: the marches have finished
     return (int)(m.pix.size() - before);
 }
 
