@@ -18,6 +18,7 @@ for cfg in "default" "single" "b4s3"; do
   RAW=/tmp/prof_$cfg; rm -rf $RAW
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o b -- python $R/bench.py $ARGS --steps 40 --warmup 10 --repeats 2 --no-cpu-baseline --no-extra-legs > $OUT/prof_$cfg.log 2>&1
   cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_${cfg}_kernel_stats.csv
+  [ $cfg = default ] && cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv  # the timed workload under the plain name as well
   python $R/tools/trace_by_grid.py $RAW/b_kernel_trace.csv > $OUT/${TAG}_bench_${cfg}_by_grid.txt
 done
 head -c 700 $OUT/${TAG}_bench.json; echo; head -12 $OUT/${TAG}_bench_default_by_grid.txt
