@@ -172,7 +172,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)  # RCCL comes up lazily: fail here, not inside the timed region
+                torch.cuda.synchronize()
+            except Exception as e:  # the collectives only carry the timing barrier and two scalars: gloo serves them as well
+                sys.stderr.write("bench.py: RCCL unavailable (%s: %s), timing barrier over gloo\n" % (type(e).__name__, e))
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend, red_dev = "gloo", "cpu"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
