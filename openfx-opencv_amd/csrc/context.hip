@@ -15,9 +15,18 @@ int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
     return status;
 }
 
+// The lock around the runtime operations that were seen to crash against each other on ROCm 7.2 (stream capture, graph
+// instantiation / launch / destruction, stream creation, device allocations and frees, host registration, context teardown).
+// Several of them touch process-global runtime state (memory-object maps, capture bookkeeping), so the lock is PROCESS-WIDE.
+// OFXCV_LOCK_PER_DEVICE=1 selects one lock per device: only for a multi-device soak
+// (tools/bench_host_threads.py --devices N, 4+ threads per device) -- no such run has been possible on the one-GPU boxes.
 std::shared_mutex &ofxcv_capture_mutex(int device) {
     static std::shared_mutex m[64];
-    return m[(unsigned)device & 63u];
+    static const bool per_device = [] {
+        const char *e = std::getenv("OFXCV_LOCK_PER_DEVICE");
+        return e && e[0] == '1';
+    }();
+    return m[per_device ? ((unsigned)device & 63u) : 0u];
 }
 
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
