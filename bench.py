@@ -532,21 +532,26 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
     out["segment_4k"] = leg
     ctx.close()
 
-    # ---- 3840x2160 Farneback (configs[4] workload on one GPU) ----
+    # ---- 3840x2160 Farneback (configs[4] workload on one GPU: 8 DIFFERENT pairs, seeds 1234..1241) ----
     w, h = 3840, 2160
     alg4 = algorithmic_bytes_per_pair(w, h)
-    leg = {"workload": "Farneback flow, 3840x2160 gray pairs resident in HBM, 8 pairs per GPU (BASELINE configs[4]) as 2 batched calls of 4 in flight; "
-                       "direct-window mode: 4 single-pair calls in flight", "unit": "frame-pairs/s"}
-    a4, b4 = synth.flow_pair(w, h)
+    leg = {"workload": "Farneback flow, 3840x2160 gray pairs resident in HBM, 8 different pairs per GPU (BASELINE configs[4], seeds 1234..1241) as ONE "
+                       "batched call of 8 at a time; direct-window mode: 4 single-pair calls in flight", "unit": "frame-pairs/s"}
+    c0 = ofxcv.Context(dev)
+    grays = []
+    for seed in range(1234, 1242):
+        a4, b4 = synth.flow_pair(w, h, seed=seed)
+        grays.append((c0.to_byte_grayscale(torch.from_numpy(a4).cuda()), c0.to_byte_grayscale(torch.from_numpy(b4).cuda())))
+    torch.cuda.synchronize()
+    del a4, b4
     for direct, key in ((False, "value"), (True, "value_direct_window")):
-        ns, nb = (4, 1) if direct else (2, 4)
+        ns, nb = (4, 1) if direct else (1, 8)
         cs = [ofxcv.Context(dev) for _ in range(ns)]
         bufs = []
-        for c in cs:
+        for i, c in enumerate(cs):
             c.set_option("farneback.opencv_rounding", 0 if direct else 1)
-            with torch.cuda.stream(c.stream):
-                ga, gb = c.to_byte_grayscale(torch.from_numpy(a4).cuda()), c.to_byte_grayscale(torch.from_numpy(b4).cuda())
-                bufs.append(([ga] * nb, [gb] * nb, [torch.empty((h, w, 2), device="cuda") for _ in range(nb)]))
+            prs = grays[i * nb:(i + 1) * nb]
+            bufs.append(([p[0] for p in prs], [p[1] for p in prs], [torch.empty((h, w, 2), device="cuda") for _ in range(nb)]))
 
         def step4():
             for c, (ga, gb, fl) in zip(cs, bufs):
@@ -564,9 +569,23 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
             rs.append(4 * ns * nb / (time.perf_counter() - t0))
         leg[key] = med(rs)
         leg[key + "_frac_of_hbm_peak"] = alg4 * med(rs) / 1e9 / HBM_PEAK_GBS
+        if not direct:
+            flows4 = [f.cpu().numpy() for f in bufs[0][2]]
+            single = [c0.calc_optical_flow_farneback(ga, gb).cpu().numpy() for ga, gb in grays[:2]]
+            par4 = {"batch_equals_single_calls_bit_for_bit_pairs_0_1": bool(all(np.array_equal(x, y) for x, y in zip(single, flows4)))}
+            if with_cpu:
+                from oracle import binding as oracle
+                ref = oracle.calc_optical_flow_farneback(grays[0][0].cpu().numpy(), grays[0][1].cpu().numpy(), PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N,
+                                                         POLY_SIGMA, 0, oracle.BLUR_FAITHFUL)
+                err = np.abs(flows4[0] - ref)
+                par4.update({"reference": "CPU oracle (FAITHFUL), pair 0 of the batch", "outside_1e-4": float((err > 1e-4 * np.maximum(1, np.abs(ref))).mean()),
+                             "max_abs_err": float(err.max()), "bit_identical": float((flows4[0] == ref).mean())})
+            leg["parity"] = par4
+            del flows4
         for c in cs:
             c.close()
         del bufs
+    c0.close()
     out["farneback_4k"] = leg
     return out
 

@@ -58,6 +58,13 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                      Also selected by the environment variable OFXCV_FARNEBACK_WINDOW=direct.
  *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
  *                                    Window sizes other than the reference's 3 always use direct sums.
+ *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x
+ *                                    (taps cast to float before they are normalised), 4 = 4.x (normalised in double, one cast):
+ *                                    two taps of the 9- and 19-tap kernels differ by one ulp;
+ *   "farneback.resize_generation" 0|1|2   cv::resize(INTER_LINEAR) rewrites itself to INTER_AREA when the level is exactly half the
+ *                                    frame in both directions; the 2x2 mean it then takes differs from the bilinear form only in the
+ *                                    association of three float additions: 0 (default) ((a+b)+(c+d))/4 = bilinear = the 4.x SIMD path,
+ *                                    1 (((a+b)+c)+d)/4 = the scalar loop (2.4.x, builds without SIMD), 2 ((a+c)+(b+d))/4 = the 3.x SSE2 path;
  *   "lut.four"                  0|1  gray LUT with four pixels per lane where the images are aligned for it (default 1);
  *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);

@@ -175,20 +175,30 @@ class Context:
                    C.c_double(poly_sigma), C.c_int(flags))
         return flow
 
-    def calc_optical_flow_farneback_batch(self, prevs, nxts, flows=None, pyr_scale=0.5, levels=3, winsize=3, iterations=15,
-                                          poly_n=5, poly_sigma=1.1, flags=0):
-        """n independent frame pairs of one size in one call (ofxcv_calc_optical_flow_farneback_batch): lists of HxW uint8
-        CUDA tensors -> list of HxWx2 float32 flows.  Pairs may share images."""
+    @staticmethod
+    def _check_batch(prevs, nxts, flows):
+        """the argument checks both batched entry points share: equal list lengths (ctypes would zero-fill a short array), dtype,
+        device, shape and contiguity of every image and flow field"""
         import torch
         n = len(prevs)
         assert n == len(nxts) and n >= 1
         h, w = prevs[0].shape
         if flows is None:
             flows = [torch.empty((h, w, 2), dtype=torch.float32, device=prevs[0].device) for _ in range(n)]
+        assert len(flows) == n
         for p, q, f in zip(prevs, nxts, flows):
             assert p.is_cuda and q.is_cuda and p.dtype == torch.uint8 and q.dtype == torch.uint8 and p.shape == (h, w) and q.shape == (h, w)
             assert p.stride(1) == 1 and q.stride(1) == 1
-            assert f.shape == (h, w, 2) and f.dtype == torch.float32 and f.stride(2) == 1 and f.stride(1) == 2
+            assert f.is_cuda and f.shape == (h, w, 2) and f.dtype == torch.float32 and f.stride(2) == 1 and f.stride(1) == 2
+        return flows
+
+    def calc_optical_flow_farneback_batch(self, prevs, nxts, flows=None, pyr_scale=0.5, levels=3, winsize=3, iterations=15,
+                                          poly_n=5, poly_sigma=1.1, flags=0):
+        """n independent frame pairs of one size in one call (ofxcv_calc_optical_flow_farneback_batch): lists of HxW uint8
+        CUDA tensors -> list of HxWx2 float32 flows.  Pairs may share images."""
+        flows = self._check_batch(prevs, nxts, flows)
+        n = len(prevs)
+        h, w = prevs[0].shape
         vp = (C.c_void_p * n)
         sz = (C.c_size_t * n)
         self._call(lib().ofxcv_calc_optical_flow_farneback_batch, C.c_int(n),
@@ -204,10 +214,10 @@ class Context:
         """the batched call with F7 fused in (ofxcv_calc_optical_flow_farneback_batch_rgba): pair i also writes flow / render scale
         into the mapped channels of the HxWx4 float32 image dsts[i] (None: no image for that pair)"""
         import torch
+        flows = self._check_batch(prevs, nxts, flows)
         n = len(prevs)
         h, w = prevs[0].shape
-        if flows is None:
-            flows = [torch.empty((h, w, 2), dtype=torch.float32, device=prevs[0].device) for _ in range(n)]
+        assert len(dsts) == n and len(chan_u_masks) == n and len(chan_v_masks) == n
         for d in dsts:
             assert d is None or (d.is_cuda and d.dtype == torch.float32 and d.shape[0] == h and d.shape[1] == w and d.shape[2] == 4 and d.stride(2) == 1 and d.stride(1) == 4)
         vp, sz, pd, un = (C.c_void_p * n), (C.c_size_t * n), (C.c_ssize_t * n), (C.c_uint * n)

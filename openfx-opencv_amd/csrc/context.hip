@@ -227,6 +227,16 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "farneback.gaussian_kernel_generation")) {
+        if (value != 3 && value != 4) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.gaussian_kernel_generation: 3 (OpenCV 2.4 / 3.x) or 4 (4.x)");
+        ctx->fb_gauss_generation = value;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.resize_generation")) {
+        if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.resize_generation: 0, 1 or 2");
+        ctx->fb_resize_generation = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "host.register")) {
         ctx->host_register = value < 0 ? 0 : (value > 2 ? 1 : value);
         return OFXCV_OK;
@@ -331,6 +341,8 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return OFXCV_ERR_INVALID;
     if (!std::strcmp(name, "farneback.opencv_rounding")) *value = ctx->fb_opencv_rounding;
     else if (!std::strcmp(name, "farneback.fold_carries")) *value = ctx->fb_fold_carries;
+    else if (!std::strcmp(name, "farneback.gaussian_kernel_generation")) *value = ctx->fb_gauss_generation;
+    else if (!std::strcmp(name, "farneback.resize_generation")) *value = ctx->fb_resize_generation;
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;

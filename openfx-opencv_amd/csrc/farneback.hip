@@ -64,8 +64,11 @@ struct PolyCoef {
 
 // ------------------------------------------------------------------ host-side coefficient prep
 
-// smooth.cpp getGaussianKernel(n, sigma, CV_32F)
-void make_gauss_taps(int n, double sigma, GaussTaps &t) {
+// smooth.cpp getGaussianKernel(n, sigma, CV_32F).  generation 3 (default): OpenCV 2.4 / 3.x -- the taps are cast to float, summed
+// (in double) over the float values, then float(tap * 1/sum).  generation 4: OpenCV 4.x (getGaussianKernelBitExact) -- taps and
+// their sum stay double, one cast at the end; two taps of the 9- and 19-tap kernels differ by one ulp.  Option
+// "farneback.gaussian_kernel_generation"; the oracle's counterpart is orc_set_gaussian_kernel_generation.
+void make_gauss_taps(int n, double sigma, GaussTaps &t, int generation = 3) {
     static const float small_tab[4][7] = {{1.f},
                                           {0.25f, 0.5f, 0.25f},
                                           {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f},
@@ -75,6 +78,21 @@ void make_gauss_taps(int n, double sigma, GaussTaps &t) {
     double scale2X = -0.5 / (sigmaX * sigmaX);
     double sum = 0;
     t.ksize = n;
+    if (generation >= 4) {
+        if (fixed) {
+            for (int i = 0; i < n; i++) t.k[i] = fixed[i];
+            return;
+        }
+        double v[kMaxGaussTaps];
+        for (int i = 0; i < n; i++) {
+            double x = i - (n - 1) * 0.5;
+            v[i] = std::exp(scale2X * x * x);
+            sum += v[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < n; i++) t.k[i] = (float)(v[i] * sum);
+        return;
+    }
     for (int i = 0; i < n; i++) {
         double x = i - (n - 1) * 0.5;
         double v = fixed ? (double)fixed[i] : std::exp(scale2X * x * x);
@@ -172,6 +190,21 @@ __device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, f
     a1 = f;
 }
 
+// The last step of resize(INTER_LINEAR): the four filtered samples an output sample lies between.  `area` != 0 only when the
+// level is EXACTLY half the frame in both directions: cv::resize then rewrites INTER_LINEAR to INTER_AREA ("INTER_AREA (fast)
+// also is equal to INTER_LINEAR", imgwarp.cpp / resize.cpp) and resizeAreaFast_ sums the 2x2 block and multiplies by 0.25f --
+// the same value up to the association of the three float additions:
+//   0  (t00*.5 + t01*.5)*.5 + (t10*.5 + t11*.5)*.5 = ((t00+t01) + (t10+t11)) / 4   bilinear = the 4.x universal-intrinsics row pairs
+//   1  ((t00 + t01) + t10) + t11                                                   the scalar loop (2.4.x; builds without SIMD)
+//   2  (t00 + t10) + (t01 + t11)                                                   ResizeAreaFastVec_SIMD_32f of 3.x (SSE2: rows first)
+// Option "farneback.resize_generation"; the oracle's counterpart is orc_set_resize_generation.
+__device__ __forceinline__ float resize_combine(float t00, float t01, float t10, float t11, float ax0, float ax1, float b0, float b1, int area) {
+    if (area == 1) return (((t00 + t01) + t10) + t11) * 0.25f;
+    if (area == 2) return ((t00 + t10) + (t01 + t11)) * 0.25f;
+    const float r0 = t00 * ax0 + t01 * ax1, r1 = t10 * ax0 + t11 * ax1;
+    return r0 * b0 + r1 * b1;
+}
+
 // Workgroup -> tile mapping.  The dispatcher is observed to place workgroup b on XCD b % 8 and every XCD has its own
 // L2, so with the plain mapping two neighbouring tiles -- which share halo rows/columns and the cache lines of the
 // R1 samples -- never share an L2.  This bijective remap hands every XCD a contiguous row-major run of tiles
@@ -241,7 +274,7 @@ __device__ __forceinline__ float col_filter(const float *__restrict__ T1, int nc
 }
 
 __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__restrict__ T1, int W, int H, int lw, int lh,
-                                                               int ntap, GaussTaps gk, float *__restrict__ I) {
+                                                               int ntap, GaussTaps gk, float *__restrict__ I, int area) {
     int dx = blockIdx.x * blockDim.x + threadIdx.x;
     int dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= lw || dy >= lh) return;
@@ -256,16 +289,13 @@ __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__re
         lerp_coef(dy, H, lh, sy, b0, b1);
         int sy1 = min(sy + 1, H - 1);
         float t00 = col_filter(T1, ncol, dx * 2, sy, H, gk), t10 = col_filter(T1, ncol, dx * 2, sy1, H, gk);
-        float r0, r1;
         if (sx + 1 < W) {
             float t01 = col_filter(T1, ncol, dx * 2 + 1, sy, H, gk), t11 = col_filter(T1, ncol, dx * 2 + 1, sy1, H, gk);
-            r0 = t00 * ax0 + t01 * ax1;
-            r1 = t10 * ax0 + t11 * ax1;
+            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
         } else {
-            r0 = t00 * 1.f;
-            r1 = t10 * 1.f;
+            const float r0 = t00 * 1.f, r1 = t10 * 1.f;
+            out = r0 * b0 + r1 * b1;
         }
-        out = r0 * b0 + r1 * b1;
     }
     I[(size_t)dy * lw + dx] = out;
 }
@@ -281,7 +311,7 @@ struct PyrTile {
 };
 
 __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int H, int lw, int lh, int ntap,
-                                                        GaussTaps gk, PyrTile t, float *__restrict__ I, size_t I_stride) {
+                                                        GaussTaps gk, PyrTile t, float *__restrict__ I, size_t I_stride, int area) {
     extern __shared__ unsigned char pyr_lds[];
     const int ksize = gk.ksize, r = ksize >> 1;
     const int ncolh = t.ow * ntap;                 // row-filtered columns kept per source row
@@ -359,16 +389,14 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
         } else {
             const int sx = s_xs[tx], sy = s_ys[ty], sy1 = min(sy + 1, H - 1);
             const float ax0 = s_xa[2 * tx], ax1 = s_xa[2 * tx + 1], b0 = s_yb[2 * ty], b1 = s_yb[2 * ty + 1];
-            float t00 = colf(2 * tx, sy), t10 = colf(2 * tx, sy1), r0, r1;
+            float t00 = colf(2 * tx, sy), t10 = colf(2 * tx, sy1);
             if (sx + 1 < W) {
                 float t01 = colf(2 * tx + 1, sy), t11 = colf(2 * tx + 1, sy1);
-                r0 = t00 * ax0 + t01 * ax1;
-                r1 = t10 * ax0 + t11 * ax1;
+                out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
             } else {
-                r0 = t00 * 1.f;
-                r1 = t10 * 1.f;
+                const float r0 = t00 * 1.f, r1 = t10 * 1.f;
+                out = r0 * b0 + r1 * b1;
             }
-            out = r0 * b0 + r1 * b1;
         }
         I[(size_t)dy * lw + dx] = out;
     }
@@ -379,7 +407,7 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
 // Same operations in the same order as the generic kernels.
 __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, int H, int lw, int lh,
                                                           int ntap, float k0, float k1, double scale_x, double scale_y,
-                                                          float *__restrict__ I, size_t I_stride) {
+                                                          float *__restrict__ I, size_t I_stride, int area) {
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     const uint8_t *__restrict__ img = imgs.p[tbz];
@@ -405,17 +433,15 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, in
         out = colf(sy, sx);
     } else {
         const int sy1 = min(sy + 1, H - 1);
-        float t00 = colf(sy, sx), t10 = colf(sy1, sx), r0, r1;
+        float t00 = colf(sy, sx), t10 = colf(sy1, sx);
         if (sx + 1 < W) {
             const int sx1 = min(sx + 1, W - 1);
             float t01 = colf(sy, sx1), t11 = colf(sy1, sx1);
-            r0 = t00 * ax0 + t01 * ax1;
-            r1 = t10 * ax0 + t11 * ax1;
+            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
         } else {
-            r0 = t00 * 1.f;
-            r1 = t10 * 1.f;
+            const float r0 = t00 * 1.f, r1 = t10 * 1.f;
+            out = r0 * b0 + r1 * b1;
         }
-        out = r0 * b0 + r1 * b1;
     }
     I[(size_t)dy * lw + dx] = out;
 }
@@ -428,7 +454,7 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, in
 // would cross the image edge take the byte path with reflected columns.  Arithmetic and order as in the byte kernel.
 template <int NTAP>
 __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, int H, int lw, int lh,
-                                                           float k0, float k1, float *__restrict__ I, size_t I_stride) {
+                                                           float k0, float k1, float *__restrict__ I, size_t I_stride, int area) {
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     const uint8_t *__restrict__ img = imgs.p[tbz];
@@ -483,10 +509,7 @@ __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, i
         float *out = I + (size_t)dy * lw + (c0 >> 1);
         float v[2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const float r0 = t0[2 * q] * 0.5f + t0[2 * q + 1] * 0.5f, r1 = t1[2 * q] * 0.5f + t1[2 * q + 1] * 0.5f;
-            v[q] = r0 * 0.5f + r1 * 0.5f;
-        }
+        for (int q = 0; q < 2; q++) v[q] = resize_combine(t0[2 * q], t0[2 * q + 1], t1[2 * q], t1[2 * q + 1], 0.5f, 0.5f, 0.5f, 0.5f, area);
         if ((lw & 1) == 0 && (((uintptr_t)I) & 7) == 0) {
             *(float2 *)out = make_float2(v[0], v[1]);
         } else {
@@ -2577,22 +2600,23 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
                      float *d_T1, float *d_I, size_t I_stride) {
     if (ksize > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksize, kMaxGaussTaps);
     GaussTaps gk;
-    make_gauss_taps(ksize, sigma, gk);
+    make_gauss_taps(ksize, sigma, gk, ctx->fb_gauss_generation);
     int ntap = (lw == W && lh == H) ? 1 : 2;
+    const int area = (W == 2 * lw && H == 2 * lh) ? ctx->fb_resize_generation : 0;  // cv::resize's exact-2x rewrite (resize_combine)
     const bool no_fused = ctx->fb_unfused_pyr;
     bool aligned = true;
     for (int i = 0; i < nimg; i++) aligned = aligned && ((uintptr_t)imgs.p[i] & 3) == 0 && (imgs.step[i] & 3) == 0;
     const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && aligned && (I_stride & 3) == 0;
     if (dword_ok && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
         dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4), nimg), block(64, 4);
-        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride);
-        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride);
+        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, 0);
+        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3v_kernel");
         return OFXCV_OK;
     }
     if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
         hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4), nimg), dim3(64, 4), 0, s, imgs, W, H, lw, lh, ntap,
-                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride);
+                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3_kernel");
         return OFXCV_OK;
     }
@@ -2613,7 +2637,7 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
                        (size_t)t.rh * t.cw;
     if (!no_fused && lds <= 60 * 1024 && lw >= 2 && lh >= 2) {
         hipLaunchKernelGGL(pyr_fused_kernel, dim3(ofxcv_div_up(lw, t.ow), ofxcv_div_up(lh, t.oh), nimg), dim3(256), lds, s, imgs, W, H, lw, lh, ntap,
-                           gk, t, d_I, I_stride);
+                           gk, t, d_I, I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_kernel");
         return OFXCV_OK;
     }
@@ -2622,7 +2646,7 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
         hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, imgs.p[i], imgs.step[i], W, H, lw, ntap, gk, d_T1);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
         hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_T1, W, H,
-                           lw, lh, ntap, gk, d_I + (size_t)i * I_stride);
+                           lw, lh, ntap, gk, d_I + (size_t)i * I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_vblur_resize_kernel");
     }
     return OFXCV_OK;

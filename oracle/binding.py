@@ -132,6 +132,11 @@ def set_gaussian_kernel_generation(generation):
     lib().orc_set_gaussian_kernel_generation(C.c_int(generation))
 
 
+def set_resize_generation(generation):
+    """association of cv::resize's exact-2x INTER_AREA rewrite: 0 (default) bilinear = 4.x SIMD, 1 scalar loop, 2 3.x SSE2"""
+    lib().orc_set_resize_generation(C.c_int(generation))
+
+
 def calc_optical_flow_farneback(prev, nxt, pyr_scale=0.5, levels=3, winsize=3, iterations=15, poly_n=5,
                                 poly_sigma=1.1, flags=0, blur_mode=BLUR_FAITHFUL, initial_flow=None):
     prev = np.ascontiguousarray(prev, np.uint8)

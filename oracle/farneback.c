@@ -170,10 +170,35 @@ static void resize_coeffs(int ssize, int dsize, int *ofs, float *a0, float *a1)
     }
 }
 
+/* imgwarp.cpp / resize.cpp cv::resize: "in case of scale_x && scale_y is equal to 2 INTER_AREA (fast) also is equal to
+ * INTER_LINEAR" -- an INTER_LINEAR request whose scale is exactly 2 in both directions is served by resizeAreaFast_: the sum of
+ * the 2x2 block times 0.25f.  Same value as the bilinear form up to the association of the three float additions:
+ *   0 (default)  bilinear: (a*.5 + b*.5)*.5 + (c*.5 + d*.5)*.5 = ((a+b) + (c+d))/4 -- also what the 4.x universal-intrinsics
+ *                path of ResizeAreaFastVec_SIMD_32f computes (row pairs first)
+ *   1            ((a + b) + c) + d   the scalar loop of resizeAreaFast_Invoker (2.4.x, builds without SIMD)
+ *   2            (a + c) + (b + d)   ResizeAreaFastVec_SIMD_32f of 3.x (SSE2: the two rows are added first)
+ * (a b / c d = the block, row-major).  Restated from memory of the upstream sources: "parity unpinned" like the rest. */
+static int g_resize_generation = 0;
+void orc_set_resize_generation(int generation) { g_resize_generation = generation < 0 || generation > 2 ? 0 : generation; }
+int orc_get_resize_generation(void) { return g_resize_generation; }
+
 void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh)
 {
     if (sw == dw && sh == dh) { /* resize(): dsize == ssize -> copyTo */
         memcpy(dst, src, sizeof(float) * (size_t)sw * sh * cn);
+        return;
+    }
+    if (g_resize_generation && sw == 2 * dw && sh == 2 * dh) {
+        for (int dy = 0; dy < dh; dy++) {
+            const float *S0 = src + (size_t)(2 * dy) * sw * cn, *S1 = S0 + (size_t)sw * cn;
+            float *D = dst + (size_t)dy * dw * cn;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    float a = S0[2 * dx * cn + c], b = S0[(2 * dx + 1) * cn + c], cc = S1[2 * dx * cn + c], d = S1[(2 * dx + 1) * cn + c];
+                    float sum = g_resize_generation == 1 ? ((a + b) + cc) + d : (a + cc) + (b + d);
+                    D[dx * cn + c] = sum * 0.25f;
+                }
+        }
         return;
     }
     int *xo = (int *)malloc(sizeof(int) * dw), *yo = (int *)malloc(sizeof(int) * dh);

@@ -54,7 +54,11 @@ int orc_get_gaussian_kernel_generation(void);
 /* GaussianBlur(src,dst,Size(ksize,ksize),sigma,sigma), CV_32F, BORDER_REFLECT_101 */
 void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize, double sigma);
 
-/* resize(src,dst,Size(dw,dh),INTER_LINEAR) for CV_32FC(cn), interleaved */
+/* resize(src,dst,Size(dw,dh),INTER_LINEAR) for CV_32FC(cn), interleaved.  cv::resize serves an exact 2x reduction with
+ * INTER_AREA's 2x2 block mean; orc_set_resize_generation picks the association of its three additions: 0 (default)
+ * ((a+b)+(c+d))/4 = the bilinear form = 4.x SIMD, 1 (((a+b)+c)+d)/4 scalar loop, 2 ((a+c)+(b+d))/4 3.x SSE2 */
+void orc_set_resize_generation(int generation);
+int orc_get_resize_generation(void);
 void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);
 
 /* FarnebackPrepareGaussian: g/xg/xxg hold 2n+1 entries each (index k+n), ig = {ig11,ig03,ig33,ig55} */

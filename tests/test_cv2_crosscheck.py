@@ -45,11 +45,49 @@ def _golden(name):
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
 
 
-def test_oracle_farneback_vs_cv2(oracle):
-    """The oracle restates the 2.4 / 3.x sources; 4.x normalises its Gaussian taps in double (orc_set_gaussian_kernel_generation).
-    Both variants are diffed and the exact counts printed: the variant of the cv2 at hand must agree at every sample."""
+def test_oracle_farneback_stages_vs_cv2(oracle):
+    """Stage by stage, so that the day a cv2 exists the log says WHICH stage and WHICH variant of the two generation switches
+    (getGaussianKernel 2.4 / 3.x vs 4.x; the association of cv::resize's exact-2x INTER_AREA rewrite) agrees with it:
+    getGaussianKernel, GaussianBlur on a float image, resize at 2x, 4x and a non-integer factor.  (FarnebackPolyExp and
+    FarnebackUpdateFlow_Blur are internal to cv2; past the pyramid image the next observable stage is the whole call, below.)
+    Exact counts are printed; the variant that matches the cv2 at hand must match at EVERY sample."""
     cv2 = pytest.importorskip("cv2", reason="cv2 absent: oracle vs OpenCV comparison not possible on this box")
-    major = int(cv2.__version__.split(".")[0])
+    from openfx_opencv_amd import synth
+    a, _ = synth.flow_pair(640, 480)
+    ga = oracle.to_byte_grayscale(a)
+    f = ga.astype(np.float32)
+    report = {}
+    try:
+        for gauss in (3, 4):
+            oracle.set_gaussian_kernel_generation(gauss)
+            for n, sigma in ((3, 0.5), (9, 1.5), (19, 3.5)):
+                ref = cv2.getGaussianKernel(n, sigma, cv2.CV_32F).ravel()
+                report[("getGaussianKernel", gauss, n)] = int((ref != oracle.gaussian_kernel(n, sigma)).sum())
+                ref = cv2.GaussianBlur(f, (n, n), sigma, sigmaY=sigma, borderType=cv2.BORDER_REFLECT_101)
+                report[("GaussianBlur", gauss, n)] = int((ref != oracle.gaussian_blur(f, n, sigma)).sum())
+        oracle.set_gaussian_kernel_generation(3)
+        blurred = oracle.gaussian_blur(f, 3, 0.5)
+        for rz in (0, 1, 2):
+            oracle.set_resize_generation(rz)
+            for dw, dh in ((320, 240), (160, 120), (213, 160)):
+                ref = cv2.resize(blurred, (dw, dh), interpolation=cv2.INTER_LINEAR)
+                report[("resize", rz, dw)] = int((ref != oracle.resize_linear(blurred, dw, dh)).sum())
+    finally:
+        oracle.set_gaussian_kernel_generation(3)
+        oracle.set_resize_generation(0)
+    for k in sorted(report, key=str):
+        print("cv2 %s stage diff %s: %d differing samples" % (cv2.__version__, k, report[k]))
+    assert min(report[("getGaussianKernel", g, 9)] + report[("getGaussianKernel", g, 19)] for g in (3, 4)) == 0, report
+    assert min(report[("GaussianBlur", g, 9)] + report[("GaussianBlur", g, 19)] for g in (3, 4)) == 0, report
+    assert min(report[("resize", rz, 320)] for rz in (0, 1, 2)) == 0, report
+    assert report[("resize", 0, 160)] == 0 and report[("resize", 0, 213)] == 0, report
+
+
+def test_oracle_farneback_vs_cv2(oracle):
+    """The oracle restates the 2.4 / 3.x sources; 4.x normalises its Gaussian taps in double (orc_set_gaussian_kernel_generation), and
+    cv::resize's exact-2x rewrite exists in three associations (orc_set_resize_generation).  All six variants are diffed and the
+    exact counts printed: at least one variant must agree with the cv2 at hand at every sample (and the log says which)."""
+    cv2 = pytest.importorskip("cv2", reason="cv2 absent: oracle vs OpenCV comparison not possible on this box")
     g = _golden("farneback_96x72.npz")
     from openfx_opencv_amd import synth
     a, b = synth.flow_pair(640, 480)
@@ -58,19 +96,22 @@ def test_oracle_farneback_vs_cv2(oracle):
     results = {}
     try:
         for gen in (3, 4):
-            oracle.set_gaussian_kernel_generation(gen)
-            for name, x, y in cases:
-                ref = cv2.calcOpticalFlowFarneback(x, y, None, 0.5, 3, 3, 15, 5, 1.1, 0)
-                mine = oracle.calc_optical_flow_farneback(x, y, blur_mode=oracle.BLUR_FAITHFUL)
-                err = np.abs(ref - mine)
-                bad = int((err > 1e-4 * np.maximum(1, np.abs(ref))).sum())
-                results[(gen, name)] = bad
-                print("cv2 %s calcOpticalFlowFarneback vs oracle FAITHFUL (getGaussianKernel generation %d), %s: max |err| %.3g, outside 1e-4: %d of %d, "
-                      "bit-identical %d" % (cv2.__version__, gen, name, err.max(), bad, err.size, int((ref == mine).sum())))
+            for rz in (0, 1, 2):
+                oracle.set_gaussian_kernel_generation(gen)
+                oracle.set_resize_generation(rz)
+                for name, x, y in cases:
+                    ref = cv2.calcOpticalFlowFarneback(x, y, None, 0.5, 3, 3, 15, 5, 1.1, 0)
+                    mine = oracle.calc_optical_flow_farneback(x, y, blur_mode=oracle.BLUR_FAITHFUL)
+                    err = np.abs(ref - mine)
+                    bad = int((err > 1e-4 * np.maximum(1, np.abs(ref))).sum())
+                    results[(gen, rz, name)] = bad
+                    print("cv2 %s calcOpticalFlowFarneback vs oracle FAITHFUL (getGaussianKernel generation %d, resize generation %d), %s: "
+                          "max |err| %.3g, outside 1e-4: %d of %d, bit-identical %d"
+                          % (cv2.__version__, gen, rz, name, err.max(), bad, err.size, int((ref == mine).sum())))
     finally:
         oracle.set_gaussian_kernel_generation(3)
-    gen = 4 if major >= 4 else 3
-    assert all(results[(gen, name)] == 0 for name, _, _ in cases), results
+        oracle.set_resize_generation(0)
+    assert any(all(results[(gen, rz, name)] == 0 for name, _, _ in cases) for gen in (3, 4) for rz in (0, 1, 2)), results
 
 
 def test_oracle_inpaint_vs_cv2(oracle):
@@ -81,7 +122,7 @@ def test_oracle_inpaint_vs_cv2(oracle):
     diff = (ref != i["out"]).any(axis=2)
     print("cv2 %s inpaint(TELEA) vs oracle on the 96x72 golden frame: %d differing pixels of %d hole pixels, max level diff %d"
           % (cv2.__version__, diff.sum(), (i["mask"] > 0).sum(), np.abs(ref.astype(int) - i["out"].astype(int)).max()))
-    assert diff.mean() < 0.01
+    assert diff.sum() == 0   # all-integer output: exact
 
 
 def test_oracle_mean_shift_vs_cv2(oracle):
@@ -90,4 +131,4 @@ def test_oracle_mean_shift_vs_cv2(oracle):
     ref = cv2.pyrMeanShiftFiltering(m["img"], 10, 20, maxLevel=2)
     diff = (ref != m["out"]).any(axis=2)
     print("cv2 %s pyrMeanShiftFiltering(10, 20, 2) vs oracle on the 96x72 golden image: %d differing pixels" % (cv2.__version__, diff.sum()))
-    assert diff.mean() < 0.01
+    assert diff.sum() == 0   # all-integer path: exact

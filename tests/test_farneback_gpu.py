@@ -54,6 +54,53 @@ def test_pyr_image_bit_exact(oracle, ofxcv, direct_ctx, w, h):
         assert np.array_equal(ref, got), "level %d max diff %g" % (k, np.abs(ref - got).max())
 
 
+@pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (98, 74), (640, 480)])
+def test_pyr_image_generations_bit_exact(oracle, ofxcv, w, h):
+    """The two places where OpenCV generations are known (from their published sources) to differ in the last bit, as matching
+    switches of the oracle and of the library: getGaussianKernel (2.4 / 3.x vs 4.x) and the association of cv::resize's exact-2x
+    INTER_AREA rewrite.  Every combination: pyramid images bit-identical, the whole call within 1e-4 at every sample."""
+    ga, gb = _gray_pair(oracle, w, h)
+    levels = ofxcv.farneback_num_levels(w, h, 0.5, 3)
+    ctx = ofxcv.Context(0)
+    seen = {}
+    try:
+        for gauss in (3, 4):
+            for rz in (0, 1, 2):
+                oracle.set_gaussian_kernel_generation(gauss)
+                oracle.set_resize_generation(rz)
+                ctx.set_option("farneback.gaussian_kernel_generation", gauss)
+                ctx.set_option("farneback.resize_generation", rz)
+                assert ctx.get_option("farneback.gaussian_kernel_generation") == gauss and ctx.get_option("farneback.resize_generation") == rz
+                for fused in (1, 0):  # the dword / LDS-fused kernels and the two-pass fall-back
+                    ctx.set_option("farneback.fused_pyramid", fused)
+                    for k in range(levels + 1):
+                        lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
+                        ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
+                        got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+                        assert np.array_equal(ref, got), "gauss %d resize %d fused %d level %d: max diff %g" % (gauss, rz, fused, k, np.abs(ref - got).max())
+                        seen[(gauss, rz, k)] = ref
+                ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+                got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+                err = np.abs(ref - got)
+                assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "gauss %d resize %d: max err %g" % (gauss, rz, err.max())
+    finally:
+        oracle.set_gaussian_kernel_generation(3)
+        oracle.set_resize_generation(0)
+        ctx.close()
+    if levels >= 1 and w % 2 == 0 and h % 2 == 0:
+        # the associations differ by at most one ulp and only at level 1 (exactly half the frame)
+        a, b, c = (seen[(3, rz, 1)] for rz in (0, 1, 2))
+        for x in (b, c):
+            assert np.abs(a.view(np.int32) - x.view(np.int32)).max() <= 1
+        assert np.array_equal(seen[(3, 0, 0)], seen[(3, 2, 0)])
+    with pytest.raises(ofxcv.OfxcvError):
+        c2 = ofxcv.Context(0)
+        try:
+            c2.set_option("farneback.resize_generation", 3)
+        finally:
+            c2.close()
+
+
 @pytest.mark.parametrize("w,h,n,sigma", [(64, 48, 5, 1.1), (160, 120, 5, 1.1), (97, 61, 7, 1.5), (33, 40, 5, 1.1)])
 def test_polyexp_bit_exact(oracle, ofxcv, direct_ctx, w, h, n, sigma):
     rng = np.random.default_rng(7)
@@ -423,6 +470,39 @@ def test_farneback_4k_both_modes(oracle, ofxcv, direct_ctx, strict_ctx):
     frac, mx = _check_flow(oracle, got, ga, gb)
     print("3840x2160 default path vs FAITHFUL: outside-1e-4 fraction %.3g, max err %.3g" % (frac, mx))
     _strict_vs_faithful(oracle, strict_ctx, w, h)
+
+
+def test_farneback_4k_batch_of_eight(oracle, ofxcv):
+    """BASELINE configs[4] in its batched form: 8 DIFFERENT 3840x2160 pairs (one GPU's share of the 64) through
+    ofxcv_calc_optical_flow_farneback_batch_rgba equal 8 single calls bit for bit (flows and RGBA images), and pair 0 is within
+    1e-4 of the FAITHFUL oracle at every sample.  Twice: the second call replays the captured graph."""
+    w, h, n = 3840, 2160, 8
+    prs = _pairs(oracle, w, h, range(1234, 1234 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    import torch
+    single = ofxcv.Context(0)
+    singles = []
+    for z in range(n):
+        f = single.calc_optical_flow_farneback(da[z], db[z])
+        singles.append(f.cpu().numpy())
+    batch = ofxcv.Context(0)
+    for _ in range(2):
+        dsts = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
+        flows = batch.calc_optical_flow_farneback_batch_rgba(da, db, None, dsts, [0b0101] * n, [0b1010] * n)
+        for z in range(n):
+            got = flows[z].cpu().numpy()
+            assert np.array_equal(got, singles[z]), "pair %d: max diff %g" % (z, np.abs(got - singles[z]).max())
+            img = dsts[z].cpu().numpy()
+            assert np.array_equal(img[..., 0], got[..., 0]) and np.array_equal(img[..., 1], got[..., 1])
+            assert np.array_equal(img[..., 2], got[..., 0]) and np.array_equal(img[..., 3], got[..., 1])
+        del dsts
+    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL)
+    err = np.abs(singles[0] - ref)
+    bad = err > REL_TOL * np.maximum(1, np.abs(ref))
+    print("3840x2160 batch of 8, pair 0 vs FAITHFUL oracle: max err %.3g, outside 1e-4: %d, bit-identical %.6f" % (err.max(), bad.sum(), (ref == singles[0]).mean()))
+    assert not bad.any()
+    single.close()
+    batch.close()
 
 
 # ---- OPTFLOW_FARNEBACK_GAUSSIAN / OPTFLOW_USE_INITIAL_FLOW (SURVEY.md 8(f) rank 3) ----

@@ -240,3 +240,30 @@ def test_gaussian_flag_and_initial_flow_recover_the_translation(oracle):
     assert err(warm) < 0.5 < err(cold)
     with pytest.raises(ValueError):
         oracle.calc_optical_flow_farneback(ga, gb, flags=1)
+
+
+def test_resize_generations_are_the_same_2x2_mean_up_to_association(oracle):
+    """cv::resize(INTER_LINEAR) at an exact 2x reduction is INTER_AREA's block mean; the three known associations of its float
+    additions agree with the exact mean to one ulp, generation 0 IS the bilinear form, and other scales are untouched."""
+    rng = np.random.default_rng(5)
+    src = rng.uniform(0, 255, size=(48, 64)).astype(np.float32)
+    exact = (src.astype(np.float64).reshape(24, 2, 32, 2).sum(axis=(1, 3)) * 0.25)
+    outs = []
+    try:
+        for gen in (0, 1, 2):
+            oracle.set_resize_generation(gen)
+            out = oracle.resize_linear(src, 32, 24)
+            assert np.abs(out - exact).max() <= np.spacing(np.float32(255.0))
+            outs.append(out)
+            other = oracle.resize_linear(src, 16, 12)   # 4x: stays bilinear in every generation
+            if gen == 0:
+                other0 = other
+            assert np.array_equal(other, other0)
+    finally:
+        oracle.set_resize_generation(0)
+    a, b, c = src[0::2, 0::2], src[0::2, 1::2], src[1::2, 0::2]
+    d = src[1::2, 1::2]
+    assert np.array_equal(outs[0], ((a + b) + (c + d)) * np.float32(0.25))
+    assert np.array_equal(outs[1], (((a + b) + c) + d) * np.float32(0.25))
+    assert np.array_equal(outs[2], ((a + c) + (b + d)) * np.float32(0.25))
+    assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])
