@@ -183,7 +183,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
     if (ctx->coarse) (void)hipStreamDestroy(ctx->coarse);
     if (ctx->ev_coarse) (void)hipEventDestroy(ctx->ev_coarse);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_persist_buf, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_persist_buf, &ctx->fb_col_flag, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
@@ -263,7 +263,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     {
         struct { const char *n; int *v; } knobs[] = {{"farneback.halo_geom", &ctx->fb_halo_geom}, {"farneback.halo_min8", &ctx->fb_halo_min8},
-                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"lut.four", &ctx->lut4}, {"farneback.halo_min5", &ctx->fb_halo_min5}, {"farneback.persist", &ctx->fb_persist}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
+                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"lut.four", &ctx->lut4}, {"farneback.halo_min5", &ctx->fb_halo_min5}, {"farneback.persist", &ctx->fb_persist}, {"farneback.col", &ctx->fb_col}, {"farneback.col_min", &ctx->fb_col_min}, {"farneback.col_geom", &ctx->fb_col_geom}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 *k.v = value;
@@ -348,6 +348,18 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else if (!std::strcmp(name, "farneback.persist")) *value = ctx->fb_persist;
+    else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;
+    else if (!std::strcmp(name, "farneback.col_aborts")) {
+        // the sticky abort word of the column-owning kernel (waits for the context's streams first)
+        *value = 0;
+        if (ctx->fb_col_flag.ptr) {
+            unsigned flag = 0;
+            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK ||
+                hipMemcpy(&flag, ctx->fb_col_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
+                return OFXCV_ERR_HIP;
+            *value = (int)flag;
+        }
+    }
     else if (!std::strcmp(name, "farneback.persist_aborts")) {
         // the sticky abort flag of the persistent small-level launches (waits for the context's streams first)
         *value = 0;

@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -2423,6 +2424,385 @@ __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_ker
                                                      KIND == kHaloLast ? &rg : nullptr);
 }
 
+// ------------------------------------------------------------------ OpenCV-order window: column-owning workgroups, TWO steps per launch
+//
+// The column prefix of iteration k+1 needs every row of M_{k+1} above it, so two iterations cannot be fused inside a strip.
+// A workgroup that owns a tile column over the FULL height can: it walks the column top to bottom in rounds of S rows
+// (NW wavefronts of RW-1 or RW rows each), runs step 1 (the solve of iteration k + the new matrices M') on the rows
+// [A, A+S) of a round and step 2 (the solve of iteration k+1 from the row differences of M' + the matrices M'') one row
+// behind it, on [A-1, A+S-1): d'_t = M'[t+1] - M'[t-2] needs the row below.  M' never leaves the registers (three boundary
+// rows per wavefront through LDS); the running column sums of both steps are handed from wavefront to wavefront (and from round
+// to round) through one LDS slot each, so the launch needs no strip sums at all and the next launch starts its chain at
+// vsum(-1) = 3 * row 0 again.  Per two iterations a pixel costs M-in 20 + 2 x (R0 20 + R1 gather 20) + M-out 20 = 120 B instead of 160, and
+// the second reads of R0 / R1 hit the L2.  64 lanes -> 62 valid columns after step 1 -> 60 after step 2 (6.7 % redundancy).
+//
+// Steps of a level: first M (zero / prolongated / given flow), iterations - 1 x iterate, last (flow + F7 out) -- paired up
+// (first, iterate) (iterate, iterate) ... (iterate, last); an odd count ends with (last, -).  The field between launches is the
+// difference field of the overlapped-strip form (rows t = 0 .. h-2 of d, the edge rows 0, h-3, h-1 of M beside it), so both
+// forms can follow each other inside a level.
+//
+// No barrier after the prologue: every hand-off is point to point (LDS data + a monotonic LDS counter, release / acquire at
+// workgroup scope on the LDS address space only -- loads and stores to memory stay in flight across it):
+//   p[s]    the running f64 column sum of step s: a token chain over (round, wavefront); wavefront u of round r adds the sum
+//           of its own row differences and passes it on (seq[s] = tickets served)
+//   b[s][u] the last three rows of M' / M'' of wavefront u, for the differences across the boundary to the wavefront below
+//           (wavefront 0 takes those of the last wavefront of the round before); wr / rd count writes and reads of a slot
+// A wavefront only ever waits for wavefronts of its own workgroup (all resident) along an acyclic order (smaller ticket, or
+// the reader of its own slot one round earlier), so the waits terminate; they are bounded all the same (`spin`), and a wait
+// that runs out raises the sticky `abort` word (ofxcv_ctx_get_option "farneback.col_aborts").
+constexpr int kColW = 60;   // columns a workgroup stores (lanes 2..61)
+enum { kColNone = -1 };
+
+struct ColArgs {
+    const float *Ein;   // [3][5][pitch] edge rows (0, max(h-3, 0), h-1) of the M the launch reads as differences
+    float *Eout;        // the same for the M it writes
+    size_t pair_vsum;   // doubles between the scratch of consecutive pairs (the edge rows are floats inside it)
+    int S, rounds;      // step-1 rows per round (NW * (RW-1) .. NW * RW), rounds (S * rounds >= h + 1)
+    unsigned *abort;
+    unsigned spin;
+    __device__ __forceinline__ void select_pair(int z) {
+        if (Ein) Ein += (size_t)z * pair_vsum * 2;
+        if (Eout) Eout += (size_t)z * pair_vsum * 2;
+    }
+};
+
+template <int NW>
+struct ColLds {
+    float b[2][NW][3][5][64];
+    double p[2][5][64];
+    int seq[2];
+    int wr[2][NW], rd[2][NW];
+};
+
+__device__ __forceinline__ int lds_flag_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_flag_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// wait until *p >= target (every lane polls the same word: a broadcast read); then LDS reads may follow
+__device__ __forceinline__ void lds_wait(const int *p, int target, const ColArgs &ca) {
+    if (lds_flag_ld(p) < target) {
+        unsigned n = 0;
+        do {
+            __builtin_amdgcn_s_sleep(1);
+            if (++n > ca.spin) {
+                atomicOr(ca.abort, 1u);
+                break;
+            }
+        } while (lds_flag_ld(p) < target);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// LDS data written before, then the counter (one lane)
+__device__ __forceinline__ void lds_post(int *p, int v, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) lds_flag_st(p, v);
+}
+
+// F7 (VectorGenerator.cpp:494-519) on a flow still in registers
+__device__ __forceinline__ void f7_store(const RgbaTab &rg, int z, int xr, int y, float fx, float fy) {
+    const float u = (float)(fx / rg.rsx), v = (float)(fy / rg.rsy);
+    const unsigned mu = rg.mu[z], mv = rg.mv[z];
+    float *d = (float *)((char *)rg.p[z] + (ptrdiff_t)y * rg.step[z]) + (size_t)xr * 4;
+    if (((mu | mv) & 15u) == 15u && (((uintptr_t)d) & 15) == 0) {
+        *(float4 *)d = make_float4((mv & 1u) ? v : u, (mv & 2u) ? v : u, (mv & 4u) ? v : u, (mv & 8u) ? v : u);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c += 2) {  // channel pairs: one 8-byte store where both are mapped
+            const unsigned m2 = ((mu | mv) >> c) & 3u;
+            if (m2 == 3u && (((uintptr_t)d) & 7) == 0) *(float2 *)(d + c) = make_float2((mv >> c) & 1u ? v : u, (mv >> (c + 1)) & 1u ? v : u);
+            else {
+                if (m2 & 1u) d[c] = (mv >> c) & 1u ? v : u;
+                if (m2 & 2u) d[c + 1] = (mv >> (c + 1)) & 1u ? v : u;
+            }
+        }
+    }
+}
+
+template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false>
+__global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                              const float *__restrict__ Din, float *__restrict__ Dout, FlowTab fin, FlowTab fout, Prolong pr,
+                                                              int w, int h, int pitch, double scale, ColArgs ca, size_t pair_stride, RgbaTab rg) {
+    constexpr bool SOLVE1 = K1 <= kHaloIter, LAST1 = K1 == kHaloLast, TWO = K2 != kColNone, LAST2 = K2 == kHaloLast;
+    constexpr bool OUT = !LAST1 && !LAST2;  // the launch leaves a field
+    static_assert(K2 == kColNone || K2 == kHaloIter || K2 == kHaloLast, "step 2 iterates or ends the level");
+    static_assert(LAST1 != TWO, "nothing follows the last step; every other step has a partner");
+    static_assert(RW >= 6 && DEPTH >= 1 && DEPTH <= RW, "the three boundary rows and three more");
+    __shared__ ColLds<NW> lds;
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    R0 += (size_t)tbz * pair_stride;
+    R1 += (size_t)tbz * pair_stride;
+    if (SOLVE1) Din += (size_t)tbz * pair_stride;
+    if (OUT) Dout += (size_t)tbz * pair_stride;
+    ca.select_pair(tbz);
+    const float *__restrict__ flow = fin.p[tbz];   // coarse / given: the flow the level starts from
+    const size_t flow_step = fin.step[tbz];
+    float *__restrict__ oflow = fout.p[tbz];       // last: the level's flow
+    const size_t oflow_step = fout.step[tbz];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < 2) lds.seq[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * NW) {
+        (&lds.wr[0][0])[threadIdx.x] = 0;
+        (&lds.rd[0][0])[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int x0 = tbx * kColW;
+    const int xr = x0 - 2 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
+    const bool own = lane >= 2 && lane < 2 + kColW && xr < w;
+    const size_t plane = (size_t)pitch * h;
+    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
+    const Buf bD = make_buf(Din, SOLVE1 ? 5 * plane * sizeof(float) : 0), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
+              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bDo = make_buf(Dout, OUT ? 5 * plane * sizeof(float) : 0);
+    const Buf bEi = make_buf(ca.Ein, SOLVE1 ? (size_t)5 * pitch * sizeof(float) : 0), bEo = make_buf(ca.Eout, OUT ? (size_t)5 * pitch * sizeof(float) : 0);
+    // lanes beyond the image edge repeat the border column: after step 1 they must hold the BORDER pixel's flow (their own box
+    // window is not the border pixel's), so that their M' is the replicated border column step 2 sums over
+    const bool fix_l = x0 == 0, fix_r = x0 - 2 + 63 >= w;
+    const int lane_r = __builtin_amdgcn_readfirstlane(min(w + 1 - x0, 63));
+    const int off = wave * RW;
+    const int pw = wave == 0 ? NW - 1 : wave - 1;  // whose boundary rows this wavefront takes
+
+    struct Px {
+        Taps tp;
+        float r0v[5];
+    };
+    auto solve = [&](const double (&D)[5], float &fx, float &fy) __attribute__((always_inline)) {
+        double acc[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
+        const double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
+        const double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        fx = (float)((g11_ * h2_ - g12_ * h1_) * idet);
+        fy = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    };
+    auto flow_out = [&](int y, float fx, float fy) __attribute__((always_inline)) {
+        if (!own || y < 0 || y >= h) return;
+        if (oflow) *(float2 *)((char *)oflow + (size_t)y * oflow_step + (size_t)xr * 8) = make_float2(fx, fy);
+        if (rg.p[tbz]) f7_store(rg, tbz, xr, y, fx, fy);
+    };
+    // hand the running column sum of step s on: P = the sum just above this wavefront's first row of the step
+    auto chain = [&](int s, int ticket, const double (&sum)[5], double (&P)[5]) __attribute__((always_inline)) {
+        if (ticket != 0) {
+            lds_wait(&lds.seq[s], ticket, ca);
+#pragma unroll
+            for (int c = 0; c < 5; c++) P[c] = lds.p[s][c][lane];
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) lds.p[s][c][lane] = P[c] + sum[c];
+        lds_post(&lds.seq[s], ticket + 1, lane);
+    };
+    // the last three rows of this wavefront's step-s field for the wavefront below
+    auto put_boundary = [&](int s, int r, const float (&m)[RW][5]) __attribute__((always_inline)) {
+        lds_wait(&lds.rd[s][wave], r, ca);  // the reader is done with what round r-1 left here
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) lds.b[s][wave][k][c][lane] = m[RW - 3 + k][c];
+        lds_post(&lds.wr[s][wave], r + 1, lane);
+    };
+    auto get_boundary = [&](int s, int r, float (&pv)[3][5]) __attribute__((always_inline)) {
+        lds_wait(&lds.wr[s][pw], wave == 0 ? r : r + 1, ca);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) pv[k][c] = lds.b[s][pw][k][c][lane];
+        lds_post(&lds.rd[s][pw], wave == 0 ? r : r + 1, lane);
+    };
+
+    // This wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]) of a round.  Rows below the image count as zero.
+    // NO per-row branches anywhere in a round: rows outside the image are computed at the clamped row index and masked out
+    // where they would count (they only occur in the first and the last round), so a round is straight-line code.
+    float d[RW][5];
+    auto load_d = [&](int r) __attribute__((always_inline)) {
+        const int a = r * ca.S + off;
+#pragma unroll
+        for (int j = 0; j < RW; j++) {
+            const int y = a + j;
+            const unsigned so = (unsigned)min(y, h - 1) * rb;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                const float v = buf_ld(bD, vx, so + c * pb);
+                d[j][c] = y < h ? v : 0.f;
+            }
+        }
+    };
+
+    for (int r = 0; r < ca.rounds; r++) {
+        const int a = r * ca.S + off;  // first step-1 row of this wavefront in this round
+        const int ticket = r * NW + wave;
+        const bool topw = ticket == 0;  // owns row 0
+        float fx1[RW], fy1[RW];
+        // ---------------------------------------------------------------- step 1: flows of the rows a .. a+RW-1
+        if (SOLVE1) {
+            load_d(r);
+            double sum[5], P[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double t = 0.;
+#pragma unroll
+                for (int j = 0; j < RW; j++) t += (double)d[j][c];
+                sum[c] = t;
+                P[c] = 0.;
+            }
+            if (topw) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) P[c] = (double)(buf_ld(bEi, vx, c * rb) * 3.f);  // vsum(-1) = srow0 * (m + 2)
+            }
+            chain(0, ticket, sum, P);
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) P[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
+                solve(P, fx1[j], fy1[j]);
+                if (LAST1) flow_out(a + j, fx1[j], fy1[j]);
+            }
+            if (LAST1) continue;
+            if (fix_l || fix_r) {
+#pragma unroll
+                for (int j = 0; j < RW; j++) {
+                    if (fix_l) {
+                        const float ex = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx1[j]), 2));
+                        const float ey = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy1[j]), 2));
+                        if (lane < 2) {
+                            fx1[j] = ex;
+                            fy1[j] = ey;
+                        }
+                    }
+                    if (fix_r) {
+                        const float ex = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx1[j]), lane_r));
+                        const float ey = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy1[j]), lane_r));
+                        if (xr >= w) {
+                            fx1[j] = ex;
+                            fy1[j] = ey;
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RW; j++) {
+                fx1[j] = fy1[j] = 0.f;
+                if (K1 == kHaloZero) continue;
+                const int y = min(a + j, h - 1);
+                if (K1 == kHaloCoarse) {
+                    prolong_flow(flow, flow_step, pr, x, y, fx1[j], fy1[j]);
+                } else {
+                    const float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
+                    fx1[j] = f.x;
+                    fy1[j] = f.y;
+                }
+            }
+        }
+        // ---------------------------------------------------------------- M' of the rows a .. a+RW-1, bottom row first: the boundary
+        // rows for the wavefront below leave early, and this wavefront's own first rows are finished when the rows from above
+        // have long arrived.  Rows below the image repeat the last row (same column sums -> same flow -> the same M'): exactly
+        // what d'_{h-1} = M'[h-1] - M'[h-3] wants of the row below the image.
+        float m1[RW][5];
+        float d2[RW][5];  // d'_t, t = a - 1 + i: rows a+i and a+i-3 of M'
+        {
+            Px q[RW];
+#pragma unroll
+            for (int p = 0; p < RW + DEPTH; p++) {  // DEPTH rows of gathers in flight ahead of the row that is finished
+                if (p < RW) {
+                    const int j = RW - 1 - p, y = min(a + j, h - 1);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) q[j].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+                    q[j].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx1[j], fy1[j]);
+                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (p >= DEPTH) {
+                    const int j = RW - 1 - (p - DEPTH), y = min(a + j, h - 1);
+                    const M5 mm = update_matrices_finish(q[j].r0v, q[j].tp, x, y, w, h, fx1[j], fy1[j]);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        m1[j][c] = mm.v[c];
+                        if (j + 3 < RW) d2[j + 3][c] = m1[j + 3][c] - mm.v[c];
+                    }
+                    if (j == RW - 3) put_boundary(0, r, m1);  // rows RW-3 .. RW-1 are complete
+                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        {
+            float pv[3][5];
+            if (!topw) get_boundary(0, r, pv);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) d2[i][c] = m1[i][c] - (topw ? m1[0][c] : pv[i][c]);  // rows above row 0 are row 0
+        }
+        // ---------------------------------------------------------------- step 2: flows of the rows a-1 .. a+RW-2 from the column sums of M'
+        float fx2[RW], fy2[RW];
+        {
+            double sum[5], P[5];
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+                const int t = a - 1 + i;
+                const bool valid = t >= 0 && t < h;  // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 5; c++) d2[i][c] = valid ? d2[i][c] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                double t = 0.;
+#pragma unroll
+                for (int i = 0; i < RW; i++) t += (double)d2[i][c];
+                sum[c] = t;
+                P[c] = topw ? (double)(m1[0][c] * 3.f) : 0.;
+            }
+            chain(1, ticket, sum, P);
+#pragma unroll
+            for (int i = 0; i < RW; i++) {
+#pragma unroll
+                for (int c = 0; c < 5; c++) P[c] += (double)d2[i][c];
+                solve(P, fx2[i], fy2[i]);
+                if (LAST2) flow_out(a - 1 + i, fx2[i], fy2[i]);
+            }
+        }
+        if (LAST2) continue;
+        // ---------------------------------------------------------------- M'' of those rows, bottom row first; its row differences leave as they complete
+        float m2[RW][5];
+        auto st_d3 = [&](float dv, int i, int c) __attribute__((always_inline)) {  // d''_t, t = a - 2 + i: rows a-1+i and a-4+i of M''
+            const int t = a - 2 + i;
+            // lanes that own no column and rows outside the image store to an out-of-range offset: dropped by the bounds check, no branch
+            buf_st(bDo, dv, (own && t >= 0 && t < h) ? vx : 0xC0000000u, (unsigned)clampi(t, 0, h - 1) * rb + c * pb);
+        };
+        {
+            Px q[RW];
+#pragma unroll
+            for (int p = 0; p < RW + DEPTH; p++) {
+                if (p < RW) {
+                    const int i = RW - 1 - p, y = clampi(a - 1 + i, 0, h - 1);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) q[i].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+                    q[i].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx2[i], fy2[i]);
+                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (p >= DEPTH) {
+                    const int i = RW - 1 - (p - DEPTH), y = clampi(a - 1 + i, 0, h - 1);
+                    const M5 mm = update_matrices_finish(q[i].r0v, q[i].tp, x, y, w, h, fx2[i], fy2[i]);
+#pragma unroll
+                    for (int c = 0; c < 5; c++) {
+                        m2[i][c] = (i == 0 && topw) ? m2[1][c] : mm.v[c];  // the row above row 0 is row 0
+                        if (i + 3 < RW) st_d3(m2[i + 3][c] - m2[i][c], i + 3, c);
+                    }
+                    if (i == RW - 3) put_boundary(1, r, m2);
+                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (topw && own) {  // row 0 of M'' for the next launch's vsum(-1)
+#pragma unroll
+            for (int c = 0; c < 5; c++) buf_st(bEo, m2[1][c], vx, c * rb);
+        }
+        {
+            float pv[3][5];
+            if (!topw) get_boundary(1, r, pv);
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) st_d3(m2[i][c] - (topw ? m2[0][c] : pv[i][c]), i, c);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ OpenCV-order window: ALL iterations of a small level in ONE launch
 //
 // A launch of a small pyramid level is bound by its own start-up and tear-down and by two dependent memory round trips from
@@ -3124,6 +3504,60 @@ int launch_persistent_level(ofxcv_ctx *ctx, hipStream_t s, const float *R0, cons
     return OFXCV_OK;
 }
 
+// Column-owning form (iterate_col_kernel): two steps of a level per launch, every pair of the group in the grid's z.
+struct ColGeom {
+    int nw, rw, S, rounds, tiles_x;
+};
+ColGeom col_geom(const ofxcv_ctx *ctx, int w, int h, bool iter_pair) {
+    ColGeom g;
+    // experimental geometries exist for the (iterate, iterate) launch only; the field between launches does not depend on it
+    (void)iter_pair;
+    g.nw = 8;
+    g.rw = 8;
+    g.tiles_x = ofxcv_div_up(w, kColW);
+    g.S = g.nw * g.rw;
+    g.rounds = ofxcv_div_up(h + 2, g.S);  // step 2 runs one row behind step 1, the differences it stores another row behind, and d_{h-1} needs the row below the image
+    return g;
+}
+// a level takes the column-owning form when its launches have enough workgroups (one per tile column and pair) to occupy the chip
+bool col_level(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
+    if (!halo || !ctx->fb_col || h < 64) return false;
+    return (long)ofxcv_div_up(w, kColW) * n >= ctx->fb_col_min;
+}
+int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Din, float *Dout, const FlowTab &fin, const FlowTab &fout,
+                     const Prolong &pr, int w, int h, int k1, int k2, const HaloScratch &hs, int slot, const Layout &L, const RgbaTab *rgba = nullptr) {
+    RgbaTab rg = {};
+    if (rgba) rg = *rgba;
+    const bool iter_pair = k1 == kHaloIter && k2 == kHaloIter;
+    const ColGeom g = col_geom(ctx, w, h, iter_pair);
+    ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, (unsigned *)ctx->fb_col_flag.ptr, (unsigned)ctx->fb_col_spin};
+    dim3 grid(g.tiles_x, 1, L.n);
+    const int pitch = plane_pitch(w);
+    const double scale = 1. / 9.;
+#define OFXCV_LAUNCH_COL_K(K1, K2, RW, NW, DEPTH) \
+    hipLaunchKernelGGL((iterate_col_kernel<K1, K2, RW, NW, DEPTH, true>), grid, dim3(64 * NW), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
+#define OFXCV_LAUNCH_COL(RW, NW, DEPTH)                                                                     \
+    do {                                                                                                \
+        if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, RW, NW, DEPTH);       \
+        else if (k1 == kHaloIter && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, RW, NW, DEPTH);  \
+        else if (k1 == kHaloLast && k2 == kColNone) OFXCV_LAUNCH_COL_K(kHaloLast, kColNone, RW, NW, DEPTH);    \
+        else if (k1 == kHaloZero && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloIter, RW, NW, DEPTH);  \
+        else if (k1 == kHaloZero && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloLast, RW, NW, DEPTH);  \
+        else if (k1 == kHaloCoarse && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloIter, RW, NW, DEPTH); \
+        else if (k1 == kHaloCoarse && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloLast, RW, NW, DEPTH); \
+        else if (k1 == kHaloGiven && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloIter, RW, NW, DEPTH); \
+        else if (k1 == kHaloGiven && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloLast, RW, NW, DEPTH); \
+        else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2); \
+    } while (0)
+    if (iter_pair && ctx->fb_col_geom == 1) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 8, 8, 2, false>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
+    else if (iter_pair && ctx->fb_col_geom == 2) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 8, 8, 2);
+    else OFXCV_LAUNCH_COL(8, 8, 1);
+#undef OFXCV_LAUNCH_COL
+#undef OFXCV_LAUNCH_COL_K
+    OFXCV_LAUNCH_CHECK(ctx, "iterate_col_kernel");
+    return OFXCV_OK;
+}
+
 // two fused iterations M -> M'' (winsize 3, direct-window mode), pair by pair
 int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
                           bool level0, const Layout &L) {
@@ -3306,9 +3740,12 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const int pitch = plane_pitch(w);
         const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)pitch * h;
         const int fit = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
-        const int per_group = ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
-        const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
+        // the column-owning form streams every pair of the call through one launch (a workgroup per tile column and pair; the
+        // fields are read once per two iterations, so the Infinity-Cache grouping below has nothing to keep on the die)
+        const bool col = col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries >= 4);
+        const int per_group = col ? n : ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
+        const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         for (int z0 = 0; z0 < n; z0 += per_group) {
             const int gn = std::min(per_group, n - z0);
@@ -3332,6 +3769,57 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             HaloScratch hs = {};
             if (halo) hs = halo_scratch(width, height, G);
             const Prolong no_pr = {0, 0, 1.0, 1.0, 1.0};
+            if (col) {
+                int fk = kHaloZero;
+                FlowTab ftab = no_flow;
+                Prolong prc = no_pr;
+                if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
+                    // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
+                    fk = kHaloGiven;
+                    ftab = sub_tab(out, z0, gn);
+                    if (k > 0) {
+                        double scale = 1;
+                        for (int i = 0; i < k; i++) scale *= pyr_scale;
+                        ftab = sub_tab(coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8), z0, gn);
+                        for (int z = 0; z < gn; z++) {
+                            hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z0 + z], out.step[z0 + z], width, height,
+                                               ftab.p[z], w, h, scale);
+                            OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
+                        }
+                    }
+                } else if (have_prev) {
+                    fk = kHaloCoarse;
+                    ftab = sub_tab(prev_all, z0, gn);
+                    prc = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
+                }
+                // steps of the level: first M, iterations - 1 x iterate, last -- two per launch
+                const int nsteps = iterations + 1;
+                int cur = 0;
+                for (int st = 0; st < nsteps; st += 2) {
+                    const int k1 = st == 0 ? fk : (st == nsteps - 1 ? kHaloLast : kHaloIter);
+                    const int k2 = st + 1 >= nsteps ? kColNone : (st + 1 == nsteps - 1 ? kHaloLast : kHaloIter);
+                    RgbaTab rg = {};
+                    const bool sink = rgba && k == 0 && (k1 == kHaloLast || k2 == kHaloLast);  // F7 rides on the launch that produces the final flow
+                    if (sink) {
+                        rg.rsx = rgba->rsx;
+                        rg.rsy = rgba->rsy;
+                        for (int z = 0; z < gn; z++) {
+                            rg.p[z] = rgba->p[z0 + z];
+                            rg.step[z] = rgba->step[z0 + z];
+                            rg.mu[z] = rgba->mu[z0 + z];
+                            rg.mv[z] = rgba->mv[z0 + z];
+                            rgba_fused[z0 + z] = true;
+                        }
+                    }
+                    const bool prof = profile && k == 0 && k1 == kHaloIter && k2 == kHaloIter;  // the dominant kernel's launches
+                    if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+                    rc = launch_col_steps(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ftab, out_tab, prc, w, h, k1, k2, hs, cur, G, sink ? &rg : nullptr);
+                    if (rc) return rc;
+                    if (prof && (rc = ofxcv_prof_mark(ctx, s))) return rc;
+                    cur ^= 1;
+                }
+                continue;
+            }
             const bool persist = persist_level(ctx, L, w, h, gn, iterations, halo) && !profile;
             if (persist && (pwords + persist_words(ctx, w, h, gn, iterations)) * sizeof(unsigned) <= ctx->fb_persist_buf.bytes) {
                 unsigned *words = (unsigned *)ctx->fb_persist_buf.ptr + pwords;
@@ -3524,6 +4012,11 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
     if (need_vsum) {
         rc = ofxcv_reserve(ctx, ctx->fb_vsum, L.vsum_bytes());
         if (rc) return rc;
+    }
+    if (ctx->fb_col && !ctx->fb_col_flag.ptr) {  // the sticky abort word of iterate_col_kernel
+        rc = ofxcv_reserve(ctx, ctx->fb_col_flag, 256);
+        if (rc) return rc;
+        OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, 256, s));
     }
     if (ctx->fb_persist && ctx->fb_opencv_rounding == 1 && winsize == 3 && ctx->fb_fold_carries >= 4 && !(flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
         // tickets and counters of the persistent small-level launches: the same walk over levels and launch groups as enqueue_farneback
