@@ -94,10 +94,11 @@ struct ofxcv_ctx {
     int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
-    int fb_col_min = 200;        // option "farneback.col_min": workgroups (tile columns x pairs of the call) from which a level takes that form
+    int fb_col_min = 250;        // option "farneback.col_min": workgroups (tile columns x pairs of the call) from which a level takes that form
     int fb_col_geom = 0;         // option "farneback.col_geom": 0 sixteen wavefronts of 8 or 9 rows per round, 1 twelve of 9 or 10
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
-    DevBuf fb_col_flag;          // the sticky abort word of iterate_col_kernel
+    int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
+    DevBuf fb_col_flag;          // the sticky abort word of iterate_col_kernel (+ the trace area)
     int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
     int fb_persist_spin = 1 << 22;  // option "farneback.persist_spin": polls of one wait before the launch gives up (abort flag)
     DevBuf fb_persist_buf;       // [0] abort flag; tickets and step / strip counters of the persistent launches of a call

@@ -263,7 +263,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     }
     {
         struct { const char *n; int *v; } knobs[] = {{"farneback.halo_geom", &ctx->fb_halo_geom}, {"farneback.halo_min8", &ctx->fb_halo_min8},
-                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"lut.four", &ctx->lut4}, {"farneback.halo_min5", &ctx->fb_halo_min5}, {"farneback.persist", &ctx->fb_persist}, {"farneback.col", &ctx->fb_col}, {"farneback.col_min", &ctx->fb_col_min}, {"farneback.col_geom", &ctx->fb_col_geom}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
+                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"lut.four", &ctx->lut4}, {"farneback.halo_min5", &ctx->fb_halo_min5}, {"farneback.persist", &ctx->fb_persist}, {"farneback.col", &ctx->fb_col}, {"farneback.col_min", &ctx->fb_col_min}, {"farneback.col_geom", &ctx->fb_col_geom}, {"farneback.col_trace", &ctx->fb_col_trace}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 *k.v = value;

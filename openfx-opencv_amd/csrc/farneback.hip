@@ -2451,6 +2451,7 @@ __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_ker
 // the reader of its own slot one round earlier), so the waits terminate; they are bounded all the same (`spin`), and a wait
 // that runs out raises the sticky `abort` word (ofxcv_ctx_get_option "farneback.col_aborts").
 constexpr int kColW = 60;   // columns a workgroup stores (lanes 2..61)
+constexpr size_t kColFlagBytes = 256 + 64 * 16 * 16 * 8;  // abort word + trace area (64 rounds x 16 wavefronts x 16 stamps)
 enum { kColNone = -1 };
 
 struct ColArgs {
@@ -2460,6 +2461,7 @@ struct ColArgs {
     int S, rounds;      // step-1 rows per round (NW * (RW-1) .. NW * RW), rounds (S * rounds >= h + 1)
     unsigned *abort;
     unsigned spin;
+    unsigned long long *trace;  // [rounds][NW][16] shader-clock stamps of one workgroup (TRACE instantiation), or null
     __device__ __forceinline__ void select_pair(int z) {
         if (Ein) Ein += (size_t)z * pair_vsum * 2;
         if (Eout) Eout += (size_t)z * pair_vsum * 2;
@@ -2516,7 +2518,7 @@ __device__ __forceinline__ void f7_store(const RgbaTab &rg, int z, int xr, int y
     }
 }
 
-template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false>
+template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false, bool TRACE = false>
 __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ Din, float *__restrict__ Dout, FlowTab fin, FlowTab fout, Prolong pr,
                                                               int w, int h, int pitch, double scale, ColArgs ca, size_t pair_stride, RgbaTab rg) {
@@ -2524,7 +2526,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     constexpr bool OUT = !LAST1 && !LAST2;  // the launch leaves a field
     static_assert(K2 == kColNone || K2 == kHaloIter || K2 == kHaloLast, "step 2 iterates or ends the level");
     static_assert(LAST1 != TWO, "nothing follows the last step; every other step has a partner");
-    static_assert(RW >= 6 && DEPTH >= 1 && DEPTH <= RW, "the three boundary rows and three more");
+    static_assert(RW >= 3 && DEPTH >= 1 && DEPTH <= RW, "the three boundary rows");
     __shared__ ColLds<NW> lds;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
@@ -2554,10 +2556,14 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     const Buf bEi = make_buf(ca.Ein, SOLVE1 ? (size_t)5 * pitch * sizeof(float) : 0), bEo = make_buf(ca.Eout, OUT ? (size_t)5 * pitch * sizeof(float) : 0);
     // lanes beyond the image edge repeat the border column: after step 1 they must hold the BORDER pixel's flow (their own box
     // window is not the border pixel's), so that their M' is the replicated border column step 2 sums over
-    const bool fix_l = x0 == 0, fix_r = x0 - 2 + 63 >= w;
     const int lane_r = __builtin_amdgcn_readfirstlane(min(w + 1 - x0, 63));
     const int off = wave * RW;
     const int pw = wave == 0 ? NW - 1 : wave - 1;  // whose boundary rows this wavefront takes
+    // TRACE (option farneback.col_trace): one workgroup writes the shader clock at the phase boundaries of every round
+    const bool tracing = TRACE && ca.trace && tbx == 3 && tbz == 0;
+    auto stamp = [&](int r, int k) __attribute__((always_inline)) {
+        if (TRACE && tracing && lane == 0) ca.trace[(size_t)(r * NW + wave) * 16 + k] = __builtin_amdgcn_s_memtime();
+    };
 
     struct Px {
         Taps tp;
@@ -2578,32 +2584,46 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         if (rg.p[tbz]) f7_store(rg, tbz, xr, y, fx, fy);
     };
     // hand the running column sum of step s on: P = the sum just above this wavefront's first row of the step
+    // the lane index, recomputed where a hand-off needs it: an LDS address kept in a register across a round is what the
+    // register allocator spills first, and a reload from scratch inside the token's critical section costs every wavefront
+    // behind this one a memory round trip (measured: two reloads = 5 000 cycles per link, the whole launch chain-bound)
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     auto chain = [&](int s, int ticket, const double (&sum)[5], double (&P)[5]) __attribute__((always_inline)) {
+        // the sums must be complete BEFORE the token is taken: whatever they wait for (the rows of the difference field still in
+        // flight, the last rows of M') would otherwise be waited for while every wavefront behind this one waits for the token
+        asm volatile("" ::"v"(sum[0]), "v"(sum[1]), "v"(sum[2]), "v"(sum[3]), "v"(sum[4]) : "memory");
+        if (ticket != 0) lds_wait(&lds.seq[s], ticket, ca);
+        const int l = fresh_lane();
         if (ticket != 0) {
-            lds_wait(&lds.seq[s], ticket, ca);
 #pragma unroll
-            for (int c = 0; c < 5; c++) P[c] = lds.p[s][c][lane];
+            for (int c = 0; c < 5; c++) P[c] = lds.p[s][c][l];
         }
 #pragma unroll
-        for (int c = 0; c < 5; c++) lds.p[s][c][lane] = P[c] + sum[c];
-        lds_post(&lds.seq[s], ticket + 1, lane);
+        for (int c = 0; c < 5; c++) lds.p[s][c][l] = P[c] + sum[c];
+        lds_post(&lds.seq[s], ticket + 1, l);
     };
     // the last three rows of this wavefront's step-s field for the wavefront below
     auto put_boundary = [&](int s, int r, const float (&m)[RW][5]) __attribute__((always_inline)) {
         lds_wait(&lds.rd[s][wave], r, ca);  // the reader is done with what round r-1 left here
+        const int l = fresh_lane();
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) lds.b[s][wave][k][c][lane] = m[RW - 3 + k][c];
-        lds_post(&lds.wr[s][wave], r + 1, lane);
+            for (int c = 0; c < 5; c++) lds.b[s][wave][k][c][l] = m[RW - 3 + k][c];
+        lds_post(&lds.wr[s][wave], r + 1, l);
     };
     auto get_boundary = [&](int s, int r, float (&pv)[3][5]) __attribute__((always_inline)) {
         lds_wait(&lds.wr[s][pw], wave == 0 ? r : r + 1, ca);
+        const int l = fresh_lane();
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) pv[k][c] = lds.b[s][pw][k][c][lane];
-        lds_post(&lds.rd[s][pw], wave == 0 ? r : r + 1, lane);
+            for (int c = 0; c < 5; c++) pv[k][c] = lds.b[s][pw][k][c][l];
+        lds_post(&lds.rd[s][pw], wave == 0 ? r : r + 1, l);
     };
 
     // This wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]) of a round.  Rows below the image count as zero.
@@ -2624,15 +2644,28 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
 
+    // lanes beyond the image edge take the border pixel's flow (see fix_l / fix_r); branch-free
+    auto border_flow = [&](float &fx, float &fy) __attribute__((always_inline)) {
+        const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), 2));
+        const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), 2));
+        const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
+        const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane_r));
+        fx = xr < 0 ? lx : (xr >= w ? rx : fx);
+        fy = xr < 0 ? ly : (xr >= w ? ry : fy);
+    };
     for (int r = 0; r < ca.rounds; r++) {
         const int a = r * ca.S + off;  // first step-1 row of this wavefront in this round
         const int ticket = r * NW + wave;
         const bool topw = ticket == 0;  // owns row 0
-        float fx1[RW], fy1[RW];
-        // ---------------------------------------------------------------- step 1: flows of the rows a .. a+RW-1
+        stamp(r, 0);
+        // ---------------------------------------------------------------- step 1, rows a .. a+RW-1 top to bottom: per row the column sums
+        // advance by the row's differences, the 2x2 solve gives its flow, its R0 samples and R1 taps are requested, and the row
+        // DEPTH rows earlier -- whose samples have arrived meanwhile -- becomes a row of M'.  The solve of a row (f64 arithmetic,
+        // no memory) runs while the gathers of the rows before it are in flight.
+        double P[5];
         if (SOLVE1) {
             load_d(r);
-            double sum[5], P[5];
+            double sum[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 double t = 0.;
@@ -2645,81 +2678,61 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #pragma unroll
                 for (int c = 0; c < 5; c++) P[c] = (double)(buf_ld(bEi, vx, c * rb) * 3.f);  // vsum(-1) = srow0 * (m + 2)
             }
+            stamp(r, 1);   // rows of the difference field requested
             chain(0, ticket, sum, P);
-#pragma unroll
-            for (int j = 0; j < RW; j++) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) P[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
-                solve(P, fx1[j], fy1[j]);
-                if (LAST1) flow_out(a + j, fx1[j], fy1[j]);
-            }
-            if (LAST1) continue;
-            if (fix_l || fix_r) {
-#pragma unroll
-                for (int j = 0; j < RW; j++) {
-                    if (fix_l) {
-                        const float ex = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx1[j]), 2));
-                        const float ey = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy1[j]), 2));
-                        if (lane < 2) {
-                            fx1[j] = ex;
-                            fy1[j] = ey;
-                        }
-                    }
-                    if (fix_r) {
-                        const float ex = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx1[j]), lane_r));
-                        const float ey = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy1[j]), lane_r));
-                        if (xr >= w) {
-                            fx1[j] = ex;
-                            fy1[j] = ey;
-                        }
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < RW; j++) {
-                fx1[j] = fy1[j] = 0.f;
-                if (K1 == kHaloZero) continue;
-                const int y = min(a + j, h - 1);
-                if (K1 == kHaloCoarse) {
-                    prolong_flow(flow, flow_step, pr, x, y, fx1[j], fy1[j]);
-                } else {
-                    const float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
-                    fx1[j] = f.x;
-                    fy1[j] = f.y;
-                }
-            }
+            stamp(r, 2);   // chain of step 1 passed
         }
-        // ---------------------------------------------------------------- M' of the rows a .. a+RW-1, bottom row first: the boundary
-        // rows for the wavefront below leave early, and this wavefront's own first rows are finished when the rows from above
-        // have long arrived.  Rows below the image repeat the last row (same column sums -> same flow -> the same M'): exactly
-        // what d'_{h-1} = M'[h-1] - M'[h-3] wants of the row below the image.
+        // Rows below the image repeat the last row (zero differences -> the same column sums -> the same flow -> the same M'):
+        // exactly what d'_{h-1} = M'[h-1] - M'[h-3] wants of the row below the image.
         float m1[RW][5];
         float d2[RW][5];  // d'_t, t = a - 1 + i: rows a+i and a+i-3 of M'
+        float r0k[RW][5];  // the R0 samples of this wavefront's step-1 rows: step 2 visits the same rows one later (its first row is the row above)
         {
             Px q[RW];
+            float fx1[RW], fy1[RW];
 #pragma unroll
-            for (int p = 0; p < RW + DEPTH; p++) {  // DEPTH rows of gathers in flight ahead of the row that is finished
+            for (int p = 0; p < RW + DEPTH; p++) {
                 if (p < RW) {
-                    const int j = RW - 1 - p, y = min(a + j, h - 1);
+                    const int j = p, y = min(a + j, h - 1);
+                    if (SOLVE1) {
 #pragma unroll
-                    for (int c = 0; c < 5; c++) q[j].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-                    q[j].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx1[j], fy1[j]);
+                        for (int c = 0; c < 5; c++) P[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
+                        solve(P, fx1[j], fy1[j]);
+                        if (LAST1) flow_out(a + j, fx1[j], fy1[j]);
+                        else border_flow(fx1[j], fy1[j]);
+                    } else {
+                        fx1[j] = fy1[j] = 0.f;
+                        if (K1 == kHaloCoarse) {
+                            prolong_flow(flow, flow_step, pr, x, y, fx1[j], fy1[j]);
+                        } else if (K1 == kHaloGiven) {
+                            const float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
+                            fx1[j] = f.x;
+                            fy1[j] = f.y;
+                        }
+                    }
+                    if (!LAST1) {
+#pragma unroll
+                        for (int c = 0; c < 5; c++) q[j].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+                        q[j].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx1[j], fy1[j]);
+                    }
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (p >= DEPTH) {
-                    const int j = RW - 1 - (p - DEPTH), y = min(a + j, h - 1);
+                if (!LAST1 && p >= DEPTH) {
+                    const int j = p - DEPTH, y = min(a + j, h - 1);
                     const M5 mm = update_matrices_finish(q[j].r0v, q[j].tp, x, y, w, h, fx1[j], fy1[j]);
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         m1[j][c] = mm.v[c];
-                        if (j + 3 < RW) d2[j + 3][c] = m1[j + 3][c] - mm.v[c];
+                        r0k[j][c] = q[j].r0v[c];
+                        if (j >= 3) d2[j][c] = mm.v[c] - m1[j - 3][c];
                     }
-                    if (j == RW - 3) put_boundary(0, r, m1);  // rows RW-3 .. RW-1 are complete
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        if (LAST1) continue;
+        stamp(r, 4);   // M' complete
+        put_boundary(0, r, m1);  // rows RW-3 .. RW-1 for the wavefront below
         {
             float pv[3][5];
             if (!topw) get_boundary(0, r, pv);
@@ -2728,10 +2741,9 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #pragma unroll
                 for (int i = 0; i < 3; i++) d2[i][c] = m1[i][c] - (topw ? m1[0][c] : pv[i][c]);  // rows above row 0 are row 0
         }
-        // ---------------------------------------------------------------- step 2: flows of the rows a-1 .. a+RW-2 from the column sums of M'
-        float fx2[RW], fy2[RW];
+        // ---------------------------------------------------------------- step 2, rows a-1 .. a+RW-2, the same way from the column sums of M'
         {
-            double sum[5], P[5];
+            double sum[5];
 #pragma unroll
             for (int i = 0; i < RW; i++) {
                 const int t = a - 1 + i;
@@ -2747,17 +2759,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                 sum[c] = t;
                 P[c] = topw ? (double)(m1[0][c] * 3.f) : 0.;
             }
+            stamp(r, 5);   // boundary rows from above arrived, differences summed
             chain(1, ticket, sum, P);
-#pragma unroll
-            for (int i = 0; i < RW; i++) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) P[c] += (double)d2[i][c];
-                solve(P, fx2[i], fy2[i]);
-                if (LAST2) flow_out(a - 1 + i, fx2[i], fy2[i]);
-            }
+            stamp(r, 6);   // chain of step 2 passed
         }
-        if (LAST2) continue;
-        // ---------------------------------------------------------------- M'' of those rows, bottom row first; its row differences leave as they complete
         float m2[RW][5];
         auto st_d3 = [&](float dv, int i, int c) __attribute__((always_inline)) {  // d''_t, t = a - 2 + i: rows a-1+i and a-4+i of M''
             const int t = a - 2 + i;
@@ -2766,28 +2771,41 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         };
         {
             Px q[RW];
+            float fx2[RW], fy2[RW];
 #pragma unroll
             for (int p = 0; p < RW + DEPTH; p++) {
                 if (p < RW) {
-                    const int i = RW - 1 - p, y = clampi(a - 1 + i, 0, h - 1);
+                    const int i = p, y = clampi(a - 1 + i, 0, h - 1);
 #pragma unroll
-                    for (int c = 0; c < 5; c++) q[i].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-                    q[i].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx2[i], fy2[i]);
+                    for (int c = 0; c < 5; c++) P[c] += (double)d2[i][c];
+                    solve(P, fx2[i], fy2[i]);
+                    if (LAST2) {
+                        flow_out(a - 1 + i, fx2[i], fy2[i]);
+                    } else {
+                        // row a-1+i: its R0 samples are step 1's of row i-1 unless the row index was clamped there or here (first / last round)
+#pragma unroll
+                        for (int c = 0; c < 5; c++) q[i].r0v[c] = i == 0 ? buf_ld(bR0, vx, (unsigned)y * rb + c * pb) : r0k[i - 1][c];
+                        q[i].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx2[i], fy2[i]);
+                    }
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (p >= DEPTH) {
-                    const int i = RW - 1 - (p - DEPTH), y = clampi(a - 1 + i, 0, h - 1);
+                if (!LAST2 && p >= DEPTH) {
+                    const int i = p - DEPTH, y = clampi(a - 1 + i, 0, h - 1);
                     const M5 mm = update_matrices_finish(q[i].r0v, q[i].tp, x, y, w, h, fx2[i], fy2[i]);
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
-                        m2[i][c] = (i == 0 && topw) ? m2[1][c] : mm.v[c];  // the row above row 0 is row 0
-                        if (i + 3 < RW) st_d3(m2[i + 3][c] - m2[i][c], i + 3, c);
+                        m2[i][c] = mm.v[c];
+                        if (i == 1 && topw) m2[0][c] = mm.v[c];  // the row above row 0 is row 0
+                        if (i >= 3) st_d3(mm.v[c] - m2[i - 3][c], i, c);
                     }
-                    if (i == RW - 3) put_boundary(1, r, m2);
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        stamp(r, 7);
+        if (LAST2) continue;
+        stamp(r, 8);   // M'' complete
+        put_boundary(1, r, m2);
         if (topw && own) {  // row 0 of M'' for the next launch's vsum(-1)
 #pragma unroll
             for (int c = 0; c < 5; c++) buf_st(bEo, m2[1][c], vx, c * rb);
@@ -2800,6 +2818,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #pragma unroll
                 for (int i = 0; i < 3; i++) st_d3(m2[i][c] - (topw ? m2[0][c] : pv[i][c]), i, c);
         }
+        stamp(r, 9);   // end of the round
     }
 }
 
@@ -3511,9 +3530,9 @@ struct ColGeom {
 ColGeom col_geom(const ofxcv_ctx *ctx, int w, int h, bool iter_pair) {
     ColGeom g;
     // experimental geometries exist for the (iterate, iterate) launch only; the field between launches does not depend on it
-    (void)iter_pair;
+    const bool tall = iter_pair && !ctx->fb_col_trace && ctx->fb_col_geom == 1;  // A/B: eight rows per wavefront and round
     g.nw = 8;
-    g.rw = 8;
+    g.rw = tall ? 8 : 4;
     g.tiles_x = ofxcv_div_up(w, kColW);
     g.S = g.nw * g.rw;
     g.rounds = ofxcv_div_up(h + 2, g.S);  // step 2 runs one row behind step 1, the differences it stores another row behind, and d_{h-1} needs the row below the image
@@ -3530,7 +3549,8 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     if (rgba) rg = *rgba;
     const bool iter_pair = k1 == kHaloIter && k2 == kHaloIter;
     const ColGeom g = col_geom(ctx, w, h, iter_pair);
-    ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, (unsigned *)ctx->fb_col_flag.ptr, (unsigned)ctx->fb_col_spin};
+    ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, (unsigned *)ctx->fb_col_flag.ptr, (unsigned)ctx->fb_col_spin,
+                  ctx->fb_col_trace ? (unsigned long long *)((char *)ctx->fb_col_flag.ptr + 256) : nullptr};
     dim3 grid(g.tiles_x, 1, L.n);
     const int pitch = plane_pitch(w);
     const double scale = 1. / 9.;
@@ -3549,9 +3569,9 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         else if (k1 == kHaloGiven && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloLast, RW, NW, DEPTH); \
         else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2); \
     } while (0)
-    if (iter_pair && ctx->fb_col_geom == 1) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 8, 8, 2, false>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
-    else if (iter_pair && ctx->fb_col_geom == 2) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 8, 8, 2);
-    else OFXCV_LAUNCH_COL(8, 8, 1);
+    if (iter_pair && ctx->fb_col_trace) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, 1, true, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
+    else if (iter_pair && ctx->fb_col_geom == 1) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 8, 8, 1);
+    else OFXCV_LAUNCH_COL(4, 8, 1);
 #undef OFXCV_LAUNCH_COL
 #undef OFXCV_LAUNCH_COL_K
     OFXCV_LAUNCH_CHECK(ctx, "iterate_col_kernel");
@@ -3586,6 +3606,17 @@ Layout one_pair_layout() { return Layout(); }
 extern "C" {
 
 int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
+
+// measurement aid (not part of the public header): the shader-clock stamps the traced workgroup of the last iterate_col_kernel
+// launch left (option "farneback.col_trace" 1); n 64-bit words
+int ofxcv_debug_col_trace(ofxcv_ctx *ctx, unsigned long long *out, int n) {
+    if (!ctx || !out || !ctx->fb_col_flag.ptr || (size_t)n * 8 + 256 > ctx->fb_col_flag.bytes) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int rc = ofxcv_ctx_quiesce(ctx);
+    if (rc) return rc;
+    OFXCV_HIP_CHECK(ctx, hipMemcpy(out, (char *)ctx->fb_col_flag.ptr + 256, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return OFXCV_OK;
+}
 
 int ofxcv_farneback_num_levels(int width, int height, double pyr_scale, int levels) {
     return num_levels(width, height, pyr_scale, levels);
@@ -4014,9 +4045,9 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         if (rc) return rc;
     }
     if (ctx->fb_col && !ctx->fb_col_flag.ptr) {  // the sticky abort word of iterate_col_kernel
-        rc = ofxcv_reserve(ctx, ctx->fb_col_flag, 256);
+        rc = ofxcv_reserve(ctx, ctx->fb_col_flag, kColFlagBytes);
         if (rc) return rc;
-        OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, 256, s));
+        OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, kColFlagBytes, s));
     }
     if (ctx->fb_persist && ctx->fb_opencv_rounding == 1 && winsize == 3 && ctx->fb_fold_carries >= 4 && !(flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
         // tickets and counters of the persistent small-level launches: the same walk over levels and launch groups as enqueue_farneback
