@@ -31,10 +31,16 @@ if ROOT not in sys.path:
 W, H = 1920, 1080
 LEVELS, ITERS, POLY_N, POLY_SIGMA, WINSIZE, PYR_SCALE = 3, 15, 5, 1.1, 3, 0.5  # VectorGenerator.cpp:804-834, :391-395
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec peak (6.29 TB/s measured float4 copy)
-VALU_ISSUE_PER_S = 1024 * 2.4e9 / 4.0  # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+# issue rate of wave64 vector instructions, measured (tools/ubench/valurate*.hip, output in profiles/r04_ubench_valu_l1.txt, 4 waves per SIMD,
+# 8 independent chains per lane): integer add / mul / dot4 / sad / bfe 5.1-5.5 clk, f32 add 5.1, f32 mul 3.0, f32 fma 3.6, f64 add / mul / fma
+# 5.6-5.8, DPP move 5.3 clk per wave-instruction per SIMD at 2.4 GHz (the guide's 2-cycle v_fma_f32 is not reached by a dependent-chain
+# stream).  The fraction below uses the integer / f64 figure; the PMC counter SQ_ACTIVE_INST_VALU (busy quad-cycles) is reported beside it.
+VALU_CLK_PER_WAVE_INSTR = 5.3
+VALU_ISSUE_PER_S = 1024 * 2.4e9 / VALU_CLK_PER_WAVE_INSTR
 # one iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
 ITER_BYTES_PER_PX = 80.0
-PMC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+COL_W = 60  # columns a workgroup of iterate_col_kernel stores (csrc/farneback.hip: kColW)
 
 
 def algorithmic_bytes_per_pair(w, h, levels=LEVELS, iters=ITERS):
@@ -132,7 +138,7 @@ def cv2_probe(ga, gb, ref_flow):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8, help="frame pairs per batched Farneback call (ofxcv_calc_optical_flow_farneback_batch_rgba); "
                     "8 = BASELINE configs[4]'s pairs per GPU")
@@ -274,17 +280,25 @@ def main():
     pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
     rates = [pairs_per_region / e for e in el]
     fold_mode = ctxs[0].get_option("farneback.fold_carries")
-    # pairs one level-0 launch carries: a level is walked in groups of pairs whose working set (80 B/px each) stays inside the
-    # Infinity Cache budget (option farneback.batch_mb), see enqueue_farneback
+    # pairs one level-0 launch of the dominant kernel carries.  Column-owning form (iterate_col_kernel, taken when tile columns x pairs of
+    # the call reach farneback.col_min workgroups): every pair of the call, TWO iterations per launch.  Otherwise the overlapped-strip
+    # form: a level is walked in groups of pairs whose working set (80 B/px each) stays inside the Infinity Cache budget
+    # (option farneback.batch_mb), one iteration per launch -- see enqueue_farneback
     pitch = ofxcv.farneback_plane_pitch(W) if hasattr(ofxcv, "farneback_plane_pitch") else (W + 63) // 64 * 64
-    ppl = max(1, min(B, (ctxs[0].get_option("farneback.batch_mb") << 20) // (80 * pitch * H)))
-    # the dominant kernel is timed on calls of as many pairs as one of its launches carries (a level-0 launch of the timed
-    # workload carries `ppl` pairs): the measurement hook runs the eager path, and a larger batch would only make the host the
-    # bottleneck between the event pairs
+    col = bool(ctxs[0].get_option("farneback.col")) and fold_mode >= 4 and -(-W // COL_W) * B >= ctxs[0].get_option("farneback.col_min")
+    ppl = B if col else max(1, min(B, (ctxs[0].get_option("farneback.batch_mb") << 20) // (80 * pitch * H)))
+    iters_per_launch = 2 if col else 1
+    # the dominant kernel is timed on calls of as many pairs as one of its launches carries in the timed workload
     kl = {k: v[:ppl] for k, v in bufs[0].items()}
     main_s, main_n = kernel_leg(ctxs[0], kl, 1)
-    carry_s, carry_n = kernel_leg(ctxs[0], kl, 2)
-    one_in_flight = one_batch_in_flight = None
+    carry_s, carry_n = (0.0, 0) if col else kernel_leg(ctxs[0], kl, 2)
+    # what the timed workload left for pair 0 (checked against the CPU oracle below) -- taken before any other leg touches the buffers
+    step(ctxs, bufs)
+    torch.cuda.synchronize()
+    strict_flow = bufs[0]["flow"][0].cpu().numpy()
+    g_a, g_b = bufs[0]["ga"][0].cpu().numpy(), bufs[0]["gb"][0].cpu().numpy()
+    col_aborts = ctxs[0].get_option("farneback.col_aborts")
+    one_in_flight = one_batch_in_flight = three_single = None
     if world == 1:
         n1 = max(10, args.steps // 2)
         e1 = timed_regions(ctxs[:1], bufs[:1], n1, 3, 3)
@@ -292,11 +306,18 @@ def main():
         one = [{k: v[:1] for k, v in bufs[0].items()}]  # a single pair per call on one stream: what one unbatched caller gets
         e1 = timed_regions(ctxs[:1], one, n1, 3, 3)
         one_in_flight = n1 / statistics.median(e1)
-    strict_flow = bufs[0]["flow"][0].cpu().numpy()
-    g_a, g_b = bufs[0]["ga"][0].cpu().numpy(), bufs[0]["gb"][0].cpu().numpy()
     for c in ctxs:
         c.close()
     del bufs
+    if world == 1:
+        # the configuration rounds 1 and 2 quoted as `value`: three single-pair calls in flight (three contexts, one pair each)
+        c3 = make_ctxs(3, direct=False)
+        b3 = make_bufs(c3, W, H, 1)
+        e3 = timed_regions(c3, b3, max(10, args.steps // 2), 5, 3)
+        three_single = max(10, args.steps // 2) * 3 / statistics.median(e3)
+        for c in c3:
+            c.close()
+        del b3
 
     # ---- the opt-in direct-window mode, same workload ----
     # (its kernels take one pair per launch: P single-pair contexts in flight, as in rounds 1 and 2)
@@ -323,10 +344,14 @@ def main():
     pc = {} if fold_mode >= 4 else pmc.get("opencv_order_fold_scan_level0" if folded else "opencv_order_carry_level0", {})
     pf = pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes_pair = ITER_BYTES_PER_PX * W * H
-    iter_bytes = iter_bytes_pair * ppl  # one launch of the dominant kernel carries `ppl` pairs of the batch
+    iter_bytes = iter_bytes_pair * ppl * iters_per_launch  # one launch of the dominant kernel: `ppl` pairs x `iters_per_launch` iterations
     achieved = iter_bytes / main_s / 1e9
+    if col:
+        pm = pmc.get("opencv_order_col_two_iterations_level0", {})
+        pc = {}
     traffic = pm.get("traffic_bytes_per_launch")
     valu = pm.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
+    valu_busy = pm.get("counters_per_launch", {}).get("SQ_ACTIVE_INST_VALU")
     line = {
         "metric": "frames/sec at %dx%d f32 (Farneback flow)" % (W, H),
         "value": value,

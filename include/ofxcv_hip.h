@@ -48,16 +48,22 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 /* context options:
  *   "farneback.opencv_rounding" 1|0|2 how the 3x3 box window of FarnebackUpdateFlow_Blur is evaluated.
  *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical
- *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel (a
- *                                      row-walking kernel per iteration + a small kernel for the carries of the column sums,
- *                                      see "farneback.fold_carries").  Reproduces the reference's
- *                                      rounding noise: every sample within 1e-4 (relative) of the CPU result.
+ *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel: levels
+ *                                      whose launches fill the chip (tile columns x pairs of the call >= "farneback.col_min")
+ *                                      by column-owning workgroups that run TWO iterations per launch (iterate_col_kernel),
+ *                                      the others by overlapped strips, one launch per iteration (iterate3h_kernel).
+ *                                      Reproduces the reference's rounding noise: every sample within 1e-4 (relative) of
+ *                                      the CPU result.
  *                                    0: direct sums (each window summed on its own in f64, two iterations fused per launch):
- *                                      ~1.8x faster, but at ill-conditioned pixels (6e-5 of the samples at 1920x1080,
+ *                                      faster for single calls, but at ill-conditioned pixels (6e-5 of the samples at 1920x1080,
  *                                      6e-4 at 3840x2160) the result leaves the 1e-4 band around the reference's.
  *                                      Also selected by the environment variable OFXCV_FARNEBACK_WINDOW=direct.
  *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
  *                                    Window sizes other than the reference's 3 always use direct sums.
+ *   "farneback.col"             0|1  the column-owning form on the levels that qualify (default 1);
+ *   "farneback.col_min"         n    workgroups (tile columns of 60 pixels x pairs of the call) from which a level takes it (250);
+ *   "farneback.batch_mb"        MiB  the other levels are walked with as many pairs per launch as keep the level's working set
+ *                                    under this (160: the Infinity Cache holds 256 MiB);
  *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x
  *                                    (taps cast to float before they are normalised), 4 = 4.x (normalised in double, one cast):
  *                                    two taps of the 9- and 19-tap kernels differ by one ulp;
@@ -73,40 +79,24 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "host.register"           0|1|2  how ofxcv_vectorgen_flow(s)_host moves host images: 1 (default) asynchronous copies straight from / into
  *                                    the host's pageable images; 2 the host's buffers registered (hipHostRegister) for the duration of the
  *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
- *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   A/B: fill-order pixels per portion of the
+ *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
  *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
- *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back;
- *   "farneback.fold_carries" 0..5    OpenCV-order mode, how the f64 column sums are carried from strip to strip:
- *                                    4 (default) overlapped strips -- a workgroup computes three rows more than it stores, leaves the sums of
- *                                    its strip's row differences, and the next launch adds them up in its prologue: ONE launch per iteration
- *                                    on every pyramid level (iterate3h_kernel), the first M of a level from the same kernel; 5 = 4 on the
- *                                    bandwidth-bound levels, 0 elsewhere; 0 a carry pre-pass over M per iteration; 1 / 2 the iteration kernel
- *                                    produces the carries of its own output (prefix over the strips by the last workgroup of a tile column /
- *                                    by a small launch of its own); 3 (first half of round 3) = 2 on the bandwidth-bound levels, 0 on the
- *                                    small ones.  Identical results; timings in DESIGN.md section 4 and profiles/r03_exp09_overlapped_strips.txt;
- *   "farneback.halo_geom" 0..3, "farneback.halo_min8" n, "farneback.halo_min4" n, "farneback.halo_strip" rows, "farneback.halo_small" 2|3|4|5,
- *   "farneback.halo_deep" n          A/B knobs of the overlapped-strip form: wavefronts per workgroup and rows per wavefront by level size,
- *                                    computed rows per strip (csrc/common.h has one line per knob);
- *   "farneback.persist" 0|1          all iterations of a small pyramid level in ONE launch (workgroups draw tickets and wait on per-strip
- *                                    completion counters; default 0: measured slower than a launch per iteration);
- *                                    ofxcv_ctx_get_option("farneback.persist_aborts") = 1 if a wait of such a launch ever ran out of polls;
- *   "farneback.fold_rows" 3|8, "farneback.fold_min" n, "farneback.fold_nw4" 0|1, "farneback.fold_nw" 0|4|8, "farneback.fold_strip" rows,
- *   "farneback.solves_first" 0|1     A/B knobs of the folded forms 1..3 (rows / wavefronts per workgroup, strip height, level-size threshold);
- *   "farneback.batch_mb" MiB         a pyramid level is walked with as many pairs per launch as keep its working set under this (160);
- *   "farneback.strict_rows" 0|2|4|8|16, "farneback.strict_variant" (1 unpipelined gather, 2 rows in pairs), "farneback.carry_groups",
- *   "farneback.lds_pad" bytes: A/B knobs of the pre-pass form of the OpenCV-order kernels. */
+ *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back.
+ * Unknown names and values outside an option's range are rejected with OFXCV_ERR_INVALID.  (Geometry hooks of the two strip-parallel
+ * kernels used by the tests -- "farneback.halo_*", "farneback.col_geom", "farneback.col_trace" -- are listed in csrc/common.h; they select
+ * forms the library otherwise picks by level size and never change a result.) */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
-/* current value of "farneback.opencv_rounding", "farneback.fold_carries", "farneback.graph", "farneback.fuse_iterations", "host.register",
- * "farneback.batch_mb", "farneback.persist", "farneback.persist_aborts" (waits for the context's streams: a test hook) */
+/* current value of "farneback.opencv_rounding", "farneback.graph", "farneback.fuse_iterations", "host.register", "farneback.batch_mb",
+ * "farneback.col", "farneback.col_min", "farneback.gaussian_kernel_generation", "farneback.resize_generation", and "farneback.col_aborts":
+ * 1 if a bounded wait inside iterate_col_kernel ever ran out (waits for the context's streams: a test hook) */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
- * While enabled, ofxcv_calc_optical_flow_farneback brackets every launch of one kernel at pyramid level 0
- * with a hipEvent pair on the stream it is launched on.  enable = 1: the dominant kernel (OpenCV-order mode: the
- * blur+solve+update kernel of one iteration, iterate3h_kernel (iterate3f_kernel / iterate3s_kernel in the other carry forms); direct-window mode: the fused
- * two-iteration kernel, iterate3x2_kernel); enable = 2: the carry kernel of the OpenCV-order carry forms 0..3 (fold_scan_kernel /
- * vsum_carry_kernel).  ofxcv_profile_read synchronises, adds up the pairs and returns the total kernel time and the
- * number of launches since the last reset. */
+ * While enabled (enable = 1), the Farneback calls bracket every launch of the dominant kernel at pyramid level 0 with a hipEvent
+ * pair on the stream it is launched on: OpenCV-order mode -- the (iterate, iterate) launches of iterate_col_kernel (two iterations of
+ * every pair of the call) where level 0 takes the column-owning form, otherwise the iterating launches of iterate3h_kernel (one
+ * iteration); direct-window mode -- the fused two-iteration kernel iterate3x2_kernel.  ofxcv_profile_read synchronises, adds up the
+ * pairs and returns the total kernel time and the number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
 int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);
 

@@ -27,7 +27,7 @@ constexpr int kFbGraphSlots = 4;
 struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
     int n, width, height, levels, winsize, iterations, poly_n, flags;
     double pyr_scale, poly_sigma;
-    const void *planes, *tmp, *cflow, *vsum, *persist;  // scratch addresses baked into the graph
+    const void *planes, *tmp, *cflow, *vsum;  // scratch addresses baked into the graph
     const void *prev[OFXCV_FB_MAX_BATCH], *next[OFXCV_FB_MAX_BATCH], *flow[OFXCV_FB_MAX_BATCH];
     size_t prev_step[OFXCV_FB_MAX_BATCH], next_step[OFXCV_FB_MAX_BATCH], flow_step[OFXCV_FB_MAX_BATCH];
     const void *rgba[OFXCV_FB_MAX_BATCH];  // F7 fused into the call (ofxcv_calc_optical_flow_farneback_batch_rgba)
@@ -73,19 +73,8 @@ struct ofxcv_ctx {
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
     int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
-    int fb_fold_carries = 4;  // OpenCV-order mode: 4 (default) overlapped strips, ONE launch per iteration on every level (iterate3h_kernel); 5 = 4 on the bandwidth-bound
-                              // levels, 0 elsewhere; 3 (round-2 default) = 2 on the bandwidth-bound levels, 0 elsewhere; 0 carry pre-pass over all of M per iteration;
-                              // 1 carries folded into the iteration kernel, prefix over the strips by the last workgroup of a tile column; 2 folded, prefix as a small launch of its own
-    int fb_strict_variant = 0, fb_carry_groups = 0, fb_lds_pad = 0;  // A/B knobs of the strip-parallel form
-    int fb_strict_rows = 0;      // rows per wavefront of the strip-parallel form (0 = by level size)
-    // A/B knobs of the folded form (options "farneback.fold_min" / "farneback.fold_rows" / "farneback.fold_nw4"): 62x64-pixel
-    // tiles (over the whole batch) from which a level counts as large; rows per wavefront on the large levels (0 = default 4);
-    // 4-wavefront workgroups on the large levels too
-    int fb_fold_min_tiles = 256, fb_fold_rows = 0;
-    bool fb_fold_nw4 = false;
-    int fb_fold_nw = 0;          // option "farneback.fold_nw": wavefronts per workgroup of the folded kernel on the large levels: 0 (default) four of 8 or 9 rows, 4 four of 8 rows, 8 the eight-wavefront forms (4 / 5 rows)
-    int fb_solves_first = 0;     // A/B (option "farneback.solves_first"): folded kernel with all solves of a wavefront before its first gather
-    // overlapped-strip form (fold_carries 4 / 5): option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
+    // Geometry hooks of the overlapped-strip form (iterate3h_kernel), for tests and A/B runs -- the forms they select are otherwise only
+    // reached at particular level sizes; validated in ofxcv_ctx_set_option.  Option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
     // 3 eight of 8 or 9; "farneback.halo_min8" / "halo_min4": workgroups from which the eight- / four-wavefront tall form is used;
     // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
     int fb_halo_geom = 0, fb_halo_min8 = 250, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
@@ -95,14 +84,10 @@ struct ofxcv_ctx {
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
     int fb_col_min = 250;        // option "farneback.col_min": workgroups (tile columns x pairs of the call) from which a level takes that form
-    int fb_col_geom = 0;         // option "farneback.col_geom": 0 sixteen wavefronts of 8 or 9 rows per round, 1 twelve of 9 or 10
+    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 eight of 8
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
     DevBuf fb_col_flag;          // the sticky abort word of iterate_col_kernel (+ the trace area)
-    int fb_persist = 0;          // option "farneback.persist": all iterations of a small pyramid level in one launch (iterate3p_kernel)
-    int fb_persist_spin = 1 << 22;  // option "farneback.persist_spin": polls of one wait before the launch gives up (abort flag)
-    DevBuf fb_persist_buf;       // [0] abort flag; tickets and step / strip counters of the persistent launches of a call
-    int fb_fold_strip = 0;       // option "farneback.fold_strip": 0 strip height of the large levels chosen by the launch's rounds, 32 fixed 32-row strips, 33..40 that height
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one
 

@@ -183,7 +183,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (ctx->prep) (void)hipStreamDestroy(ctx->prep);
     if (ctx->coarse) (void)hipStreamDestroy(ctx->coarse);
     if (ctx->ev_coarse) (void)hipEventDestroy(ctx->ev_coarse);
-    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_persist_buf, &ctx->fb_col_flag, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
+    DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_col_flag, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
@@ -262,61 +262,21 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         return OFXCV_OK;
     }
     {
-        struct { const char *n; int *v; } knobs[] = {{"farneback.halo_geom", &ctx->fb_halo_geom}, {"farneback.halo_min8", &ctx->fb_halo_min8},
-                                                     {"farneback.halo_min4", &ctx->fb_halo_min4}, {"farneback.halo_strip", &ctx->fb_halo_strip}, {"farneback.halo_deep", &ctx->fb_halo_deep}, {"farneback.halo_small", &ctx->fb_halo_small}, {"lut.four", &ctx->lut4}, {"farneback.halo_min5", &ctx->fb_halo_min5}, {"farneback.persist", &ctx->fb_persist}, {"farneback.col", &ctx->fb_col}, {"farneback.col_min", &ctx->fb_col_min}, {"farneback.col_geom", &ctx->fb_col_geom}, {"farneback.col_trace", &ctx->fb_col_trace}, {"farneback.persist_spin", &ctx->fb_persist_spin}};
+        // test / A-B hooks (csrc/common.h has one line per hook): name, target, accepted range
+        struct { const char *n; int *v; int lo, hi; } knobs[] = {
+            {"farneback.halo_geom", &ctx->fb_halo_geom, 0, 3},    {"farneback.halo_min8", &ctx->fb_halo_min8, 0, 1 << 30},
+            {"farneback.halo_min4", &ctx->fb_halo_min4, 0, 1 << 30}, {"farneback.halo_strip", &ctx->fb_halo_strip, 0, 72},
+            {"farneback.halo_deep", &ctx->fb_halo_deep, 0, 8},    {"farneback.halo_small", &ctx->fb_halo_small, 2, 6},
+            {"farneback.halo_min5", &ctx->fb_halo_min5, 0, 1 << 30}, {"lut.four", &ctx->lut4, 0, 1},
+            {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
+            {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1},
+            {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
+                if (value < k.lo || value > k.hi) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);
                 *k.v = value;
                 return OFXCV_OK;
             }
-    }
-    if (!std::strcmp(name, "farneback.fold_rows")) {
-        ctx->fb_fold_rows = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fold_min")) {
-        ctx->fb_fold_min_tiles = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.batch_mb")) {
-        ctx->fb_batch_mb = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fold_nw")) {
-        ctx->fb_fold_nw = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.solves_first")) {
-        ctx->fb_solves_first = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fold_strip")) {
-        ctx->fb_fold_strip = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fold_nw4")) {
-        ctx->fb_fold_nw4 = value != 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fold_carries")) {
-        ctx->fb_fold_carries = value < 0 ? 0 : (value > 5 ? 5 : value);
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.lds_pad")) {
-        ctx->fb_lds_pad = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.strict_variant")) {
-        ctx->fb_strict_variant = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.carry_groups")) {
-        ctx->fb_carry_groups = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.strict_rows")) {
-        ctx->fb_strict_rows = value;
-        return OFXCV_OK;
     }
     if (!std::strcmp(name, "farneback.graph")) {
         ctx->fb_no_graph = value == 0;
@@ -340,15 +300,14 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     if (!ctx || !name || !value) return OFXCV_ERR_INVALID;
     if (!std::strcmp(name, "farneback.opencv_rounding")) *value = ctx->fb_opencv_rounding;
-    else if (!std::strcmp(name, "farneback.fold_carries")) *value = ctx->fb_fold_carries;
     else if (!std::strcmp(name, "farneback.gaussian_kernel_generation")) *value = ctx->fb_gauss_generation;
     else if (!std::strcmp(name, "farneback.resize_generation")) *value = ctx->fb_resize_generation;
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
-    else if (!std::strcmp(name, "farneback.persist")) *value = ctx->fb_persist;
     else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;
+    else if (!std::strcmp(name, "farneback.col_min")) *value = ctx->fb_col_min;
     else if (!std::strcmp(name, "farneback.col_aborts")) {
         // the sticky abort word of the column-owning kernel (waits for the context's streams first)
         *value = 0;
@@ -356,17 +315,6 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
             unsigned flag = 0;
             if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK ||
                 hipMemcpy(&flag, ctx->fb_col_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
-                return OFXCV_ERR_HIP;
-            *value = (int)flag;
-        }
-    }
-    else if (!std::strcmp(name, "farneback.persist_aborts")) {
-        // the sticky abort flag of the persistent small-level launches (waits for the context's streams first)
-        *value = 0;
-        if (ctx->fb_persist_buf.ptr) {
-            unsigned flag = 0;
-            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK ||
-                hipMemcpy(&flag, ctx->fb_persist_buf.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
                 return OFXCV_ERR_HIP;
             *value = (int)flag;
         }

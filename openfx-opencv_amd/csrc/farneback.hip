@@ -1379,66 +1379,13 @@ __global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restri
     }
 }
 
-// ------------------------------------------------------------------ OpenCV-order box window, strip-parallel
+// ------------------------------------------------------------------ OpenCV-order box window, strip-parallel: shared helpers
 //
 // The running sum above is vsum(y) = c0 + sum_{t<=y} (double)d_t with d_t = (float)(M[min(t+1,h-1)] - M[max(t-2,0)]) and
-// c0 = (double)(3.f * M[0]): a column prefix of row differences that were rounded to f32.  Only the f64 additions are
-// re-associated here (errors of 1e-16 relative to the partial sums, nine orders of magnitude below the f32 rounding of
-// the d_t themselves, which is reproduced exactly):
-//   * vsum_carry_kernel (one per iteration, reads M once) sums d_t over strips of RW rows and leaves, per strip, column
-//     and channel, the f64 value of vsum just above the strip: `carry` (prefix inside a group of strips handled by one
-//     workgroup) + `gtot` (totals of the groups above).
-//   * iterate3s_kernel: one wavefront owns 62 columns (+ one halo lane each side) x RW rows.  It starts from the carry,
-//     adds its own row differences top to bottom exactly like the reference, takes the left/right column sums from the
-//     neighbouring lanes by DPP wave shifts (two dwords per f64), solves, gathers R1 and writes the next M.  The R1
-//     gather of a row is issued one row ahead of the arithmetic that consumes it.
-// No intermediate field in HBM: per iteration M is read (RW+3)/RW times plus 40 B of carries per column and strip.
-constexpr int kSsSPW = 4;   // strips per wavefront of the carry kernel (upper bound)
-
-template <int RW>
-__global__ __launch_bounds__(1024) void vsum_carry_kernel(const float *__restrict__ M, int w, int h, int pitch, double *__restrict__ carry,
-                                                          double *__restrict__ gtot, int nstrips, int spg, int spw, size_t pair_stride,
-                                                          size_t pair_vsum) {
-    __shared__ double tot[16][64];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pz = blockIdx.y / 5;  // grid y = channel + 5 * pair
-    const int xr = blockIdx.x * 64 + lane, x = min(xr, w - 1), c = blockIdx.y - 5 * pz, g = blockIdx.z;
-    M += (size_t)pz * pair_stride;
-    carry += (size_t)pz * pair_vsum;
-    gtot += (size_t)pz * pair_vsum;
-    const int s_first = g * spg + wv * spw, s_end = min(s_first + spw, min((g + 1) * spg, nstrips));
-    const float *m = M + (size_t)c * pitch * h + x;
-    const int a = s_first * RW;
-    double pre[kSsSPW];  // sum of the strips of this wavefront before strip i
-    double acc = 0.;
-    if (s_first < s_end) {
-        // rows a-2 .. a + spw*RW of M (clamped): d_t = row[t+1] - row[t-2]
-        float row[kSsSPW * RW + 3];
-#pragma unroll
-        for (int r = 0; r < kSsSPW * RW + 3; r++) row[r] = r < spw * RW + 3 ? m[(size_t)clampi(a - 2 + r, 0, h - 1) * pitch] : 0.f;
-        if (a == 0) acc = (double)(row[2] * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product (row[2] = M[0])
-#pragma unroll
-        for (int i = 0; i < kSsSPW; i++) {
-            pre[i] = acc;
-            if (s_first + i < s_end) {
-#pragma unroll
-                for (int j = 0; j < RW; j++)
-                    if (a + i * RW + j < h) acc += (double)(row[i * RW + j + 3] - row[i * RW + j]);
-            }
-        }
-    }
-    tot[wv][lane] = acc;
-    __syncthreads();
-    double base = 0.;
-    for (int v = 0; v < wv; v++) base += tot[v][lane];
-    if (xr < w) {
-#pragma unroll
-        for (int i = 0; i < kSsSPW; i++)
-            if (s_first + i < s_end) carry[((size_t)(s_first + i) * 5 + c) * pitch + xr] = base + pre[i];
-        if (wv == 15) gtot[((size_t)g * 5 + c) * pitch + xr] = base + acc;
-    }
-}
-
+// c0 = (double)(3.f * M[0]): a column prefix of row differences that were rounded to f32.  The strip-parallel forms below
+// reproduce the d_t exactly and only re-associate the f64 additions (partial sums per wavefront, strip or round: errors of
+// 1e-16 relative to the partial sums, nine orders of magnitude below the f32 rounding of the d_t themselves).  The left / right
+// column sums of the 3-column window come from the neighbouring lanes by DPP wave shifts (two dwords per f64).
 __device__ __forceinline__ double dpp64_from_left(double v) {  // lane i <- lane i-1
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
@@ -1452,360 +1399,7 @@ __device__ __forceinline__ double dpp64_from_right(double v) {  // lane i <- lan
     return __hiloint2double(hi, lo);
 }
 
-constexpr int kSsW = 62;  // columns a wavefront of iterate3s_kernel owns (lanes 1..62; lanes 0 and 63 carry the halo columns)
-
-// MODE 0: the R1 gather of a row is consumed right away; 1: issued one row ahead of the arithmetic that consumes it; 2: rows in
-// pairs -- both gathers are issued back to back (the bottom R1 row of one is the top row of the other), then both finished
-template <bool UPDATE, int RW, int MODE>
-__global__ __launch_bounds__(128) void iterate3s_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                        const float *__restrict__ Min, float *__restrict__ Mout,
-                                                        FlowTab flows, int w, int h, int pitch, double scale,
-                                                        const double *__restrict__ carry, const double *__restrict__ gtot, int spg,
-                                                        size_t pair_stride, size_t pair_vsum) {
-    int tbx, tby, tbz;
-    xcd_tile(tbx, tby, tbz);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int x0 = (tbx * 2 + wave) * kSsW;
-    if (x0 >= w) return;  // wave-uniform
-    R0 += (size_t)tbz * pair_stride;
-    R1 += (size_t)tbz * pair_stride;
-    Min += (size_t)tbz * pair_stride;
-    if (UPDATE) Mout += (size_t)tbz * pair_stride;
-    carry += (size_t)tbz * pair_vsum;
-    gtot += (size_t)tbz * pair_vsum;
-    float *__restrict__ flow = flows.p[tbz];  // may be null while UPDATE (the flow then stays on chip)
-    const size_t flow_step = flows.step[tbz];
-    const int a = tby * RW;
-    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
-    const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    const size_t plane = (size_t)pitch * h;
-    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
-    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
-              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
-
-    // rows a-2 .. a+RW of M: index r <-> image row clamp(a - 2 + r).  Row j needs indices j and j+3; the loads run PF rows
-    // ahead of their use instead of all up front (55 live registers for RW = 8 otherwise).
-    constexpr int PF = RW > 4 ? 3 : RW;
-    float m[RW + 3][5];
-    auto load_m = [&](int r) {
-        const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
-#pragma unroll
-        for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
-    };
-#pragma unroll
-    for (int r = 0; r < 3 + PF && r < RW + 3; r++) load_m(r);
-    // vsum just above the strip
-    double D[5];
-    {
-        const int g = tby / spg;
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            double p = carry[((size_t)tby * 5 + c) * pitch + x];
-            if (g > 0) {
-                double s = gtot[(size_t)c * pitch + x];
-                for (int gg = 1; gg < g; gg++) s += gtot[((size_t)gg * 5 + c) * pitch + x];
-                p = s + p;
-            }
-            D[c] = p;
-        }
-    }
-    struct Px {
-        Taps tp;
-        float r0v[5];
-        float fxv, fyv;
-    };
-    Px prev;
-    auto finish = [&](const Px &p, int y) {
-        M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
-        if (own) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
-        }
-    };
-    auto solve_row = [&](int j, float &fxv, float &fyv) {
-        double acc[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            D[c] += (double)(m[j + 3][c] - m[j][c]);  // the reference's vsum[x] += srow1[x] - srow0[x]
-            acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
-        }
-        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-        fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-        fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
-    };
-    auto request = [&](Px &p, int y) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) p.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-        p.tp = gather_taps(bR1, x, y, w, h, pitch, pb, p.fxv, p.fyv);
-    };
-    if (MODE == 2 && UPDATE) {
-#pragma unroll
-        for (int j = 0; j < RW; j += 2) {
-            const int y = a + j;
-            if (y >= h) break;  // wave-uniform
-            const bool two = j + 1 < RW && y + 1 < h;
-            if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
-            if (j + 4 + PF < RW + 3) load_m(j + 4 + PF);
-            Px p0, p1;
-            solve_row(j, p0.fxv, p0.fyv);
-            if (two) solve_row(j + 1, p1.fxv, p1.fyv);
-            request(p0, y);
-            if (two) request(p1, y + 1);
-            finish(p0, y);
-            if (two) finish(p1, y + 1);
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < RW; j++) {
-        const int y = a + j;
-        if (y >= h) break;  // wave-uniform
-        if (j + 3 + PF < RW + 3) load_m(j + 3 + PF);
-        float fxv, fyv;
-        solve_row(j, fxv, fyv);
-        if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
-        if (UPDATE) {
-            Px cur;
-            cur.fxv = fxv;
-            cur.fyv = fyv;
-            request(cur, y);
-            if (MODE == 1) {
-                if (j > 0) finish(prev, y - 1);
-                prev = cur;
-            } else {
-                finish(cur, y);
-            }
-        }
-    }
-    if (UPDATE && MODE == 1) finish(prev, min(a + RW, h) - 1);
-}
-
-// ------------------------------------------------------------------ OpenCV-order window, carries folded into the iteration
-//
-// iterate3s_kernel needs vsum just above every strip, and vsum_carry_kernel re-reads all of M once per iteration to
-// provide it.  Here the iteration kernel produces the carries of ITS OUTPUT for the next launch:
-//   * a workgroup = NW wavefronts stacked over the same 62 columns, RW rows each (a strip of NW*RW rows).  One f64 per
-//     strip, column and channel comes in (`Kin`: vsum just above the strip); the wavefronts pass the sums of their own
-//     row differences through LDS, so each starts its column chain at the right value.
-//   * while the rows of the new M are produced, every wavefront adds up the row differences of the new M that lie inside
-//     its own rows (d_t = (float)(M'[t+1] - M'[t-2]) needs rows three apart); its last three rows go to LDS so that the
-//     wavefront below can add the three differences that straddle the wavefront boundary.  The strip's sum goes to
-//     `Spart`.
-//   * the three differences that straddle a STRIP boundary need rows of two workgroups.  The last workgroup of a tile
-//     column to finish (one atomic counter per tile column; nobody spins) reads those boundary rows and the strip sums
-//     of its tile column back, runs the prefix over the strips and leaves `Kout` for the next launch.
-// Everything is summed in ascending row order; only f64 additions are re-associated (strip and wavefront partial sums),
-// as in the two-kernel form.  vsum_seed_kernel provides the carries of the first M of a pyramid level the same way.
-struct FoldArgs {
-    const double *Kin;    // [nstrips][5][pitch]  vsum of Min at the row above each strip
-    double *Kout;         // [nstrips][5][pitch]  the same for Mout (complete when the launch has finished)
-    double *Spart;        // [nstrips][5][pitch]  sum of the row differences of Mout with both rows inside the strip
-    unsigned *counters;   // [tile columns]       workgroups of the tile column that have finished (0 on entry and on exit)
-    int nstrips;
-    int scan_in_kernel;   // 1: the last workgroup of a tile column runs the prefix over the strips itself; 0: fold_scan_kernel does
-    size_t pair_vsum;     // batched calls: doubles between the Kin / Kout / Spart of consecutive pairs
-    unsigned pair_ctr;    //                counters between consecutive pairs
-    int sh;               // rows per strip (= rows per wavefront x wavefronts, or anything above (rows - 1) x wavefronts: wave_rows)
-    __device__ __forceinline__ void select_pair(int z) {
-        if (Kin) Kin += (size_t)z * pair_vsum;
-        Kout += (size_t)z * pair_vsum;
-        Spart += (size_t)z * pair_vsum;
-        counters += (size_t)z * pair_ctr;
-    }
-};
-
-// Data that one workgroup hands to another inside a launch (the boundary rows of the new M, the strip sums) goes through
-// device-scope accesses: stores that write through the XCD's L2 and loads that do not hit in a non-coherent cache.  A
-// device-wide fence would have every workgroup write back its whole L2 (measured: 199 instead of 40 us per launch).
-__device__ __forceinline__ float ld_dev(const float *p) {
-    return __builtin_bit_cast(float, __hip_atomic_load((const unsigned *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ double ld_dev(const double *p) {
-    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void st_dev(double *p, double v) {
-    __hip_atomic_store((unsigned long long *)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// buffer store with the sc0 | sc1 cache policy (write-through to memory)
-__device__ __forceinline__ void buf_st_dev(const Buf &b, float v, unsigned voff_bytes, unsigned soff_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, 17);
-}
-
-// Last workgroup of tile column: prefix over the strips.  M = the field the carries are for, rows of `sh` per strip.
-template <int NW, bool DEV>
-__device__ __forceinline__ void fold_scan(const float *__restrict__ M, const FoldArgs &fa, int sh, int xr, int w, int h, int pitch,
-                                          int wave, bool own) {
-    auto ldf = [](const float *p) { return DEV ? ld_dev(p) : *p; };
-    auto ldd = [](const double *p) { return DEV ? ld_dev(p) : *p; };
-    const size_t plane = (size_t)pitch * h;
-    const int x = clampi(xr, 0, w - 1);
-    for (int c = wave; c < 5; c += NW) {  // one channel per wavefront (wavefront 0 also takes what is left over)
-        const float *m = M + c * plane + x;
-        const size_t kst = (size_t)5 * pitch, kof = (size_t)c * pitch + x;
-        double run = (double)(ldf(m) * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
-        if (own) fa.Kout[kof] = run;
-        constexpr int CH = 8;  // strip boundaries per batch of loads
-        for (int s0 = 1; s0 < fa.nstrips; s0 += CH) {
-            float r[CH][6];
-            double sp[CH];
-#pragma unroll
-            for (int i = 0; i < CH; i++) {
-                const int s = s0 + i;
-                if (s < fa.nstrips) {
-                    const int A = s * sh;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) r[i][k] = ldf(m + (size_t)min(A - 3 + k, h - 1) * pitch);
-                    sp[i] = ldd(fa.Spart + (size_t)(s - 1) * kst + kof);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; i++) {
-                const int s = s0 + i;
-                if (s < fa.nstrips) {
-                    run += sp[i];                          // differences inside strip s-1
-                    run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
-                    if (own) fa.Kout[(size_t)s * kst + kof] = run;
-                    run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
-                    run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
-                }
-            }
-        }
-    }
-}
-
-// strip sum from the wavefront sums (s_w), then the hand-over to the last workgroup of the tile column
-template <int NW>
-__device__ __forceinline__ void fold_finish(const float *__restrict__ M, const FoldArgs &fa, double (*s_w)[5][64], unsigned *s_flag, int sh,
-                                            int tbx, int tby, int xr, int w, int h, int pitch, int wave, int lane, bool own) {
-    __syncthreads();
-    if (wave == 0 && own) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            double sum = s_w[0][c][lane];
-            for (int u = 1; u < NW; u++) sum += s_w[u][c][lane];
-            st_dev(fa.Spart + ((size_t)tby * 5 + c) * pitch + xr, sum);
-        }
-    }
-    if (!fa.scan_in_kernel) return;  // fold_scan_kernel follows as its own launch
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wavefront's write-through stores (rows of M, strip sum) have completed
-    __syncthreads();
-    if (threadIdx.x == 0) *s_flag = __hip_atomic_fetch_add(fa.counters + tbx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*s_flag != (unsigned)(fa.nstrips - 1)) return;
-    fold_scan<NW, true>(M, fa, sh, xr, w, h, pitch, wave, own);
-    if (threadIdx.x == 0) __hip_atomic_store(fa.counters + tbx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// The prefix over the strips as its own (small) launch: one workgroup per tile column and channel, kScanQ wavefronts that
-// each take a portion of the strip boundaries (one workgroup for all five channels is bound by the L1 of its one CU).  A wavefront loads the boundary rows and strip sums of its portion (all loads in
-// flight at once), adds them up in ascending row order, the portion totals meet in LDS, and each wavefront then writes the
-// carries of its portion.  (With one wavefront per channel walking all boundaries in batches the launch took 9.9 us at
-// 1080p -- five dependent batches -- which is on the critical path when one pair is in flight.)
-constexpr int kScanQ = 8, kScanB = 8;  // portions per channel; boundaries per batch of loads
-__global__ __launch_bounds__(64 * kScanQ) void fold_scan_kernel(const float *__restrict__ M, int w, int h, int pitch, int sh, FoldArgs fa,
-                                                                size_t pair_stride) {
-    __shared__ double s_tot[kScanQ][64];
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int tbx, c, tbz;  // (tile column, channel, pair): neighbouring tile columns -- they read neighbouring 248-byte pieces of the same rows -- on one XCD
-    xcd_tile(tbx, c, tbz);
-    M += (size_t)tbz * pair_stride;
-    fa.select_pair(tbz);
-    const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
-    const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    const size_t plane = (size_t)pitch * h;
-    const float *m = M + c * plane + x;
-    const size_t kst = (size_t)5 * pitch, kof = (size_t)c * pitch + x;
-    const int nb = fa.nstrips - 1, per = (nb + kScanQ - 1) / kScanQ;  // boundaries s = 1 .. nstrips-1
-    const int s_lo = 1 + q * per, s_hi = min(s_lo + per, fa.nstrips);
-    const float m_top = m[0];
-    if (per <= kScanB) {
-        // the usual case: the whole portion in one batch of loads, kept in registers for both passes (one memory round trip)
-        float r[kScanB][6];
-        double sp[kScanB];
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s_lo + i < s_hi) {
-                const int A = (s_lo + i) * sh;
-#pragma unroll
-                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
-                sp[i] = fa.Spart[(size_t)(s_lo + i - 1) * kst + kof];
-            }
-        double tot = 0.;
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s_lo + i < s_hi) {
-                tot += sp[i];
-                tot += (double)(r[i][3] - r[i][0]);
-                tot += (double)(r[i][4] - r[i][1]);
-                tot += (double)(r[i][5] - r[i][2]);
-            }
-        s_tot[q][lane] = tot;
-        __syncthreads();
-        double run = (double)(m_top * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
-        if (q == 0 && own) fa.Kout[kof] = run;
-        for (int u = 0; u < q; u++) run += s_tot[u][lane];
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s_lo + i < s_hi) {
-                run += sp[i];                          // differences inside strip s-1
-                run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
-                if (own) fa.Kout[(size_t)(s_lo + i) * kst + kof] = run;
-                run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
-                run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
-            }
-        return;
-    }
-    // pass 1: total of the portion (strip sums + the three boundary differences each)
-    double tot = 0.;
-    for (int s0 = s_lo; s0 < s_hi; s0 += kScanB) {
-        float r[kScanB][6];
-        double sp[kScanB];
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s0 + i < s_hi) {
-                const int A = (s0 + i) * sh;
-#pragma unroll
-                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
-                sp[i] = fa.Spart[(size_t)(s0 + i - 1) * kst + kof];
-            }
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s0 + i < s_hi) {
-                tot += sp[i];
-                tot += (double)(r[i][3] - r[i][0]);
-                tot += (double)(r[i][4] - r[i][1]);
-                tot += (double)(r[i][5] - r[i][2]);
-            }
-    }
-    s_tot[q][lane] = tot;
-    __syncthreads();
-    double run = (double)(m_top * 3.f);  // vsum(-1) = srow0 * (m + 2), a float product
-    if (q == 0 && own) fa.Kout[kof] = run;
-    for (int u = 0; u < q; u++) run += s_tot[u][lane];
-    // pass 2: the carries of the portion (the same loads again: they hit in the cache)
-    for (int s0 = s_lo; s0 < s_hi; s0 += kScanB) {
-        float r[kScanB][6];
-        double sp[kScanB];
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s0 + i < s_hi) {
-                const int A = (s0 + i) * sh;
-#pragma unroll
-                for (int k = 0; k < 6; k++) r[i][k] = m[(size_t)min(A - 3 + k, h - 1) * pitch];
-                sp[i] = fa.Spart[(size_t)(s0 + i - 1) * kst + kof];
-            }
-#pragma unroll
-        for (int i = 0; i < kScanB; i++)
-            if (s0 + i < s_hi) {
-                run += sp[i];                          // differences inside strip s-1
-                run += (double)(r[i][3] - r[i][0]);    // t = A-1: rows A, A-3
-                if (own) fa.Kout[(size_t)(s0 + i) * kst + kof] = run;
-                run += (double)(r[i][4] - r[i][1]);    // t = A:   rows A+1, A-2
-                run += (double)(r[i][5] - r[i][2]);    // t = A+1: rows A+2, A-1
-            }
-    }
-}
+constexpr int kSsW = 62;  // columns a wavefront of the overlapped-strip form owns (lanes 1..62; lanes 0 and 63 carry the halo columns)
 
 // Rows of a strip over the wavefronts of its workgroup.  A strip of `sh` rows (NW*(RW-1) < sh <= NW*RW) is cut into NW
 // wavefronts of RW-1 or RW rows: the first sh - NW*(RW-1) wavefronts take RW.  With sh = NW*RW every wavefront has RW rows
@@ -1824,219 +1418,10 @@ __device__ __forceinline__ void wave_rows(int sh, int wave, int &off, int &nr) {
     nr = RW - 1 + (wave < extra ? 1 : 0);
 }
 
-// carries of a field that already lies in memory (the first M of a pyramid level)
-template <int RW, int NW, bool VAR>
-__global__ __launch_bounds__(64 * NW) void vsum_seed_kernel(const float *__restrict__ M, int w, int h, int pitch, FoldArgs fa, size_t pair_stride) {
-    __shared__ double s_w[NW][5][64];
-    __shared__ unsigned s_flag;
-    int tbx, tby, tbz;
-    xcd_tile(tbx, tby, tbz);
-    M += (size_t)tbz * pair_stride;
-    fa.select_pair(tbz);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int xr = tbx * kSsW - 1 + lane, x = clampi(xr, 0, w - 1);
-    const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    const int SH = VAR ? fa.sh : RW * NW;
-    int off, nr;
-    wave_rows<RW, NW, VAR>(SH, wave, off, nr);
-    const int A = tby * SH, a = A + off;
-    const size_t plane = (size_t)pitch * h;
-    // rows a-3 .. a+RW-1: the differences with the later row inside this wavefront's rows
-    float m[RW + 3][5];
-#pragma unroll
-    for (int r = 0; r < RW + 3; r++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) m[r][c] = M[c * plane + (size_t)clampi(a - 3 + r, 0, h - 1) * pitch + x];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        double sum = 0.;
-#pragma unroll
-        for (int j = 0; j < RW; j++) {
-            // t = a+j-1: rows a+j and a+j-3.  The first three of a strip belong to the strip boundary (fold_scan), except
-            // at the top of the image, where rows above 0 are row 0: t = 0, 1 are (row 1 - row 0), (row 2 - row 0).
-            const int row = a + j;
-            if (j >= nr || row >= h || row - 1 < 0) continue;        // t = row - 1 >= 0
-            if (wave == 0 && j < 3 && A > 0) continue;
-            sum += (double)(m[j + 3][c] - m[j][c]);
-        }
-        s_w[wave][c][lane] = sum;
-    }
-    fold_finish<NW>(M, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
-}
-
-// SF ("solves first"): the 2x2 solves of all rows of the wavefront run before the first gather is issued -- they only depend
-// on the column sums, so they are independent instruction chains the SIMD can interleave -- instead of row by row
-template <bool UPDATE, int RW, int NW, bool VAR, bool SF = false>
-__global__ __launch_bounds__(64 * NW, 4) void iterate3f_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                           const float *__restrict__ Min, float *__restrict__ Mout,
-                                                           FlowTab flows, int w, int h, int pitch, double scale,
-                                                           FoldArgs fa, size_t pair_stride) {
-    constexpr bool PIPE = RW < 8 || SF;  // with 8 rows per wavefront the second in-flight pixel record only fits 128 registers in the solves-first form
-    static_assert(RW >= 3 && (!VAR || RW >= 4), "a row difference spans three rows: wavefront boundaries are resolved between neighbours only");
-    __shared__ double s_w[NW][5][64];        // wavefront sums: of Min's row differences first, of Mout's afterwards
-    __shared__ float s_first[NW][3][5][64];  // the first three rows of Mout of every wavefront (for the wavefront above)
-    __shared__ unsigned s_flag;
-    int tbx, tby, tbz;
-    xcd_tile(tbx, tby, tbz);
-    R0 += (size_t)tbz * pair_stride;
-    R1 += (size_t)tbz * pair_stride;
-    Min += (size_t)tbz * pair_stride;
-    if (UPDATE) Mout += (size_t)tbz * pair_stride;
-    fa.select_pair(tbz);
-    float *__restrict__ flow = flows.p[tbz];  // may be null while UPDATE
-    const size_t flow_step = flows.step[tbz];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int x0 = tbx * kSsW;
-    const int SH = VAR ? fa.sh : RW * NW;
-    int off, nr;  // this wavefront's rows inside the strip (wave-uniform)
-    wave_rows<RW, NW, VAR>(SH, wave, off, nr);
-    const int A = tby * SH, a = A + off;
-    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
-    const bool own = lane >= 1 && lane <= kSsW && xr < w;
-    const size_t plane = (size_t)pitch * h;
-    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u, vx = 4u * (unsigned)x;
-    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
-              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
-
-    // rows a-2 .. a+nr of Min (index r <-> image row clamp(a - 2 + r)); all of them are needed before the chain can start
-    float m[RW + 3][5];
-#pragma unroll
-    for (int r = 0; r < RW + 3; r++) {
-        if (VAR && r == RW + 2 && nr < RW) {  // a short wavefront has no use for the last row
-#pragma unroll
-            for (int c = 0; c < 5; c++) m[r][c] = 0.f;
-            continue;
-        }
-        const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
-#pragma unroll
-        for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
-    }
-    double D[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) D[c] = fa.Kin[((size_t)tby * 5 + c) * pitch + x];
-    // the f32 row differences of this wavefront's rows (the reference's srow1[x] - srow0[x]); the rows themselves are dead after this
-    float d[RW][5];
-#pragma unroll
-    for (int j = 0; j < RW; j++)
-#pragma unroll
-        for (int c = 0; c < 5; c++) d[j][c] = m[j + 3][c] - m[j][c];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        double t = 0.;
-#pragma unroll
-        for (int j = 0; j < RW; j++)
-            if (j < nr && a + j < h) t += (double)d[j][c];
-        s_w[wave][c][lane] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 5; c++)
-        for (int u = 0; u < wave; u++) D[c] += s_w[u][c][lane];  // vsum just above this wavefront's first row
-    __syncthreads();  // s_w is reused for the sums of Mout
-
-    struct Px {
-        Taps tp;
-        float r0v[5];
-        float fxv, fyv;
-    };
-    Px prev;
-    float mo[RW][5];   // rows of Mout as they are produced (only the last three finished ones stay live)
-    double I[5] = {0., 0., 0., 0., 0.};  // row differences of Mout with both rows in this wavefront, ascending t
-    auto finish = [&](const Px &p, int j) {
-        const int y = a + j;
-        M5 mm = update_matrices_finish(p.r0v, p.tp, x, y, w, h, p.fxv, p.fyv);
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            mo[j][c] = mm.v[c];
-            if (own) {
-                if (fa.scan_in_kernel) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
-                else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
-            }
-            if (j < 3) s_first[wave][j][c][lane] = mm.v[c];
-            // at the top of the image rows above row 0 are row 0: t = 0, 1 are (row 1 - row 0), (row 2 - row 0)
-            if (A == 0 && wave == 0 && (j == 1 || j == 2)) I[c] += (double)(mm.v[c] - mo[0][c]);
-            if (j >= 3) I[c] += (double)(mm.v[c] - mo[j - 3][c]);   // t = y-1: rows y, y-3, both in this wavefront
-        }
-    };
-    auto solve_row = [&](int j, float &fxv, float &fyv) {
-        double acc[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            D[c] += (double)d[j][c];  // the reference's vsum[x] += srow1[x] - srow0[x]
-            acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
-        }
-        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-        fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-        fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
-    };
-    float fxs[RW], fys[RW];
-    if (SF) {
-#pragma unroll
-        for (int j = 0; j < RW; j++)
-            if (j < nr && a + j < h) solve_row(j, fxs[j], fys[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < RW; j++) {
-        const int y = a + j;
-        if (j >= nr || y >= h) break;  // wave-uniform
-        float fxv, fyv;
-        if (SF) {
-            fxv = fxs[j];
-            fyv = fys[j];
-        } else {
-            solve_row(j, fxv, fyv);
-        }
-        if (flow && own) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)xr * 8) = make_float2(fxv, fyv);
-        if (UPDATE) {
-            Px cur;
-            cur.fxv = fxv;
-            cur.fyv = fyv;
-#pragma unroll
-            for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, fxv, fyv);
-            if (PIPE) {  // the gather of row j is in flight while row j-1 is finished
-                if (j > 0) finish(prev, j - 1);
-                prev = cur;
-            } else {
-                finish(cur, j);
-            }
-        }
-    }
-    if (!UPDATE) return;
-    const int nre = min(nr, h - a);  // rows of this wavefront inside the image (<= 0: none, bottom strip only)
-    if (PIPE) {
-        if (nre > 0) {
-#pragma unroll
-            for (int j = 0; j < RW; j++)
-                if (j == nre - 1) finish(prev, j);
-        }
-    }
-    __syncthreads();  // every wavefront's first three rows are in LDS
-    // the three differences across the boundary to the wavefront below (t = b-1, b, b+1 with b its first row): its rows
-    // 0..2 against this wavefront's last three; the ones across the strip boundary are left to fold_scan
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        double sum = I[c];
-        if (wave < NW - 1) {
-            // this wavefront's last three rows (a short wavefront's are one index earlier)
-            const bool full = !VAR || nr == RW;
-            const float l0 = full ? mo[RW - 3][c] : mo[RW >= 4 ? RW - 4 : 0][c], l1 = full ? mo[RW - 2][c] : mo[RW - 3][c],
-                        l2 = full ? mo[RW - 1][c] : mo[RW - 2][c];
-            sum += (double)(s_first[wave + 1][0][c][lane] - l0);
-            sum += (double)(s_first[wave + 1][1][c][lane] - l1);
-            sum += (double)(s_first[wave + 1][2][c][lane] - l2);
-        }
-        s_w[wave][c][lane] = sum;
-    }
-    fold_finish<NW>(Mout, fa, s_w, &s_flag, SH, tbx, tby, xr, w, h, pitch, wave, lane, own);
-}
-
 // ------------------------------------------------------------------ OpenCV-order window, overlapped strips: ONE launch per iteration
 //
-// The folded form above still needs a second launch per iteration (fold_scan_kernel) for the three row differences that
-// straddle a strip boundary: d_t = (float)(M'[t+1] - M'[t-2]) of the NEW field needs rows of two workgroups.  Here the strips
-// overlap instead: a workgroup that owns the output rows [A, A + SO) of the new M computes the rows [A - 2, A + SO] -- three
+// The three row differences that straddle a strip boundary, d_t = (float)(M'[t+1] - M'[t-2]) of the NEW field, need rows of two
+// workgroups (rounds 2 and 3 spent a second launch per iteration on them).  Here the strips overlap instead: a workgroup that owns the output rows [A, A + SO) of the new M computes the rows [A - 2, A + SO] -- three
 // more, not stored -- so that every difference d_t with t in [A, A + SO) has both of its rows in this workgroup.  It leaves
 //     T_s  = sum of d_t over t in [A_s, A_s + SO)          (ascending t: wavefront sums, then the wavefronts in order)
 //     T'_s = the same without the last two (t < A_s + SO - 2)
@@ -2090,14 +1475,9 @@ struct HaloLds {
     float s_first[LROWS ? 1 : NW][3][5][64];   // the first three rows of Mout of every wavefront (for the wavefront above)
     float s_rows[LROWS ? NW * RW : 1][5][64];  // LROWS: all computed rows of Mout
 };
-__device__ __forceinline__ float buf_ld_dev(const Buf &b, unsigned voff_bytes, unsigned soff_bytes) {  // sc0 | sc1: not served from a non-coherent cache
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff_bytes, (int)soff_bytes, 17));
-}
 
-// One workgroup's tile (tile column tbx, strip tby, pair tbz).  COH: the tile runs inside the persistent kernel below, where
-// Min / Tin were written by other workgroups of the SAME launch: device-scope loads for them, write-through stores for
-// Mout / Tout (R0 / R1 and the flows are not touched by the launch and stay ordinary accesses).
-template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS, bool COH>
+// One workgroup's tile (tile column tbx, strip tby, pair tbz).
+template <int KIND, int RW, int NW, bool VAR, bool DEEP, bool LROWS>
 __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const float *__restrict__ R0, const float *__restrict__ R1,
                                           const float *__restrict__ Min, float *__restrict__ Mout, const FlowTab &flows, const Prolong &pr,
                                           int w, int h, int pitch, double scale, HaloArgs ha, size_t pair_stride, int tbx, int tby, int tbz,
@@ -2145,21 +1525,21 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
         // ahead of the rows of M (loads return in order: the sums are added up while the rows are still in flight)
         for (int c = wave; c < 5; c += NW) {
             // vsum(-1) = srow0 * (m + 2), a float product of row 0: the top strip reads it; for the others it is part of the top
-            // strip's sums (a tile of the persistent kernel must not read rows outside its own neighbourhood)
+            // strip's sums
             double k = 0.;
             if (tby == 0) {  // row 0 of M
-                if (DF) k = (double)((COH ? buf_ld_dev(bEi, vx, c * rb) : buf_ld(bEi, vx, c * rb)) * 3.f);
-                else k = (double)((COH ? buf_ld_dev(bM, vx, c * pb) : buf_ld(bM, vx, c * pb)) * 3.f);
+                if (DF) k = (double)(buf_ld(bEi, vx, c * rb) * 3.f);
+                else k = (double)(buf_ld(bM, vx, c * pb) * 3.f);
             } else {
                 const size_t kst = (size_t)5 * pitch;
                 const double *T = ha.Tin + (size_t)c * pitch + x;
                 const int n = tby - 1;  // T of the strips 0 .. tby-2, then T' of strip tby-1
                 constexpr int CH = 16;  // one batch of loads up to 17 strips
-                const double tl = COH ? ld_dev(T + (size_t)(ha.nstrips + n) * kst) : T[(size_t)(ha.nstrips + n) * kst];
+                const double tl = T[(size_t)(ha.nstrips + n) * kst];
                 for (int s0 = 0; s0 < n; s0 += CH) {
                     double t[CH];
 #pragma unroll
-                    for (int i = 0; i < CH; i++) t[i] = s0 + i < n ? (COH ? ld_dev(T + (size_t)(s0 + i) * kst) : T[(size_t)(s0 + i) * kst]) : 0.;
+                    for (int i = 0; i < CH; i++) t[i] = s0 + i < n ? T[(size_t)(s0 + i) * kst] : 0.;
 #pragma unroll
                     for (int i = 0; i < CH; i++)
                         if (s0 + i < n) k += t[i];
@@ -2178,7 +1558,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             for (int r = 0; r < RW + 3; r++) {
                 const unsigned so = (unsigned)clampi(a - 2 + r, 0, h - 1) * rb;
 #pragma unroll
-                for (int c = 0; c < 5; c++) m[r][c] = COH ? buf_ld_dev(bM, vx, so + c * pb) : buf_ld(bM, vx, so + c * pb);
+                for (int c = 0; c < 5; c++) m[r][c] = buf_ld(bM, vx, so + c * pb);
             }
 #pragma unroll
             for (int j = 0; j < RW; j++)
@@ -2194,10 +1574,10 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             } else if (y == h - 1) {
 #pragma unroll
                 for (int c = 0; c < 5; c++)  // rows h-1 and max(h-3, 0) of M
-                    d[j][c] = COH ? buf_ld_dev(bEi, vx, 2 * eb + c * rb) - buf_ld_dev(bEi, vx, eb + c * rb) : buf_ld(bEi, vx, 2 * eb + c * rb) - buf_ld(bEi, vx, eb + c * rb);
+                    d[j][c] = buf_ld(bEi, vx, 2 * eb + c * rb) - buf_ld(bEi, vx, eb + c * rb);
             } else {
 #pragma unroll
-                for (int c = 0; c < 5; c++) d[j][c] = COH ? buf_ld_dev(bM, vx, (unsigned)y * rb + c * pb) : buf_ld(bM, vx, (unsigned)y * rb + c * pb);
+                for (int c = 0; c < 5; c++) d[j][c] = buf_ld(bM, vx, (unsigned)y * rb + c * pb);
             }
         }
 #pragma unroll
@@ -2274,13 +1654,11 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
     };
     Px prev;
     auto st_e = [&](float v, unsigned soff) {  // an edge row of M_out (own lanes: `st`)
-        if (COH) buf_st_dev(bEo, v, vx, soff);
-        else buf_st(bEo, v, vx, soff);
+        buf_st(bEo, v, vx, soff);
     };
     auto st_d = [&](float dv, int t, int c) {  // row t of the difference field of M_out
         if (!DF || !own) return;
-        if (COH) buf_st_dev(bMo, dv, vx, (unsigned)t * rb + c * pb);
-        else buf_st(bMo, dv, vx, (unsigned)t * rb + c * pb);
+        buf_st(bMo, dv, vx, (unsigned)t * rb + c * pb);
     };
     float mo[RW][5];   // rows of Mout as they are produced (only the last three finished ones stay live)
     double I[5] = {0., 0., 0., 0., 0.};   // row differences of Mout with both rows in this wavefront, ascending t
@@ -2292,8 +1670,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             if (!DF && st) {
-                if (COH) buf_st_dev(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
-                else buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
+                buf_st(bMo, mm.v[c], vx, (unsigned)y * rb + c * pb);
             }
             if (DF && st && (y == 0 || y == h - 1 || y == max(h - 3, 0))) {
                 if (y == 0) st_e(mm.v[c], c * rb);
@@ -2405,8 +1782,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             sum += wave == 0 ? s_w[NW - 1][c][lane] : s_ip[c][lane];
             if (tby == 0) sum = (LROWS ? (double)(s_rows[2][c][lane] * 3.f) : s_kin[c][lane]) + sum;  // the top strip's sums carry vsum(-1)
             double *o = ha.Tout + (wave ? tq : 0) + ((size_t)tby * 5 + c) * pitch + xr;
-            if (COH) st_dev(o, sum);
-            else *o = sum;
+            *o = sum;
         }
     }
 }
@@ -2420,7 +1796,7 @@ __global__ __launch_bounds__(64 * NW, DEEP && !LROWS ? 2 : 4) void iterate3h_ker
     __shared__ HaloLds<RW, NW, LROWS> lds;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
-    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS, false>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz,
+    halo_tile<KIND, RW, NW, VAR, DEEP, LROWS>(lds, R0, R1, Min, Mout, flows, pr, w, h, pitch, scale, ha, pair_stride, tbx, tby, tbz,
                                                      KIND == kHaloLast ? &rg : nullptr);
 }
 
@@ -2822,91 +2198,6 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     }
 }
 
-// ------------------------------------------------------------------ OpenCV-order window: ALL iterations of a small level in ONE launch
-//
-// A launch of a small pyramid level is bound by its own start-up and tear-down and by two dependent memory round trips from
-// a cold L2, not by work (a 240x135 iteration occupies 28 workgroups for 10 us), and a level needs iterations + 1 of them
-// back to back.  Here the level is one launch: its workgroups draw TICKETS from a counter -- ticket = (step, strip, pair,
-// tile column), step-major; step 0 = the level's first M, steps 1 .. iterations-1 = iterate, step `iterations` = the last
-// iteration (flow out) -- and run halo_tile for each.  A tile of step i reads rows of M and strip sums that tiles of step
-// i-1 wrote: it waits until every tile of the strips 0 .. s+1 of step i-1 (its own pair) has signalled completion (one
-// counter per pair, step and strip).  That also covers the write-after-read on the M ping-pong buffer (the readers of what
-// it overwrites are the strips s-1 .. s+1 of step i-1); the strip sums have one slot per step.  Data handed from one
-// workgroup to another goes through write-through stores and device-scope loads (no cache is flushed).
-// No deadlock for any number of resident workgroups: a tile only waits for tiles with SMALLER ticket numbers, every drawn
-// ticket belongs to a running workgroup, so the smallest unfinished ticket never waits.  The polls are bounded all the same
-// (`spin_limit`): a wait that runs out raises `abort`, every workgroup drains, and the host sees the flag with the result.
-struct PersistArgs {
-    unsigned *ticket;      // next ticket (0 on entry)
-    unsigned *cnt;         // [pairs][nsteps][nstrips] tiles that have finished (0 on entry)
-    unsigned *abort_flag;  // sticky: a wait ran out of polls
-    double *T;             // [nsteps] x { [2][nstrips][5][pitch] strip sums, [3][5][pitch] edge rows (floats) } of every step's M; pair z lies pair_vsum doubles further
-    int nsteps;            // iterations + 1
-    unsigned spin_limit;
-};
-
-template <int FIRST, int RW, int NW>
-__global__ __launch_bounds__(64 * NW, 4) void iterate3p_kernel(const float *__restrict__ R0, const float *__restrict__ R1, float *__restrict__ M0,
-                                                               float *__restrict__ M1, FlowTab fin, FlowTab fout, Prolong pr, int w, int h,
-                                                               int pitch, double scale, int nstrips, int so, int tiles_x, int npairs,
-                                                               size_t pair_stride, size_t pair_vsum, PersistArgs pa) {
-    __shared__ HaloLds<RW, NW, true> lds;
-    __shared__ unsigned s_ticket, s_abort;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const unsigned row = (unsigned)tiles_x * npairs, per_step = row * nstrips, total = per_step * pa.nsteps;
-    const size_t estep = 8 * (size_t)pitch, tstep = (size_t)2 * nstrips * 5 * pitch + estep;  // doubles per step: T, T', edge rows
-    // thread 0 draws the NEXT ticket while the current tile is computed (the draw is a round trip to the device's atomics)
-    unsigned next = 0;
-    if (threadIdx.x == 0) next = __hip_atomic_fetch_add(pa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        __syncthreads();  // the previous tile is done with the LDS
-        if (threadIdx.x == 0) {
-            s_ticket = next;
-            s_abort = 0;
-            if (next < total) next = __hip_atomic_fetch_add(pa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const unsigned t = s_ticket;
-        if (t >= total) break;
-        const int step = t / per_step, r = t - step * per_step, strip = r / row, r2 = r - strip * row, z = r2 / tiles_x, tbx = r2 - z * tiles_x;
-        if (step > 0) {
-            if (wave == 0) {  // lane l watches strip l of the step before
-                const unsigned *c = pa.cnt + ((size_t)z * pa.nsteps + (step - 1)) * nstrips;
-                const bool need = lane <= min(strip + 1, nstrips - 1);
-                unsigned polls = 0;
-                for (;;) {
-                    const unsigned v = need ? __hip_atomic_load(c + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)tiles_x;
-                    if (__builtin_amdgcn_ballot_w64(v != (unsigned)tiles_x) == 0) break;
-                    if (++polls > pa.spin_limit || __hip_atomic_load(pa.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        if (lane == 0) {
-                            __hip_atomic_store(pa.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s_abort = 1;
-                        }
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            __syncthreads();
-            if (s_abort) break;
-        }
-        HaloArgs ha = {step > 0 ? pa.T + (size_t)(step - 1) * tstep : nullptr, pa.T + (size_t)step * tstep,
-                       step > 0 ? (const float *)(pa.T + (size_t)step * tstep - estep) : nullptr, (float *)(pa.T + (size_t)(step + 1) * tstep - estep),
-                       nstrips, so, pair_vsum};
-        const float *Min = (step - 1) & 1 ? M1 : M0;
-        float *Mout = step & 1 ? M1 : M0;
-        if (step == 0) halo_tile<FIRST, RW, NW, false, true, true, true>(lds, R0, R1, nullptr, Mout, fin, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
-        else if (step < pa.nsteps - 1) halo_tile<kHaloIter, RW, NW, false, true, true, true>(lds, R0, R1, Min, Mout, fin, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
-        else halo_tile<kHaloLast, RW, NW, false, false, true, true>(lds, R0, R1, Min, nullptr, fout, pr, w, h, pitch, scale, ha, pair_stride, tbx, strip, z);
-        if (step < pa.nsteps - 1) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wavefront's write-through stores (rows of M, strip sums) have completed
-            __syncthreads();
-            if (threadIdx.x == 0)
-                __hip_atomic_fetch_add(pa.cnt + ((size_t)z * pa.nsteps + step) * nstrips + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ host-side geometry (optflowgf.cpp calc())
 
 int num_levels(int w, int h, double pyr_scale, int levels) {
@@ -2945,27 +2236,23 @@ struct Layout {
     size_t img = 0;        // floats between the pyramid images of consecutive frames
     size_t cflow = 0;      // floats of ONE coarse flow field (two per pair)
     size_t vsum = 0;       // doubles between the column-sum scratch of consecutive pairs
-    unsigned ctr = 0;      // fold counters per pair (after the column-sum scratch of all pairs)
-    double *vsum_ptr = nullptr;    // column-sum scratch / fold counters of the first pair of the launch group (set by the level walk)
-    unsigned *ctr_ptr = nullptr;
+    double *vsum_ptr = nullptr;    // column-sum scratch of the first pair of the launch group (set by the level walk)
     size_t planes_bytes() const { return sizeof(float) * planes * n; }
     size_t tmp_bytes() const { return sizeof(float) * (t1 + 2 * (size_t)n * img); }
     size_t flow_bytes() const { return sizeof(float) * 2 * cflow * n; }
-    size_t vsum_bytes() const { return sizeof(double) * vsum * n + sizeof(unsigned) * (size_t)ctr * n; }
+    size_t vsum_bytes() const { return sizeof(double) * vsum * n; }
 };
 
 
 
-// f64 scratch of the OpenCV-order / Gaussian window kernels for one pair at geometry w x h: the largest of
+// f64 scratch of the OpenCV-order / Gaussian window kernels for one pair at geometry w x h: the larger of
 //   serial column scan / Gaussian vertical pass   5 * pitch * h values
-//   carry pre-pass                                (strips of >= 2 rows + up to 8 group totals + 1) * 5 * pitch
-//   folded carries                                3 * (strips of >= 12 rows + 1) * 5 * pitch
-//   overlapped strips                             4 * (strips of >= 9 rows + 1) * 5 * pitch
+//   overlapped strips                             4 * (strips of >= 9 rows + 1) * 5 * pitch + the edge rows (the column-owning form uses the edge rows only)
 size_t vsum_doubles(int w, int h) {
     const size_t pitch = (size_t)plane_pitch(w);
-    const size_t a = 5 * pitch * h, b = (size_t)(ofxcv_div_up(h, 2) + 10) * 5 * pitch, c = 3 * (size_t)(ofxcv_div_up(h, 12) + 1) * 5 * pitch;
+    const size_t a = 5 * pitch * h;
     const size_t d = 4 * (size_t)(ofxcv_div_up(h, 9) + 1) * 5 * pitch + 16 * pitch;  // overlapped strips: T, T' and the edge rows, two buffers
-    return round_up(std::max(std::max(a, d), std::max(b, c)), 32);
+    return round_up(std::max(a, d), 32);
 }
 
 int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, int levels, Layout &L) {
@@ -2990,7 +2277,6 @@ int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, 
         L.cflow = round_up((size_t)lw * lh * 2, 64);
     }
     L.vsum = vsum_doubles(width, height);
-    L.ctr = (unsigned)round_up((size_t)ofxcv_div_up(width, kSsW) + 1, 2);
     return OFXCV_OK;
 }
 
@@ -3094,54 +2380,11 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
     const int pitch = plane_pitch(w);
-    if (ctx->fb_opencv_rounding == 1 && winsize == 3) {
-        // strip-parallel OpenCV-order window: carries of the column running sums, then the iteration itself
-        const int tiles_x = ofxcv_div_up(w, kSsW);
-        int rw = ctx->fb_strict_rows;
-        if (rw != 2 && rw != 4 && rw != 8 && rw != 16) {
-            const long nt = (long)tiles_x * L.n;  // a batch fills the chip with fewer, longer wavefronts
-            rw = nt * ofxcv_div_up(h, 8) >= 4096 ? 8 : (nt * ofxcv_div_up(h, 4) >= 2048 ? 4 : 2);
-        }
-        const int nstrips = ofxcv_div_up(h, rw), G = std::max(ofxcv_div_up(nstrips, 16 * kSsSPW), std::min(ctx->fb_carry_groups, 8)), spg = ofxcv_div_up(nstrips, G), spw = ofxcv_div_up(spg, 16);
-        double *carry = L.vsum_ptr, *gtot = carry + (size_t)nstrips * 5 * pitch;  // reserved by the caller
-        dim3 cgrid(ofxcv_div_up(w, 64), 5 * L.n, G), grid(ofxcv_div_up(tiles_x, 2), nstrips, L.n);
-#define OFXCV_LAUNCH_SS(RW)                                                                                                              \
-    do {                                                                                                                                 \
-        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-        hipLaunchKernelGGL(vsum_carry_kernel<RW>, cgrid, dim3(1024), 0, s, Min, w, h, pitch, carry, gtot, nstrips, spg, spw, L.planes, L.vsum); \
-        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-        if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-        if (update && pairs)                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 2>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
-        else if (update && pipe)                                                                                                         \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 1>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
-        else if (update)                                                                                                                 \
-            hipLaunchKernelGGL((iterate3s_kernel<true, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
-        else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3s_kernel<false, RW, 0>), grid, dim3(128), lds_pad, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, \
-                               (const double *)carry, (const double *)gtot, spg, L.planes, L.vsum);                                      \
-        if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;                                                                      \
-    } while (0)
-        const int mark = ctx->prof_now ? ctx->prof_on : 0;  // measurement hook: 1 = the iteration kernel, 2 = the carry pre-pass
-        const size_t lds_pad = (size_t)ctx->fb_lds_pad;     // A/B: unused dynamic LDS that limits the resident workgroups per CU
-        int rc;
-        const bool pipe = !(ctx->fb_strict_variant & 1), pairs = (ctx->fb_strict_variant & 2) != 0;
-        if (rw == 16) OFXCV_LAUNCH_SS(16);
-        else if (rw == 8) OFXCV_LAUNCH_SS(8);
-        else if (rw == 4) OFXCV_LAUNCH_SS(4);
-        else OFXCV_LAUNCH_SS(2);
-#undef OFXCV_LAUNCH_SS
-        OFXCV_LAUNCH_CHECK(ctx, "iterate3s_kernel");
-        return OFXCV_OK;
-    }
     for (int z = 0; z < L.n; z++) {  // the other window forms: pair by pair
         const float *r0 = R0 ? R0 + (size_t)z * L.planes : nullptr, *r1 = R1 ? R1 + (size_t)z * L.planes : nullptr, *mi = Min + (size_t)z * L.planes;
         float *mo = Mout ? Mout + (size_t)z * L.planes : nullptr, *flow = flows.p[z];
         const size_t flow_step = flows.step[z];
-        if (ctx->fb_opencv_rounding && winsize == 3) {  // 2: the serial column scan (cross-check of the strip-parallel form)
+        if (ctx->fb_opencv_rounding && winsize == 3) {  // OpenCV's order as a serial column scan: mode 2 (cross-check of the strip-parallel forms) and the stage-level entry point
             double *V = L.vsum_ptr + (size_t)z * L.vsum;  // reserved by the caller
             hipLaunchKernelGGL(strict_colscan_kernel, dim3(ofxcv_div_up(w, 256), 5), dim3(256), 0, s, mi, w, h, pitch, V);
             OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
@@ -3208,170 +2451,6 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
         else
             hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t);
         OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
-    }
-    return OFXCV_OK;
-}
-
-// OpenCV-order window with the carries folded into the iteration kernel (winsize 3).  Strip geometry by level size
-// (of the whole batch: what matters is how many workgroups a launch has).
-struct FoldGeom {
-    int rw, nw, tiles_x, nstrips, sh;
-    bool var;  // strips of sh rows with rw - 1 or rw rows per wavefront (wave_rows)
-};
-bool fold_level_is_large(const ofxcv_ctx *ctx, int w, int h, int n) {  // bandwidth-bound level
-    return (long)ofxcv_div_up(w, kSsW) * ofxcv_div_up(h, 64) * n >= ctx->fb_fold_min_tiles;
-}
-FoldGeom fold_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
-    FoldGeom g;
-    g.tiles_x = ofxcv_div_up(w, kSsW);
-    const bool large = fold_level_is_large(ctx, w, h, n);
-    g.nw = (large && !ctx->fb_fold_nw4) ? 8 : 4;  // 4 wavefronts per workgroup where 8 would leave CUs without a second workgroup
-    // 4 rows per wavefront: 7 rows of M in registers leave room for the pipelined gather (8 rows: 918 -> 900 pairs/s at 1080p)
-    g.rw = (long)g.tiles_x * ofxcv_div_up(h, 32) * n >= 128 ? 4 : 3;
-    if (large && (ctx->fb_fold_rows == 3 || ctx->fb_fold_rows == 8)) g.rw = ctx->fb_fold_rows;
-    g.sh = g.rw * g.nw;
-    g.var = false;
-    if (large && ctx->fb_fold_nw != 8) {
-        // Tall wavefronts (default on the bandwidth-bound levels): four wavefronts of 8 or 9 rows, all solves of a wavefront
-        // before its first gather.  Every wavefront re-reads three rows of M above / below its own (11 rows for 8 instead of
-        // 7 for 4) and pays the strip-sum exchange and the row-difference tail once: measured against the eight-wavefront
-        // form of 4 / 5 rows 38.5 -> 36.3 us per level-0 iteration at 1920x1080, 182 -> 167-173 us at 3840x2160, 980 ->
-        // 1000-1040 pairs/s with several calls in flight (profiles/r03_experiments.md).  Option farneback.fold_nw: 4 = 8 rows
-        // fixed, 8 = the eight-wavefront forms.
-        g.nw = 4;
-        g.rw = ctx->fb_fold_nw == 4 ? 8 : 9;
-        g.var = g.rw == 9;
-        g.sh = 32;
-        if (g.var) {  // strip height 33 .. 36 by the launch's rounds over the resident slots (four 4-wavefront workgroups per CU)
-            const double slots = 4.0 * ctx->num_cus;
-            double best_cost = 0;
-            for (int sh = 33; sh <= 36; sh++) {
-                if (ctx->fb_fold_strip >= 33 && ctx->fb_fold_strip <= 36 && sh != ctx->fb_fold_strip) continue;
-                const double r = (double)g.tiles_x * ofxcv_div_up(h, sh) * n / slots, full = std::floor(r), frac = r - full;
-                const double cost = sh * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0));
-                if (best_cost == 0 || cost < best_cost) {
-                    best_cost = cost;
-                    g.sh = sh;
-                }
-            }
-        }
-        g.nstrips = ofxcv_div_up(h, g.sh);
-        return g;
-    }
-    if (large && g.nw == 8 && g.rw == 4 && ctx->fb_fold_strip != 32) {
-        // Strip height 32 .. 40 (4 or 5 rows per wavefront) by the number of rounds the launch makes over the resident
-        // workgroup slots (two 8-wavefront workgroups per CU): a round that is nearly empty costs almost a full one.
-        const double slots = 2.0 * ctx->num_cus;
-        int best = 32;
-        double best_cost = 0;
-        for (int sh = 32; sh <= 40; sh++) {
-            if (ctx->fb_fold_strip >= 33 && ctx->fb_fold_strip <= 40 && sh != ctx->fb_fold_strip) continue;
-            const double r = (double)g.tiles_x * ofxcv_div_up(h, sh) * n / slots, full = std::floor(r), frac = r - full;
-            const double cost = sh * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0)) * (sh > 32 ? 1.02 : 1.0);
-            if (best_cost == 0 || cost < best_cost) {
-                best_cost = cost;
-                best = sh;
-            }
-        }
-        if (best > 32) {
-            g.sh = best;
-            g.rw = 5;
-            g.var = true;
-        }
-    }
-    g.nstrips = ofxcv_div_up(h, g.sh);
-    return g;
-}
-struct FoldScratch {  // carved from ctx->fb_vsum by the caller (pair 0's; pair z lies L.vsum doubles / L.ctr counters further)
-    double *K[2], *Spart;
-    unsigned *counters;
-};
-FoldScratch fold_scratch(ofxcv_ctx *ctx, int w0, int h0, const Layout &L) {  // sized for the level-0 geometry (the largest)
-    const size_t n = (size_t)(ofxcv_div_up(h0, 3 * 4) + 1) * 5 * plane_pitch(w0);  // upper bound over all levels (strips of >= 12 rows)
-    FoldScratch fs;
-    double *base = L.vsum_ptr;
-    fs.K[0] = base;
-    fs.K[1] = base + n;
-    fs.Spart = base + 2 * n;
-    fs.counters = L.ctr_ptr;
-    return fs;
-}
-int launch_fold_seed(ofxcv_ctx *ctx, hipStream_t s, const float *M, int w, int h, const FoldScratch &fs, int kslot, const Layout &L) {
-    const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {nullptr, fs.K[kslot], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh};
-    dim3 grid(g.tiles_x, g.nstrips, L.n);
-    const int pitch = plane_pitch(w);
-    if (g.nw == 4 && g.rw == 8) {
-        hipLaunchKernelGGL((vsum_seed_kernel<8, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
-    } else if (g.nw == 4 && g.rw == 9) {
-        hipLaunchKernelGGL((vsum_seed_kernel<9, 4, true>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
-    } else if (g.var) {
-        hipLaunchKernelGGL((vsum_seed_kernel<5, 8, true>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-    } else if (g.nw == 8) {
-        if (g.rw == 8) hipLaunchKernelGGL((vsum_seed_kernel<8, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-        else if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 8, false>), grid, dim3(512), 0, s, M, w, h, pitch, fa, L.planes);
-    } else {
-        if (g.rw == 4) hipLaunchKernelGGL((vsum_seed_kernel<4, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
-        else hipLaunchKernelGGL((vsum_seed_kernel<3, 4, false>), grid, dim3(256), 0, s, M, w, h, pitch, fa, L.planes);
-    }
-    OFXCV_LAUNCH_CHECK(ctx, "vsum_seed_kernel");
-    if (!fa.scan_in_kernel) {
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, M, w, h, pitch, g.sh, fa, L.planes);
-        OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
-    }
-    return OFXCV_OK;
-}
-int launch_fold_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
-                          int w, int h, bool update, const FoldScratch &fs, int kslot, const Layout &L) {
-    const FoldGeom g = fold_geom(ctx, w, h, L.n);
-    FoldArgs fa = {fs.K[kslot], fs.K[kslot ^ 1], fs.Spart, fs.counters, g.nstrips, ctx->fb_fold_carries == 1, L.vsum, L.ctr, g.sh};
-    dim3 grid(g.tiles_x, g.nstrips, L.n);
-    const int pitch = plane_pitch(w);
-    const double scale = 1. / 9.;
-    int rc;
-    const int mark = ctx->prof_now ? ctx->prof_on : 0;
-    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-#define OFXCV_LAUNCH_FOLD(RW, NW, VAR)                                                                                                   \
-    do {                                                                                                                                 \
-        if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW, VAR>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
-        else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW, VAR>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
-    } while (0)
-#define OFXCV_LAUNCH_TALL(RW, NW, VAR)                                                                                                   \
-    do {                                                                                                                                 \
-        if (update)                                                                                                                      \
-            hipLaunchKernelGGL((iterate3f_kernel<true, RW, NW, VAR, true>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
-        else                                                                                                                             \
-            hipLaunchKernelGGL((iterate3f_kernel<false, RW, NW, VAR, false>), grid, dim3(64 * NW), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes); \
-    } while (0)
-    if (g.nw == 4 && g.rw == 8) {  // four wavefronts of 8 rows
-        OFXCV_LAUNCH_TALL(8, 4, false);
-    } else if (g.nw == 4 && g.rw == 9) {  // ... of 8 or 9 rows
-        OFXCV_LAUNCH_TALL(9, 4, true);
-    } else if (g.var && update && ctx->fb_solves_first) {
-        hipLaunchKernelGGL((iterate3f_kernel<true, 5, 8, true, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes);
-    } else if (g.var) {
-        OFXCV_LAUNCH_FOLD(5, 8, true);
-    } else if (g.nw == 8 && g.rw == 4 && update && ctx->fb_solves_first) {
-        hipLaunchKernelGGL((iterate3f_kernel<true, 4, 8, false, true>), grid, dim3(512), 0, s, R0, R1, Min, Mout, flows, w, h, pitch, scale, fa, L.planes);
-    } else if (g.nw == 8) {
-        if (g.rw == 8) OFXCV_LAUNCH_FOLD(8, 8, false);
-        else if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 8, false);
-        else OFXCV_LAUNCH_FOLD(3, 8, false);
-    } else {
-        if (g.rw == 4) OFXCV_LAUNCH_FOLD(4, 4, false);
-        else OFXCV_LAUNCH_FOLD(3, 4, false);
-    }
-#undef OFXCV_LAUNCH_FOLD
-    OFXCV_LAUNCH_CHECK(ctx, "iterate3f_kernel");
-    if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-    if (update && !fa.scan_in_kernel) {
-        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-        hipLaunchKernelGGL(fold_scan_kernel, dim3(g.tiles_x, 5, L.n), dim3(64 * kScanQ), 0, s, (const float *)Mout, w, h, pitch, g.sh, fa, L.planes);
-        OFXCV_LAUNCH_CHECK(ctx, "fold_scan_kernel");
-        if (mark == 2 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
     }
     return OFXCV_OK;
 }
@@ -3481,45 +2560,6 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 #undef OFXCV_LAUNCH_HALO_K
     OFXCV_LAUNCH_CHECK(ctx, "iterate3h_kernel");
     if (mark == 1 && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-    return OFXCV_OK;
-}
-
-// All steps of a small level in one launch (iterate3p_kernel).  Used where the overlapped-strip form would take its small
-// geometry of eight 3- or 2-row wavefronts, at most 64 strips (one lane of the waiting wavefront per strip) and the strip sums
-// of every step fit the pair's f64 scratch.
-bool persist_level(const ofxcv_ctx *ctx, const Layout &L, int w, int h, int gn, int iterations, bool halo) {
-    if (!halo || !ctx->fb_persist || ctx->prof_on) return false;
-    const HaloGeom g = halo_geom(ctx, w, h, gn);
-    if (g.nw != 8 || (g.rw != 3 && g.rw != 2) || g.nstrips > 64) return false;
-    return (size_t)(iterations + 1) * (2 * (size_t)g.nstrips * 5 * plane_pitch(w) + halo_edge_doubles(w)) <= L.vsum;
-}
-size_t persist_words(const ofxcv_ctx *ctx, int w, int h, int gn, int iterations) {  // ticket (+ padding) and the step / strip counters of one launch
-    const HaloGeom g = halo_geom(ctx, w, h, gn);
-    return 16 + round_up((size_t)gn * (iterations + 1) * g.nstrips, 16);
-}
-constexpr size_t kPersistHead = 16;  // unsigned words in front of the first launch's region: [0] = the abort flag (sticky)
-int launch_persistent_level(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, float *M0, float *M1, const FlowTab &fin, const FlowTab &fout,
-                            const Prolong &pr, int w, int h, int first_kind, int iterations, unsigned *words, const Layout &L) {
-    const HaloGeom g = halo_geom(ctx, w, h, L.n);
-    PersistArgs pa = {words, words + 16, (unsigned *)ctx->fb_persist_buf.ptr, L.vsum_ptr, iterations + 1, (unsigned)ctx->fb_persist_spin};
-    const int per_step = g.tiles_x * g.nstrips * L.n;
-    const int nwg = std::max(1, std::min(2 * per_step, 2 * ctx->num_cus));
-    const int pitch = plane_pitch(w);
-    const double scale = 1. / 9.;
-#define OFXCV_LAUNCH_P(FIRST, RW) \
-    hipLaunchKernelGGL((iterate3p_kernel<FIRST, RW, 8>), dim3(nwg), dim3(512), 0, s, R0, R1, M0, M1, fin, fout, pr, w, h, pitch, scale, g.nstrips, g.so, \
-                       g.tiles_x, L.n, L.planes, L.vsum, pa)
-    if (g.rw == 3) {
-        if (first_kind == kHaloZero) OFXCV_LAUNCH_P(kHaloZero, 3);
-        else if (first_kind == kHaloCoarse) OFXCV_LAUNCH_P(kHaloCoarse, 3);
-        else OFXCV_LAUNCH_P(kHaloGiven, 3);
-    } else {
-        if (first_kind == kHaloZero) OFXCV_LAUNCH_P(kHaloZero, 2);
-        else if (first_kind == kHaloCoarse) OFXCV_LAUNCH_P(kHaloCoarse, 2);
-        else OFXCV_LAUNCH_P(kHaloGiven, 2);
-    }
-#undef OFXCV_LAUNCH_P
-    OFXCV_LAUNCH_CHECK(ctx, "iterate3p_kernel");
     return OFXCV_OK;
 }
 
@@ -3699,11 +2739,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     float *I = T1 + L.t1;
     float *cflow[2] = {(float *)ctx->fb_flow.ptr, (float *)ctx->fb_flow.ptr + L.cflow};
 
-    // tickets and counters of the persistent small-level launches (regions handed out in launch order; the abort flag in
-    // front of them is sticky)
-    size_t pwords = kPersistHead;
-    if (ctx->fb_persist_buf.bytes > kPersistHead * sizeof(unsigned))
-        OFXCV_HIP_CHECK(ctx, hipMemsetAsync((unsigned *)ctx->fb_persist_buf.ptr + kPersistHead, 0, ctx->fb_persist_buf.bytes - kPersistHead * sizeof(unsigned), s));
     // fork: the preparation stream starts once the inputs are ready on the main stream
     OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, s));
     OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(sp, ctx->ev_fork, 0));
@@ -3751,7 +2786,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
     FlowTab prev_all = {};
     bool have_prev = false;
     int pw = 0, ph = 0;
-    bool counters_clear = false;
     bool rgba_fused[kMaxBatch] = {};  // F7 of the pair was done by the last level-0 launch (overlapped-strip form); otherwise it follows as its own launch
     hipStream_t s_main = s;
     const bool use_coarse = ctx->coarse && levels > 0 && sp != s && !profile;
@@ -3774,7 +2808,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         // the column-owning form streams every pair of the call through one launch (a workgroup per tile column and pair; the
         // fields are read once per two iterations, so the Infinity-Cache grouping below has nothing to keep on the die)
-        const bool col = col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries >= 4);
+        const bool col = col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian);
         const int per_group = col ? n : ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
         const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
@@ -3783,18 +2817,14 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             Layout G = L;  // this group's view of the scratch: its first pair is "pair 0" of every launch
             G.n = gn;
             G.vsum_ptr = (double *)ctx->fb_vsum.ptr + (size_t)z0 * L.vsum;
-            G.ctr_ptr = (unsigned *)((double *)ctx->fb_vsum.ptr + L.vsum * L.n) + (size_t)z0 * L.ctr;
             const size_t po = (size_t)z0 * L.planes;
             float *M0 = Mbuf[0] + po, *M1 = Mbuf[1] + po;
             const float *R0 = R[k][0] + po, *R1 = R[k][1] + po;
             float *Mg[2] = {M0, M1};
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4), gn), block(64, 4);
             const FlowTab out_tab = sub_tab(out_all, z0, gn);
-            // OpenCV-order window with the carries folded into the iteration kernel (fold) / with overlapped strips (halo)
-            const bool fold = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries && ctx->fb_fold_carries < 4 &&
-                              (ctx->fb_fold_carries != 3 || fold_level_is_large(ctx, w, h, gn));  // 3: only the levels that are bandwidth-bound
-            const bool halo = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian && ctx->fb_fold_carries >= 4 &&
-                              (ctx->fb_fold_carries != 5 || fold_level_is_large(ctx, w, h, gn));  // 5: only the bandwidth-bound levels
+            // OpenCV-order window (the library default): overlapped strips, or -- above -- column-owning workgroups
+            const bool halo = ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian;
             // halo: the level's first field, its strip sums and edge rows come from the iteration kernel's "first" forms in one launch
             const bool halo_first = halo;
             HaloScratch hs = {};
@@ -3851,32 +2881,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                 }
                 continue;
             }
-            const bool persist = persist_level(ctx, L, w, h, gn, iterations, halo) && !profile;
-            if (persist && (pwords + persist_words(ctx, w, h, gn, iterations)) * sizeof(unsigned) <= ctx->fb_persist_buf.bytes) {
-                unsigned *words = (unsigned *)ctx->fb_persist_buf.ptr + pwords;
-                pwords += persist_words(ctx, w, h, gn, iterations);
-                if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
-                    FlowTab init = sub_tab(out, z0, gn);
-                    if (k > 0) {
-                        double scale = 1;
-                        for (int i = 0; i < k; i++) scale *= pyr_scale;
-                        init = sub_tab(coarse_tab(cflow[(k & 1) ^ 1], (size_t)w * 8), z0, gn);
-                        for (int z = 0; z < gn; z++) {
-                            hipLaunchKernelGGL(initial_flow_kernel, dim3(grid.x, grid.y), block, 0, s, (const float *)out.p[z0 + z], out.step[z0 + z], width, height,
-                                               init.p[z], w, h, scale);
-                            OFXCV_LAUNCH_CHECK(ctx, "initial_flow_kernel");
-                        }
-                    }
-                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, init, out_tab, no_pr, w, h, kHaloGiven, iterations, words, G);
-                } else if (!have_prev) {
-                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, no_flow, out_tab, no_pr, w, h, kHaloZero, iterations, words, G);
-                } else {
-                    const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
-                    rc = launch_persistent_level(ctx, s, R0, R1, M0, M1, sub_tab(prev_all, z0, gn), out_tab, pr, w, h, kHaloCoarse, iterations, words, G);
-                }
-                if (rc) return rc;
-                continue;
-            }
             if (!have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW)) {
                 // the caller's flow, area-resized to the top level and scaled; at k == 0 it is the flow buffer itself
                 FlowTab init = sub_tab(out, z0, gn);
@@ -3904,20 +2908,10 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             if (halo_first && rc) return rc;
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
             int cur = 0;
-            FoldScratch fs = {};
-            if (fold) {
-                fs = fold_scratch(ctx, width, height, G);
-                if (!counters_clear) {
-                    OFXCV_HIP_CHECK(ctx, hipMemsetAsync((double *)ctx->fb_vsum.ptr + L.vsum * L.n, 0, sizeof(unsigned) * (size_t)L.ctr * n, s));
-                    counters_clear = true;
-                }
-                rc = launch_fold_seed(ctx, s, M0, w, h, fs, 0, G);
-                if (rc) return rc;
-            }
             for (int i = 0; i < iterations;) {
                 const bool pair = fuse && i + 2 <= iterations - 1;
                 const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
-                const bool inner = prof && !pair && !gaussian && ctx->fb_opencv_rounding == 1 && winsize == 3;  // marks set around the kernels inside
+                const bool inner = prof && halo && !pair;  // marks set around the kernel inside launch_halo_iteration
                 ctx->prof_now = inner;
                 if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
                 if (pair) {  // two updating iterations in one launch
@@ -3944,9 +2938,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                             }
                         }
                         rc = launch_halo_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, no_pr, w, h, update ? kHaloIter : kHaloLast, hs, cur, G, sink ? &rg : nullptr);
-                    } else if (fold)
-                        rc = launch_fold_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, update, fs, cur, G);
-                    else
+                    } else
                         rc = launch_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
                     i += 1;
                 }
@@ -4049,30 +3041,6 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         if (rc) return rc;
         OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, kColFlagBytes, s));
     }
-    if (ctx->fb_persist && ctx->fb_opencv_rounding == 1 && winsize == 3 && ctx->fb_fold_carries >= 4 && !(flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN)) {
-        // tickets and counters of the persistent small-level launches: the same walk over levels and launch groups as enqueue_farneback
-        size_t words = kPersistHead;
-        const size_t budget = (size_t)std::max(1, ctx->fb_batch_mb) << 20;
-        for (int k = levels; k >= 0; k--) {
-            int w, h, ksz;
-            double sigma;
-            level_geom(width, height, pyr_scale, k, w, h, sigma, ksz);
-            const size_t level_bytes = 4 * sizeof(float) * 5 * (size_t)plane_pitch(w) * h;
-            const int fit = (int)std::min<size_t>((size_t)n, std::max<size_t>(1, budget / level_bytes));
-            const int per_group = ofxcv_div_up(n, ofxcv_div_up(n, fit));
-            for (int z0 = 0; z0 < n; z0 += per_group) {
-                const int gn = std::min(per_group, n - z0);
-                const bool halo = ctx->fb_fold_carries != 5 || fold_level_is_large(ctx, w, h, gn);
-                if (persist_level(ctx, L, w, h, gn, iterations, halo)) words += persist_words(ctx, w, h, gn, iterations);
-            }
-        }
-        if (words > kPersistHead) {
-            const bool fresh = ctx->fb_persist_buf.bytes < words * sizeof(unsigned);
-            rc = ofxcv_reserve(ctx, ctx->fb_persist_buf, words * sizeof(unsigned));
-            if (rc) return rc;
-            if (fresh) OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_persist_buf.ptr, 0, kPersistHead * sizeof(unsigned), s));  // the abort flag
-        }
-    }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;
     hipStream_t sp = ctx->fb_one_stream ? s : ctx->prep;
@@ -4099,7 +3067,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
     key.n = n;
     key.width = width; key.height = height; key.levels = levels; key.winsize = winsize; key.iterations = iterations; key.poly_n = poly_n; key.flags = flags;
     key.pyr_scale = pyr_scale; key.poly_sigma = poly_sigma;
-    key.planes = ctx->fb_planes.ptr; key.tmp = ctx->fb_tmp.ptr; key.cflow = ctx->fb_flow.ptr; key.vsum = need_vsum ? ctx->fb_vsum.ptr : nullptr; key.persist = ctx->fb_persist_buf.ptr;
+    key.planes = ctx->fb_planes.ptr; key.tmp = ctx->fb_tmp.ptr; key.cflow = ctx->fb_flow.ptr; key.vsum = need_vsum ? ctx->fb_vsum.ptr : nullptr;
     for (int z = 0; z < n; z++) {
         key.prev[z] = d_prev[z]; key.next[z] = d_next[z]; key.flow[z] = d_flow[z];
         key.prev_step[z] = prev_step[z]; key.next_step[z] = next_step[z]; key.flow_step[z] = flow_step[z];

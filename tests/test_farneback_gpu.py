@@ -254,7 +254,7 @@ def test_default_mode_is_opencv_order(oracle, ofxcv, gpu_ctx, strict_ctx):
 @pytest.fixture()
 def strict_ctx(ofxcv):
     """a context in the OpenCV-order mode: the box window evaluated with the reference's running sums (every vertical row
-    difference rounded to f32 before it enters the f64 column sum), strip-parallel (carry pre-pass + row walker)"""
+    difference rounded to f32 before it enters the f64 column sum), strip-parallel"""
     ctx = ofxcv.Context(0)
     ctx.set_option("farneback.opencv_rounding", 1)
     yield ctx
@@ -284,114 +284,99 @@ def test_opencv_order_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx
     _strict_vs_faithful(oracle, strict_ctx, w, h)
 
 
-@pytest.mark.parametrize("rows", [2, 4, 8])
-def test_opencv_order_mode_strip_heights_and_serial_scan_agree(oracle, ofxcv, rows):
-    """the strip height only changes where the f64 column sums are cut: same result for 2/4/8 rows per wavefront, several
-    carry groups, the unpipelined variant, and the serial one-thread-per-column scan (mode 2)"""
-    ga, gb = _gray_pair(oracle, 333, 257)
-    outs = []
-    for opts in [dict(opencv_rounding=2), dict(opencv_rounding=1, strict_rows=rows), dict(opencv_rounding=1, strict_rows=rows, carry_groups=3, strict_variant=1)]:
-        ctx = ofxcv.Context(0)
-        for k, v in opts.items():
-            ctx.set_option("farneback." + k, v)
-        outs.append(ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy())
-        ctx.close()
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+# the three evaluations of OpenCV's running sums the library has: mode 2 (serial column scan, the independent cross-check), the
+# overlapped-strip form and the column-owning form (farneback.col_min 1 forces it on every level of any frame)
+_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_geom=1))
+# strip / wavefront geometries of the overlapped-strip form the library otherwise picks by level size
+_HALO_GEOMS = (dict(halo_geom=1), dict(halo_geom=2), dict(halo_geom=3), dict(halo_geom=2, halo_strip=33), dict(halo_geom=2, halo_strip=35),
+               dict(halo_geom=3, halo_strip=65), dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=70), dict(halo_geom=3, halo_strip=72),
+               dict(halo_small=2), dict(halo_small=4), dict(halo_small=5), dict(halo_small=6), dict(halo_min5=1))
+
+
+def _flow_with(ofxcv, opts, ga, gb, *args, twice=False, **kw):
+    ctx = ofxcv.Context(0)
+    for k, v in opts.items():
+        ctx.set_option("farneback." + k, v)
+    for _ in range(2 if twice else 1):   # twice: the second call replays the captured graph
+        a = tuple(_dev(x.copy()) for x in args)
+        got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), *a, **kw).cpu().numpy()
+    assert ctx.get_option("farneback.col_aborts") == 0
+    ctx.close()
+    return got
 
 
 @pytest.mark.parametrize("w,h", [(125, 70), (333, 257), (640, 480), (1920, 1080)])
-def test_opencv_order_mode_folded_carry_variants_agree(oracle, ofxcv, w, h):
-    """the carries of the f64 column sums from a pre-pass over M (farneback.fold_carries 0), produced by the iteration kernel
-    itself (1: prefix over the strips by the last workgroup of a tile column, an atomic counter, device-scope loads; 2: by a small
-    launch of its own; 3: 2 on the large pyramid levels, the pre-pass on the small ones) or from overlapped strips whose sums the
-    next launch adds up in its prologue (4, the default: one launch per iteration; 5: 4 on the large levels only): the same flow
-    bit for bit, within tolerance of the faithful oracle at every sample"""
+def test_opencv_order_mode_forms_agree(oracle, ofxcv, w, h):
+    """OpenCV's running sums as a serial column scan (mode 2), strip-parallel with overlapped strips (one launch per iteration, every
+    strip / wavefront geometry) and with column-owning workgroups (two steps per launch, both row geometries): the same flow bit for
+    bit, within tolerance of the faithful oracle at every sample; no bounded wait of the column-owning kernel ever ran out"""
     ga, gb = _gray_pair(oracle, w, h)
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
-    outs = []
-    for fold in (0, 1, 2, 3, 4, 5):
-        ctx = ofxcv.Context(0)
-        ctx.set_option("farneback.fold_carries", fold)
-        for _ in range(2):   # twice: the tile-column counters must be back at zero after a call
-            got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
-        ctx.close()
-        assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), fold
-        outs.append(got)
+    outs = [_flow_with(ofxcv, opts, ga, gb, twice=True) for opts in _FORMS]
+    assert (np.abs(outs[0] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
-    # geometry of the folded kernel on the large levels: four wavefronts of 8 or 9 rows (default), of 8 rows, eight wavefronts
-    # of 4 / 5 rows with and without the solves-first order; fold_min 1 makes every level of these frames a "large" one
-    for opts in (dict(fold_nw=4), dict(fold_nw=8), dict(fold_nw=8, solves_first=1), dict(fold_nw=8, fold_strip=32), dict(fold_min=1),
-                 dict(fold_min=1, fold_nw=4), dict(fold_min=1, fold_nw=8), dict(fold_strip=35),
-                 # overlapped strips (one launch per iteration): four wavefronts of 5 rows, four / eight of 8 or 9, fixed strip heights
-                 dict(fold_carries=4, halo_geom=1), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3),
-                 dict(fold_carries=4, halo_geom=2, halo_strip=33), dict(fold_carries=4, halo_geom=2, halo_strip=35),
-                 dict(fold_carries=4, halo_geom=3, halo_strip=65), dict(fold_carries=4, halo_geom=3, halo_strip=70),
-                 dict(fold_carries=5, fold_min=1, halo_geom=2),
-                 dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=72), dict(halo_small=2), dict(halo_small=4), dict(halo_small=5), dict(halo_small=6), dict(halo_min5=1)):
-        ctx = ofxcv.Context(0)
-        for k, v in opts.items():
-            ctx.set_option("farneback." + k, v)
-        got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
-        ctx.close()
-        assert np.array_equal(got, outs[0]), opts
+    for opts in _HALO_GEOMS:
+        assert np.array_equal(_flow_with(ofxcv, dict(col=0, **opts), ga, gb), outs[0]), opts
 
 
-@pytest.mark.parametrize("w,h,levels", [(333, 257, 3), (160, 120, 0), (640, 480, 2)])
-def test_opencv_order_mode_overlapped_strips_first_matrix_forms(oracle, ofxcv, w, h, levels):
-    """farneback.fold_carries 4: the first M of a level and its strip sums come out of the iteration kernel's "first" forms
-    (zero flow on the coarsest level, the prolongated coarser flow below it, the caller's flow with USE_INITIAL_FLOW) --
-    same result as the carry pre-pass form, with and without an initial flow, for 1 .. 3 iterations"""
+@pytest.mark.parametrize("w,h,levels", [(333, 257, 3), (160, 120, 0), (640, 480, 2), (61, 131, 0), (60, 64, 1), (59, 300, 1)])
+def test_opencv_order_mode_step_pairs_and_first_matrix_forms(oracle, ofxcv, w, h, levels):
+    """The steps of a level -- first M (zero flow on the coarsest level, the prolongated coarser flow below it, the caller's flow with
+    USE_INITIAL_FLOW), iterations - 1 x iterate, last -- in every pairing the column-owning form has: (first, last) for one iteration,
+    (first, iterate) + (last, -) for two, (first, iterate) (iterate, last) for three, an (iterate, iterate) between for four and five;
+    widths of one tile column minus / plus one, heights around a round of 32 rows.  All forms bit for bit, with and without an initial flow."""
     ga, gb = _gray_pair(oracle, w, h)
     rng = np.random.default_rng(5)
     init = rng.normal(0, 2, size=(h, w, 2)).astype(np.float32)
-    for kw in (dict(iterations=1), dict(iterations=2), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
-        outs = []
-        for opts in (dict(fold_carries=0), dict(fold_carries=4), dict(fold_carries=4, halo_geom=2), dict(fold_carries=4, halo_geom=3), dict(fold_carries=4, halo_small=5)):
-            ctx = ofxcv.Context(0)
-            for k, v in opts.items():
-                ctx.set_option("farneback." + k, v)
-            args = (_dev(init.copy()),) if "flags" in kw else ()
-            outs.append(ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), *args, levels=levels, **kw).cpu().numpy())
-            ctx.close()
+    for kw in (dict(iterations=1), dict(iterations=2), dict(iterations=3), dict(iterations=4, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW),
+               dict(iterations=5), dict(iterations=2, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
+        args = (init,) if "flags" in kw else ()
+        outs = [_flow_with(ofxcv, opts, ga, gb, *args, levels=levels, **kw) for opts in _FORMS + (dict(col=0, halo_geom=2), dict(col=0, halo_small=5))]
         assert all(np.array_equal(outs[0], o) for o in outs[1:]), kw
+    ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, levels=levels, iterations=3)
+    got = _flow_with(ofxcv, dict(col_min=1), ga, gb, levels=levels, iterations=3)
+    assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
 
 
-@pytest.mark.parametrize("w,h,n", [(333, 257, 1), (640, 480, 2), (1920, 1080, 1), (125, 70, 3)])
-def test_opencv_order_mode_persistent_small_levels(oracle, ofxcv, w, h, n):
-    """farneback.persist 1 (default): every small pyramid level is ONE launch -- workgroups draw (step, strip, pair, tile) tickets
-    and wait on per-strip completion counters of the step before -- against one launch per iteration (persist 0): the same flow
-    bit for bit, for 1 / 2 / 15 iterations, with an initial flow, with two- and three-row wavefronts, with a single resident
-    workgroup's worth of tickets in flight (graph replay twice); no wait ever runs out of polls."""
+@pytest.mark.parametrize("w,h,n", [(640, 480, 2), (125, 70, 3), (1920, 1080, 8)])
+def test_column_owning_form_batches(oracle, ofxcv, w, h, n):
+    """batches through the column-owning form (one workgroup per tile column and pair): forced on every level (col_min 1) and, for the
+    8 x 1080p batch of the benchmark, as the library picks it (level 0 only) -- equal to single calls through the overlapped strips bit
+    for bit, with an initial flow as well; pair 0 within tolerance of the faithful oracle at every sample"""
     prs = _pairs(oracle, w, h, range(7, 7 + n))
     da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
     rng = np.random.default_rng(9)
     inits = [rng.normal(0, 2, size=(h, w, 2)).astype(np.float32) for _ in prs]
-    for kw in (dict(), dict(iterations=1), dict(iterations=2, levels=2), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
-        outs = []
-        for opts in (dict(persist=0), dict(persist=1), dict(persist=1, halo_small=2), dict(persist=1, halo_geom=1)):
+    for kw in (dict(), dict(iterations=2, levels=2, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
+        ref_ctx = ofxcv.Context(0)
+        ref_ctx.set_option("farneback.col", 0)
+        singles = []
+        for z in range(n):
+            a = (_dev(inits[z].copy()),) if "flags" in kw else ()
+            singles.append(ref_ctx.calc_optical_flow_farneback(da[z], db[z], *a, **kw).cpu().numpy())
+        ref_ctx.close()
+        for opts in (dict(col_min=1), dict()):
             ctx = ofxcv.Context(0)
             for k, v in opts.items():
                 ctx.set_option("farneback." + k, v)
             for _ in range(2):
                 fl = [_dev(i0.copy()) for i0 in inits] if "flags" in kw else None
                 got = [f.cpu().numpy() for f in ctx.calc_optical_flow_farneback_batch(da, db, fl, **kw)]
-            assert ctx.get_option("farneback.persist_aborts") == 0
-            outs.append(got)
+            assert ctx.get_option("farneback.col_aborts") == 0
             ctx.close()
-        for o in outs[1:]:
             for z in range(n):
-                assert np.array_equal(outs[0][z], o[z]), (kw, z)
-    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL, iterations=1)
-    # the last case of outs[0] has an initial flow; check the plain one-iteration result against the oracle instead
+                assert np.array_equal(singles[z], got[z]), (kw, opts, z)
+    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL)
     ctx = ofxcv.Context(0)
-    got = ctx.calc_optical_flow_farneback(da[0], db[0], iterations=1).cpu().numpy()
+    ctx.set_option("farneback.col_min", 1)
+    got = ctx.calc_optical_flow_farneback(da[0], db[0]).cpu().numpy()
     ctx.close()
     assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
 
 
 @pytest.mark.parametrize("w,h", [(1, 1), (2, 3), (3, 2), (7, 5), (17, 4), (64, 1), (1, 64), (130, 9), (9, 130), (63, 22), (33, 24)])
 def test_opencv_order_mode_tiny_frames(oracle, ofxcv, w, h):
-    """frames smaller than a strip, a tile, the three-row reach of a row difference: every carry form gives the same flow as
+    """frames smaller than a strip, a tile, the three-row reach of a row difference: every form gives the same flow as
     the faithful oracle's (levels clip to 0 below 32 pixels), scratch reservations hold (column-sum scratch of
     one-row images)"""
     rng = np.random.default_rng(w * 131 + h)
@@ -399,15 +384,9 @@ def test_opencv_order_mode_tiny_frames(oracle, ofxcv, w, h):
     gb = np.roll(ga, 1, axis=1) if w > 1 else ga.copy()
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, iterations=3)
     outs = []
-    for fold in (0, 2, 4):
-        ctx = ofxcv.Context(0)
-        ctx.set_option("farneback.fold_carries", fold)
-        if fold == 2:
-            ctx.set_option("farneback.fold_min", 1)
-        for _ in range(2):
-            got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb), iterations=3).cpu().numpy()
-        ctx.close()
-        assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), (fold, np.abs(got - ref).max())
+    for opts in _FORMS[:3]:   # frames below 64 rows stay with the overlapped strips even when the column-owning form is forced
+        got = _flow_with(ofxcv, opts, ga, gb, twice=True, iterations=3)
+        assert (np.abs(got - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all(), (opts, np.abs(got - ref).max())
         outs.append(got)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
@@ -605,15 +584,15 @@ def test_batch_equals_single_calls_bit_for_bit(oracle, ofxcv, w, h, n):
 
 def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
     """forward + backward flow of one reference frame (two pairs that share their first image) as a batch, in every
-    evaluation mode of the window (OpenCV order with each carry form, serial scan, direct sums, other window size,
+    evaluation mode of the window (OpenCV order with overlapped strips / column-owning workgroups, serial scan, direct sums, other window size,
     Gaussian window): identical to single calls"""
     w, h = 333, 257
     (a, b), (_, c) = _pairs(oracle, w, h, (5, 6))
     da, db, dc = _dev(a), _dev(b), _dev(c)
-    cases = [dict(opts=dict(opencv_rounding=1, fold_carries=f)) for f in (0, 1, 2, 3, 4, 5)]
-    cases += [dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
-              dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
-              dict(opts=dict(opencv_rounding=1, fold_carries=2, fold_min=1)), dict(opts=dict(opencv_rounding=1, fold_carries=1, fold_min=1))]
+    cases = [dict(opts=dict(opencv_rounding=1)), dict(opts=dict(opencv_rounding=1, col_min=1)), dict(opts=dict(opencv_rounding=1, col_min=1, col_geom=1)),
+             dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
+             dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
+             dict(opts=dict(opencv_rounding=1, halo_geom=2)), dict(opts=dict(opencv_rounding=1, halo_small=5))]
     for case in cases:
         ctx = ofxcv.Context(0)
         for k, v in case["opts"].items():
@@ -635,19 +614,18 @@ def test_batch_launch_groups(oracle, ofxcv, mb):
     ctx = ofxcv.Context(0)
     singles = [ctx.calc_optical_flow_farneback(_dev(a), _dev(b)).cpu().numpy() for a, b in prs]
     ctx.set_option("farneback.batch_mb", mb)
-    for fold in (3, 2, 4):
-        ctx.set_option("farneback.fold_carries", fold)
-        ctx.set_option("farneback.fold_min", 1 if fold == 2 else 256)
+    for geom in (0, 2, 3):
+        ctx.set_option("farneback.halo_geom", geom)
         flows = ctx.calc_optical_flow_farneback_batch([_dev(a) for a, _ in prs], [_dev(b) for _, b in prs])
         for f, s in zip(flows, singles):
             assert np.array_equal(f.cpu().numpy(), s)
     ctx.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(fold_carries=3), dict(opencv_rounding=0), dict(persist=1)])
+@pytest.mark.parametrize("opts", [dict(), dict(col_min=1), dict(opencv_rounding=0), dict(col_min=1, col_geom=1), dict(opencv_rounding=2)])
 def test_flow_to_rgba_fused_into_the_call(oracle, ofxcv, opts):
-    """ofxcv_calc_optical_flow_farneback_batch_rgba: F7 rides on the last level-0 launch (default mode) or is appended by the
-    library (other window modes) -- the RGBA images equal ofxcv_flow_to_rgba applied to the returned flows bit for bit: all
+    """ofxcv_calc_optical_flow_farneback_batch_rgba: F7 rides on the launch that produces the final flow (overlapped strips: the default for these
+    small batches; column-owning form: col_min 1) or is appended by the library (other window modes) -- the RGBA images equal ofxcv_flow_to_rgba applied to the returned flows bit for bit: all
     four channels mapped, two, one, none; render scales; a pair without an image; forward + backward flow of one output frame
     written into ONE image with disjoint channels; unmapped channels keep their content.  Twice (graph replay)."""
     w, h = 333, 257
