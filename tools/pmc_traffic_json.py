@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """gpurun_out/pmc_bench/summary.txt (tools/pmc_bench.sh) -> profiles/<tag>_pmc_traffic.json: HBM-side bytes per launch of
 the level-0 iteration kernels, read = sum of TCC_EA0_RDREQ_{32B,64B,128B} x size, write = WRREQ_64B x 64 + the rest x 32
-(MI355X_MICROARCH.md, HBM / rocprofv3 section).  usage: pmc_traffic_json.py <summary.txt> <out.json>"""
+(MI355X_MICROARCH.md, HBM / rocprofv3 section); per-pair bytes from summary_calls.txt (totals over a known number of pairs).
+usage: pmc_traffic_json.py <summary.txt> <out.json> [<summary_calls.txt>]"""
 import collections
 import json
 import re
@@ -21,10 +22,11 @@ def traffic(c):
     return rd, wr
 
 
-out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over bench.py --batch 1 --streams 1 --steps 2: single-pair calls, so a launch "
-                 "is one pair's); per-launch averages per kernel and grid",
+out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over a short bench.py run of the timed workload -- batched calls of 8 pairs -- plus its "
+                 "single-pair legs); per-launch averages per kernel and grid.  The iterate_col_kernel launches carry all 8 pairs of the call, the iterate3h_kernel "
+                 "launches at level 0 one pair",
        "kernels": {}}
-want = {"iterate3h_kernel<1, 9, 8": "opencv_order_halo_iteration_level0", "iterate3f_kernel<true,": "opencv_order_folded_iteration_level0", "iterate3s_kernel<true, 8,": "opencv_order_iteration_level0", "vsum_carry_kernel<8>": "opencv_order_carry_level0", "fold_scan_kernel": "opencv_order_fold_scan_level0",
+want = {"iterate_col_kernel<1, 1,": "opencv_order_col_two_iterations_level0", "iterate3h_kernel<1, 9, 8": "opencv_order_halo_iteration_level0",
         "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
 for (name, grid), c in rows.items():
     for k, tag in want.items():
@@ -36,27 +38,27 @@ for (name, grid), c in rows.items():
             out["kernels"][tag] = {"kernel": name, "grid_threads": grid, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                                    "traffic_bytes_per_launch": rd + wr, "counters_per_launch": c}
 
-# HBM-side bytes of one whole 1080p frame pair (gray LUT x2 + Farneback with levels 3, iterations 15 + flow -> RGBA) in each
-# window mode: per-launch traffic of every kernel and grid (largest grid = pyramid level 0) x its launches per pair
-def per_level(prefix):
-    grids = sorted(((g, traffic(c)) for (n, g), c in rows.items() if n.startswith(prefix) and "TCC_EA0_RDREQ_sum" in c), reverse=True)
-    return [sum(t) for g, t in grids]
-
-
-def total(spec):
-    return sum(mult * sum(per_level(prefix)) for prefix, mult in spec)
-
-
-prep = [("polyexp_persistent_kernel", 1), ("pyr_", 1), ("gray_lut_kernel", 2)]  # one pyramid / polynomial-expansion launch per level carries both frames of the pair
-out["per_pair_traffic_bytes"] = {
-    # OpenCV-order mode (default): the overlapped-strip kernel does everything on the main stream -- per level one "first" launch (kind 2 on
-    # the coarsest level, 3 below it), 14 iterating launches (kind 1) and the last one (kind 0, which also stores the RGBA pixels)
-    "opencv_order": total(prep + [("iterate3h_kernel<1,", 14), ("iterate3h_kernel<0,", 1), ("iterate3h_kernel<2,", 1), ("iterate3h_kernel<3,", 1)]),
-    "direct_window": total(prep + [("update_matrices_kernel", 1), ("flow_to_rgba_kernel", 1), ("iterate3x2_kernel", 7), ("iterate3_kernel<false", 1)]),
-    "note": "sum over kernels of (bytes per launch from the PMC passes) x (launches per 1920x1080 pair: per level 1 first + 14 iterating + 1 last "
-            "launch of iterate3h_kernel in the OpenCV-order mode, 1 first update + 7 fused pairs + 1 final in the direct-window mode + 1 flow -> RGBA; "
-            "1 pyramid-image launch + 1 polynomial-expansion launch per level (both frames each), 2 gray LUTs)"}
+# HBM-side bytes of one whole 1080p frame pair in the timed workload (2 gray LUTs + its share of a batched Farneback call of 8 with F7 inside):
+# totals of the counters over tools/run_batch_calls.py divided by the pairs it processed
+import os
+calls = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(sys.argv[1]), "summary_calls.txt")
+tot = collections.defaultdict(dict)
+pairs = 0
+if os.path.exists(calls):
+    for line in open(calls):
+        if line.startswith("pairs "):
+            pairs = int(line.split()[1])
+        m = re.match(r"(.+?)\s+(\S+)\s+total\s+([0-9.]+) \(launches=(\d+)\)", line)
+        if m:
+            tot[m.group(1).strip()][m.group(2)] = float(m.group(3))
+            tot[m.group(1).strip()]["launches"] = int(m.group(4))
+if pairs:
+    per = {k: sum(traffic(c)) / pairs for k, c in tot.items()}
+    out["per_pair_traffic_bytes"] = {"opencv_order": sum(per.values()), "by_kernel": {k: v for k, v in sorted(per.items(), key=lambda kv: -kv[1]) if v > 1e5},
+                                     "note": "sum over every kernel of the run of its L2 <-> fabric bytes / %d pairs (tools/run_batch_calls.py: batched calls of 8 pairs, "
+                                             "2 gray LUTs per pair, F7 inside the call)" % pairs}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
-print("per pair: OpenCV order %.0f MB, direct window %.0f MB" % (out["per_pair_traffic_bytes"]["opencv_order"] / 1e6, out["per_pair_traffic_bytes"]["direct_window"] / 1e6))
+if "per_pair_traffic_bytes" in out:
+    print("per pair (timed workload): %.0f MB" % (out["per_pair_traffic_bytes"]["opencv_order"] / 1e6))
 for k, v in out["kernels"].items():
     print(k, v["kernel"], "%.1f MB" % (v["traffic_bytes_per_launch"] / 1e6))
