@@ -2002,7 +2002,8 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         lds_post(&lds.rd[s][pw], wave == 0 ? r : r + 1, l);
     };
 
-    // This wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]) of a round.  Rows below the image count as zero.
+    // This wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]) of a round, requested one round ahead (20
+    // registers at four rows per round).  Rows below the image count as zero.
     // NO per-row branches anywhere in a round: rows outside the image are computed at the clamped row index and masked out
     // where they would count (they only occur in the first and the last round), so a round is straight-line code.
     float d[RW][5];
@@ -2040,7 +2041,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         // no memory) runs while the gathers of the rows before it are in flight.
         double P[5];
         if (SOLVE1) {
-            load_d(r);
+            if (r == 0) load_d(0);  // later rounds: requested while the round before was in its second step
             double sum[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
@@ -2106,6 +2107,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                 }
             }
         }
+        if (SOLVE1 && r + 1 < ca.rounds) load_d(r + 1);  // this round's rows are used up: the next round's arrive during step 2
         if (LAST1) continue;
         stamp(r, 4);   // M' complete
         put_boundary(0, r, m1);  // rows RW-3 .. RW-1 for the wavefront below
