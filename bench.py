@@ -351,7 +351,7 @@ def main():
     strict_flow = bufs[0]["flow"][0].cpu().numpy()
     g_a, g_b = bufs[0]["ga"][0].cpu().numpy(), bufs[0]["gb"][0].cpu().numpy()
     col_aborts = ctxs[0].get_option("farneback.col_aborts")
-    one_in_flight = one_batch_in_flight = three_single = None
+    one_in_flight = one_batch_in_flight = three_single = batch16 = None
     if world == 1:
         n1 = max(10, args.steps // 2)
         e1 = timed_regions(ctxs[:1], bufs[:1], n1, 3, 3)
@@ -371,6 +371,14 @@ def main():
         for c in c3:
             c.close()
         del b3
+        # twice the pairs per call: the 960x540 level then has 256 workgroups as well and takes the column-owning form
+        c16 = make_ctxs(1, direct=False)
+        b16 = make_bufs(c16, W, H, 16)
+        e16 = timed_regions(c16, b16, max(5, args.steps // 4), 3, 3)
+        batch16 = max(5, args.steps // 4) * 16 / statistics.median(e16)
+        for c in c16:
+            c.close()
+        del b16
 
     # ---- the opt-in direct-window mode, same workload ----
     # (its kernels take one pair per launch: P single-pair contexts in flight, as in rounds 1 and 2)
@@ -427,6 +435,7 @@ def main():
         "value_one_pair_in_flight": one_in_flight,      # one unbatched call at a time (a single OFX render thread, one direction)
         "value_one_batch_in_flight": one_batch_in_flight,  # one batched call of `pairs_per_batched_call` pairs at a time
         "value_three_single_pair_calls_in_flight": three_single,  # the configuration BENCH_r01 / BENCH_r02 quoted as `value`
+        "value_batches_of_16": batch16,  # one batched call of 16 pairs at a time (the call's maximum)
         "col_aborts": col_aborts,  # 1 if a bounded LDS wait of iterate_col_kernel ever ran out (never seen)
         "value_direct_window": statistics.median(drates),
         "value_direct_window_stats": dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
