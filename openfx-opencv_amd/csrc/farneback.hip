@@ -2810,7 +2810,10 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         const bool gaussian = (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN) != 0;
         // the column-owning form streams every pair of the call through one launch (a workgroup per tile column and pair; the
         // fields are read once per two iterations, so the Infinity-Cache grouping below has nothing to keep on the die)
-        const bool col = col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian);
+        // (one exception: a single iteration on a caller-supplied flow at level 0 would pair "first M from the given flow" with "last: flow
+        // out" in ONE launch over the SAME buffer -- a workgroup's halo lanes read columns its neighbour overwrites; found by tests/perf/fuzz_halo.py)
+        const bool given_in_place = k == 0 && !have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW) && iterations == 1;
+        const bool col = !given_in_place && col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian);
         const int per_group = col ? n : ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
         const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;

@@ -329,7 +329,8 @@ def test_opencv_order_mode_step_pairs_and_first_matrix_forms(oracle, ofxcv, w, h
     rng = np.random.default_rng(5)
     init = rng.normal(0, 2, size=(h, w, 2)).astype(np.float32)
     for kw in (dict(iterations=1), dict(iterations=2), dict(iterations=3), dict(iterations=4, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW),
-               dict(iterations=5), dict(iterations=2, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):
+               dict(iterations=5), dict(iterations=2, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW),
+               dict(iterations=1, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):   # at level 0 the given flow and the result share a buffer (fuzz_halo.py, round 4)
         args = (init,) if "flags" in kw else ()
         outs = [_flow_with(ofxcv, opts, ga, gb, *args, levels=levels, **kw) for opts in _FORMS + (dict(col=0, halo_geom=2), dict(col=0, halo_small=5))]
         assert all(np.array_equal(outs[0], o) for o in outs[1:]), kw
