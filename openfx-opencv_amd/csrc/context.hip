@@ -257,6 +257,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_parallel_march = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "inpaint.tiles")) {
+        ctx->ip_tiles = value != 0;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "inpaint.spin_limit")) {
         ctx->ip_spin_limit = value;
         return OFXCV_OK;

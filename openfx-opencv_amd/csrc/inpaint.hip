@@ -246,6 +246,50 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
     return nwg;
 }
 
+// Tile schedule of ONE portion (round 4): the portion's pixels grouped by square tiles of `ts` padded-image pixels, one workgroup per
+// occupied tile, its 16 wavefronts taking the tile's pixels round-robin in fill order.  Dependencies are spatially local (window
+// radius range + 2), so most of a pixel's predecessors lie in its own tile and reach it through the workgroup's LDS slots
+// (telea_fill_kernel: `ts`); only those across a tile edge go through the L2.  Every workgroup of the launch can wait for any
+// other, so all of them must be resident at once: the caller caps the number of tiles (kMaxTileGroups x kMaxConcurrentFills
+// workgroups of 1024 threads fit the chip one per CU) and picks the tile size for it; returns -1 if even the largest does not do.
+constexpr int kMaxTileGroups = 48;
+int build_tile_portion(const March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
+                       std::vector<int> &cell, int &ts_out) {
+    const int ec = m.w + 2, er = m.h + 2;
+    const int n = k1 - k0;
+    if (n <= 0) return 0;
+    static const int sizes[] = {32, 48, 64, 96, 128, 192, 256, 384, 512};
+    for (int ts : sizes) {
+        const int gw = (ec + ts - 1) / ts, gh = (er + ts - 1) / ts;
+        cell.assign((size_t)gw * gh, -1);
+        int ntile = 0;
+        for (int k = k0; k < k1 && ntile <= kMaxTileGroups; k++) {
+            int &c = cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts];
+            if (c < 0) c = ntile++;
+        }
+        if (ntile > kMaxTileGroups) continue;
+        std::vector<int> off(ntile + 1, 0);
+        for (int k = k0; k < k1; k++) off[cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts] + 1]++;
+        for (int t = 0; t < ntile; t++) off[t + 1] += off[t];
+        const int base = (int)sched_pix.size();
+        sched_pix.resize(base + n);
+        sched_ord.resize(base + n);
+        std::vector<int> fillp(off.begin(), off.end() - 1);
+        for (int k = k0; k < k1; k++) {  // ascending k: fill order is kept inside a tile
+            const int q = base + fillp[cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts]]++;
+            sched_pix[q] = m.pix[k];
+            sched_ord[q] = k + 1;
+        }
+        for (int t = 0; t < ntile; t++) {
+            const int rec[4] = {base + off[t], base + off[t + 1], 0, kFillWavesHost};
+            sched_wg.insert(sched_wg.end(), rec, rec + 4);
+        }
+        ts_out = ts;
+        return ntile;
+    }
+    return -1;
+}
+
 // ------------------------------------------------------------------ I4 colour fill (device)
 
 constexpr int kFillThreads = 1024;             // 16 wavefronts: 16 pixels of a level in flight per workgroup
@@ -254,6 +298,7 @@ static_assert(kFillWaves == kFillWavesHost, "the host schedule assumes 16 wavefr
 constexpr int kAcc = 10;                       // Ia[3], Jx[3], Jy[3], s
 constexpr int kMaxLdsRange = 5;                // (2r+3)^2 <= 169 neighbourhood entries staged in LDS
 constexpr int kWinMax = (2 * kMaxLdsRange + 3) * (2 * kMaxLdsRange + 3);
+constexpr int kFillSlots = 8192;               // tile schedule: one LDS dword per fill-order pixel of a launch (the default portion)
 
 // The fill works on 4-byte pixels (R | G<<8 | B<<16 | X<<24), w*h dwords: one aligned load / store per pixel.
 struct FillArgs {
@@ -266,6 +311,8 @@ struct FillArgs {
     const int *cmp_pix, *cmp_ord, *cmp_off;              // dataflow schedule: the pixels of each component in fill order
     int *err;                                            // dataflow: set when a poll gave up (see the poll loop)
     int spin_limit;                                      // polls a wavefront spends on one awaited colour before it gives up
+    int k0;                                              // tile schedule: the order numbers of this launch's pixels are k0+1 .. k0+kFillSlots at most
+    int ts;                                              // tile schedule: tile size (padded pixels); 0 = component schedule (all polls through the L2)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between lanes of ONE wavefront
@@ -320,6 +367,15 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     __shared__ int s_word[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
     __shared__ float s_wt[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
     __shared__ uint32_t s_wrgb[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
+    // Tile schedule: slot q - k0 - 1 receives the colour | tag of the pixel with fill-order number q the moment it is final; the
+    // wavefronts of this workgroup that need it poll the slot -- an LDS round trip where the store -> L2 -> poll path costs
+    // microseconds per link of the dependency chain.  Only pixels of this workgroup's tile are ever looked up here.
+    __shared__ uint32_t s_slot[LDSWIN ? kFillSlots : 1];
+    const int ts = LDSWIN ? a.ts : 0;
+    if (ts) {
+        for (int e = threadIdx.x; e < kFillSlots; e += kFillThreads) s_slot[e] = 0;
+        __syncthreads();
+    }
     const int ec = a.w + 2, er = a.h + 2, range = a.range;
     const int side = 2 * range + 1, ntap = side * side, ws = side + 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -347,7 +403,9 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     int q[kEl];
                     float tv[kEl];
                     uint32_t rgb[kEl];
-                    const uint32_t *wait_on[kEl];  // entries the sequential algorithm fills before pixel o
+                    const uint32_t *wait_on[kEl];  // entries the sequential algorithm fills before pixel o: polled through the L2 ...
+                    int wait_slot[kEl];            // ... or, inside this workgroup's tile, in their LDS slot
+                    const int ti = ts ? i / ts : 0, tj = ts ? j / ts : 0;
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         const int e = lane + 64 * u;
@@ -355,6 +413,7 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                         tv[u] = 0.f;
                         rgb[u] = 0;
                         wait_on[u] = nullptr;
+                        wait_slot[u] = -1;
                         if (e < ws * ws) {
                             const int r = wi0 + e / ws, c = wj0 + e % ws;
                             if (r >= 0 && c >= 0 && r < er && c < ec) {
@@ -362,8 +421,13 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                                 tv[u] = a.t[r * ec + c];
                                 if (r >= 1 && c >= 1 && r <= a.h && c <= a.w) {
                                     const size_t at = (size_t)(r - 1) * a.w + (c - 1);
-                                    if (q[u] != 0 && q[u] < o) wait_on[u] = a.out + at;
-                                    else rgb[u] = a.src[at];
+                                    if (q[u] != 0 && q[u] < o) {
+                                        if (ts && q[u] <= a.k0) rgb[u] = a.out[at];  // filled by an earlier launch: final in memory
+                                        else if (ts && r / ts == ti && c / ts == tj) wait_slot[u] = q[u] - a.k0 - 1;  // by this workgroup: its slot
+                                        else wait_on[u] = a.out + at;               // by another workgroup of this launch
+                                    } else {
+                                        rgb[u] = a.src[at];
+                                    }
                                 }
                             }
                         }
@@ -371,13 +435,25 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         int spins = 0;
+                        while (wait_slot[u] >= 0) {
+                            const uint32_t v = __hip_atomic_load(&s_slot[wait_slot[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (v >> 24) {
+                                rgb[u] = v;
+                                wait_slot[u] = -1;
+                            } else if (++spins > a.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                                __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // bounded like the L2 polls below
+                                wait_slot[u] = -1;
+                            } else {
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                        }
                         while (wait_on[u]) {  // agent-scope load: straight from the L2, never a stale L1 line
                             const uint32_t v = __hip_atomic_load(wait_on[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (v >> 24) {
                                 rgb[u] = v;
                                 wait_on[u] = nullptr;
                             } else if (++spins > a.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                                // Bounded wait.  The owner of the awaited pixel is a wavefront of this component's workgroups; should
+                                // Bounded wait.  The owner of the awaited pixel is a wavefront of another workgroup of this launch; should
                                 // it not be running (a partner workgroup that never became resident), give up instead of
                                 // spinning for ever inside the host's render thread: flag the launch, let every wavefront
                                 // drain, and the host repeats the fill with the barrier-scheduled kernel.
@@ -514,7 +590,9 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 const uint32_t g = __shfl(byte, 1), bl = __shfl(byte, 2);
                 if (lane == 0) {
                     const size_t at = (size_t)(i - 1) * a.w + (j - 1);
-                    __hip_atomic_store(a.out + at, byte | (g << 8) | (bl << 16) | 0x01000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t px = byte | (g << 8) | (bl << 16) | 0x01000000u;
+                    if (ts) __hip_atomic_store(&s_slot[o - a.k0 - 1], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // first: it is on the chain
+                    __hip_atomic_store(a.out + at, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 }
             }
@@ -808,6 +886,8 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     fa.range = range;
     fa.err = nullptr;
     fa.spin_limit = 0;
+    fa.k0 = 0;
+    fa.ts = 0;
     fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);
     fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
     fa.lvl_off = fa.cmp_off = (const int *)(dp + off_wg);
@@ -858,8 +938,18 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             if (got <= 0) break;
             const int k1 = k0 + got;
             const size_t wg0 = sw.size() / 4;
-            const int nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256,
-                                                   ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8);
+            // tile schedule (default): a workgroup per occupied tile, hand-offs inside a tile through LDS; the component schedule
+            // (1..8 workgroups per connected group of pixels, every hand-off through the L2) where the tiles do not fit
+            int nwg = -1, ts = 0;
+            if (ctx->ip_tiles && got <= kFillSlots) nwg = build_tile_portion(m, k0, k1, sp, so, sw, m.cell, ts);
+            if (nwg < 0) {
+                ts = 0;
+                m.cell.clear();  // the tile pass leaves the grid in another geometry
+                nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256,
+                                             ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8);
+            }
+            fa.k0 = k0;
+            fa.ts = ts;
             t_sched += trace ? now() - tb : 0;
             if ((rc = scatter_front(k0, k1))) return rc;
             std::memcpy(hp + off_pix + (size_t)k0 * 4, sp.data() + k0, (size_t)got * 4);
