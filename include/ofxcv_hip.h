@@ -42,7 +42,8 @@ const char *ofxcv_status_string(int status);
 int ofxcv_ctx_device(const ofxcv_ctx *ctx);
 /* the context's compute stream (hipStream_t), used whenever a `stream` argument is NULL */
 void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
-/* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL) */
+/* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL); OFXCV_ERR_HIP if a bounded wait of the
+ * column-owning Farneback kernel ever ran out on this context (its flows are then not valid; never observed) */
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 
 /* context options:

@@ -349,6 +349,13 @@ int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int res
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ofxcv_stream(ctx, stream)));
+    if (ctx->fb_col_flag.ptr) {
+        // the sticky abort word of iterate_col_kernel: a bounded wait that ran out leaves wrong flows behind -- fail loudly here, at the
+        // library's own synchronisation point (4 bytes; the waits terminate by construction, this is for a faulting device)
+        unsigned flag = 0;
+        OFXCV_HIP_CHECK(ctx, hipMemcpy(&flag, ctx->fb_col_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost));
+        if (flag) return ofxcv_fail(ctx, OFXCV_ERR_HIP, "calc_optical_flow_farneback: a bounded wait inside iterate_col_kernel ran out; the flows of that call are not valid");
+    }
     return OFXCV_OK;
 }
 
