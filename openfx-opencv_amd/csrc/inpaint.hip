@@ -623,6 +623,12 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     }
 }
 
+// render body: alpha forced to 255 (inpaint.cpp:349-352) on the device image, before it goes back to the host
+__global__ __launch_bounds__(256) void opaque_alpha_kernel(uint32_t *__restrict__ img, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) img[i] |= 0xff000000u;
+}
+
 // ---- persistent device maps of the march (distance, order number): defaults everywhere, sparse updates per call
 __global__ __launch_bounds__(256) void map_init_kernel(float *__restrict__ t, int *__restrict__ ord, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1030,14 +1036,12 @@ int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
     if (rc) return rc;
     // write-back of inpaint.cpp:320-358 for noise == 0: RGB copied, alpha forced to 255 (the caller applies the
     // libc rand() noise of :336-347 itself when the noise parameter is non-zero, using h_mask_out)
+    hipLaunchKernelGGL(opaque_alpha_kernel, dim3((unsigned)(((size_t)w * h + 255) / 256)), dim3(256), 0, s, (uint32_t *)d_dst, (size_t)w * h);
+    OFXCV_LAUNCH_CHECK(ctx, "opaque_alpha_kernel");
     rc = ofxcv_download_rows(ctx, h_dst, dst_row_bytes, d_dst, row, h, s);
     if (rc) return rc;
     if (h_mask_out) OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_mask_out, w, d_mask, w, w, h, hipMemcpyDeviceToHost, s));
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
-    for (int y = 0; y < h; y++) {
-        uint8_t *d = h_dst + (ptrdiff_t)y * dst_row_bytes;
-        for (int x = 0; x < w; x++) d[x * 4 + 3] = 255;
-    }
     return OFXCV_OK;
 }
 
