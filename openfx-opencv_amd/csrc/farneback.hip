@@ -1386,16 +1386,19 @@ __global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restri
 // reproduce the d_t exactly and only re-associate the f64 additions (partial sums per wavefront, strip or round: errors of
 // 1e-16 relative to the partial sums, nine orders of magnitude below the f32 rounding of the d_t themselves).  The left / right
 // column sums of the 3-column window come from the neighbouring lanes by DPP wave shifts (two dwords per f64).
+// bound_ctrl form with a zero `old` operand: ONE v_mov_b32_dpp per dword (the form update_dpp(x, x, ...) costs a copy first: 4 instead of 2
+// instructions per f64 shift, 20 of the ~200 vector instructions of a pixel row).  The lane without a source (0 / 63) receives 0: it is
+// a halo lane in every kernel that uses these, its window sum is never used.
 __device__ __forceinline__ double dpp64_from_left(double v) {  // lane i <- lane i-1
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp64_from_right(double v) {  // lane i <- lane i+1
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
