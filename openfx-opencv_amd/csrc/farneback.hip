@@ -2016,11 +2016,11 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         for (int j = 0; j < RW; j++) {
             const int y = a + j;
             const unsigned so = (unsigned)min(y, h - 1) * rb;
+            // rows below the image: an out-of-range offset, the bounds check returns 0.  (A select behind each load makes the compiler wait for
+            // every load where it is issued as soon as register pressure rises: 20 serial round trips per round, measured 414 -> 598 us.)
+            const unsigned vo = y < h ? vx : 0xC0000000u;
 #pragma unroll
-            for (int c = 0; c < 5; c++) {
-                const float v = buf_ld(bD, vx, so + c * pb);
-                d[j][c] = y < h ? v : 0.f;
-            }
+            for (int c = 0; c < 5; c++) d[j][c] = buf_ld(bD, vo, so + c * pb);
         }
     };
 
@@ -2575,9 +2575,9 @@ struct ColGeom {
 ColGeom col_geom(const ofxcv_ctx *ctx, int w, int h, bool iter_pair) {
     ColGeom g;
     // experimental geometries exist for the (iterate, iterate) launch only; the field between launches does not depend on it
-    const bool tall = iter_pair && !ctx->fb_col_trace && ctx->fb_col_geom == 1;  // A/B: eight rows per wavefront and round
-    g.nw = 8;
-    g.rw = tall ? 8 : 4;
+    const bool wide = iter_pair && !ctx->fb_col_trace && ctx->fb_col_geom == 1;  // A/B: twelve wavefronts of three rows (36-row rounds)
+    g.nw = wide ? 12 : 8;
+    g.rw = wide ? 3 : 4;
     g.tiles_x = ofxcv_div_up(w, kColW);
     g.S = g.nw * g.rw;
     g.rounds = ofxcv_div_up(h + 2, g.S);  // step 2 runs one row behind step 1, the differences it stores another row behind, and d_{h-1} needs the row below the image
@@ -2615,7 +2615,7 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2); \
     } while (0)
     if (iter_pair && ctx->fb_col_trace) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, 1, true, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
-    else if (iter_pair && ctx->fb_col_geom == 1) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 8, 8, 1);
+    else if (iter_pair && ctx->fb_col_geom == 1) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, 1);
     else OFXCV_LAUNCH_COL(4, 8, 1);
 #undef OFXCV_LAUNCH_COL
 #undef OFXCV_LAUNCH_COL_K
