@@ -57,6 +57,7 @@ struct ofxcv_ctx {
     unsigned fb_graph_next = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
     int fb_polyexp_variant = 5;
+    int fb_pyr_bytewise = 0;     // option "farneback.pyr_bytewise": 1 = the coarse pyramid levels take the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel)
     int fb_gauss_generation = 3;    // option "farneback.gaussian_kernel_generation": getGaussianKernel of OpenCV 2.4 / 3.x (3) or 4.x (4)
     int fb_resize_generation = 0;   // option "farneback.resize_generation": association of cv::resize's exact-2x INTER_AREA rewrite (farneback.hip: resize_combine)
     int num_cus = 256;

@@ -403,6 +403,98 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
     }
 }
 
+// The fused tile kernel for the coarse levels of the default pyramid: the level is the frame divided by S = 4 or 8 in both
+// directions exactly, so every output sample lies half-way between source columns S*d + S/2 - 1 and S*d + S/2 (rows alike) and
+// the two row-filtered columns of an output column share KS - 1 of their KS + 1 source bytes.  Same operations in the same order
+// as pyr_fused_kernel; what changes is how the bytes travel:
+//  * the footprint is staged with aligned dword loads (the host checks base and row step; dwords that touch the image edge
+//    take the byte path with reflected columns),
+//  * a lane filters BOTH columns of an output column from one run of KS + 1 bytes: aligned LDS dwords, re-aligned by the
+//    tile-uniform byte offset (v_alignbyte_b32), bytes converted with v_cvt_f32_ubyteN -- 6 LDS reads for 38 taps at KS = 19
+//    instead of 38 byte reads,
+//  * the column filter reads the two filtered columns of a row as one 8-byte LDS word and evaluates the four filtered samples
+//    of an output sample (rows sy, sy + 1) from the 2r + 2 rows they share.
+template <int S, int KS>
+struct PyrAl {
+    static constexpr int OW = 32, OH = 8, R = KS / 2;
+    static constexpr int SPAN_C = (OW - 1) * S + 2 + 2 * R, SPAN_R = (OH - 1) * S + 2 + 2 * R;  // source columns / rows a tile touches
+    static constexpr int ND = ((3 + SPAN_C + 3) / 4) | 1;  // staged dwords per row (origin aligned down by up to 3 bytes); odd: rows of a wavefront's two half-rows fall on different banks
+    static constexpr int NB = (3 + KS + 1 + 3) / 4;        // aligned dwords that hold a lane's KS + 1 bytes at any byte offset
+    static constexpr size_t lds_bytes = (size_t)SPAN_R * ND * 4 + (size_t)SPAN_R * OW * 2 * 4;
+};
+template <int S, int KS>
+__global__ __launch_bounds__(256) void pyr_fused_al_kernel(ImgTab imgs, int W, int H, int lw, int lh, GaussTaps gk, float *__restrict__ I, size_t I_stride) {
+    using G = PyrAl<S, KS>;
+    constexpr int R = G::R, ND = G::ND, NB = G::NB, OW = G::OW, OH = G::OH;
+    __shared__ unsigned s_src[G::SPAN_R * ND];
+    __shared__ float s_h[G::SPAN_R * OW * 2];
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    const uint8_t *__restrict__ img = imgs.p[tbz];
+    const size_t step = imgs.step[tbz];
+    I += (size_t)tbz * I_stride;
+    const int ox0 = tbx * OW, oy0 = tby * OH, tid = threadIdx.x;
+    const int c_first = S * ox0 + S / 2 - 1 - R, r_lo = S * oy0 + S / 2 - 1 - R;  // first source column / row of the footprint
+    const int c_lo = c_first & ~3, m = c_first - c_lo;                            // staging origin (a multiple of 4, may be negative)
+
+    for (int e = tid; e < G::SPAN_R * ND; e += 256) {
+        const int ry = e / ND, k = e - ry * ND, c = c_lo + 4 * k;
+        const uint8_t *Srow = img + (size_t)reflect101(r_lo + ry, H) * step;
+        unsigned v;
+        if (c >= 0 && c + 3 < W) {
+            v = *(const unsigned *)(Srow + c);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v |= (unsigned)Srow[reflect101(c + b, W)] << (8 * b);
+        }
+        s_src[e] = v;
+    }
+    __syncthreads();
+    // row filter: lane (ry, tx) -> the filtered samples at source columns sx = S*(ox0+tx) + S/2 - 1 and sx + 1 of row ry
+    for (int e = tid; e < G::SPAN_R * OW; e += 256) {
+        const int ry = e / OW, tx = e - ry * OW;
+        const unsigned *Wd = s_src + ry * ND + tx * (S / 4);  // the dword that holds byte (sx - R) - c_lo = m + S*tx
+        unsigned w[NB], b[NB - 1];
+#pragma unroll
+        for (int i = 0; i < NB; i++) w[i] = Wd[i];
+#pragma unroll
+        for (int i = 0; i < NB - 1; i++) b[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], (unsigned)m);  // byte q of the run = byte q & 3 of b[q >> 2]
+        auto B = [&](int q) __attribute__((always_inline)) { return (float)((b[q >> 2] >> (8 * (q & 3))) & 255u); };
+        float va = gk.k[0] * B(0), vb = gk.k[0] * B(1);
+#pragma unroll
+        for (int q = 1; q < KS; q++) {
+            va += B(q) * gk.k[q];
+            vb += B(q + 1) * gk.k[q];
+        }
+        *(float2 *)(s_h + (size_t)e * 2) = make_float2(va, vb);
+    }
+    __syncthreads();
+    {
+        const int ty = tid / OW, tx = tid - ty * OW;
+        const int dx = ox0 + tx, dy = oy0 + ty;
+        if (dx >= lw || dy >= lh) return;
+        int sx, sy;
+        float ax0, ax1, b0, b1;
+        lerp_coef(dx, W, lw, sx, ax0, ax1);
+        lerp_coef(dy, H, lh, sy, b0, b1);
+        // rows sy - R .. sy + 1 + R of the two filtered columns: footprint rows S*ty .. S*ty + 2R + 1
+        float2 c[2 * R + 2];
+#pragma unroll
+        for (int i = 0; i < 2 * R + 2; i++) c[i] = *(const float2 *)(s_h + ((size_t)(S * ty + i) * OW + tx) * 2);
+        const float *kc = gk.k + R;
+        float t00 = kc[0] * c[R].x, t01 = kc[0] * c[R].y, t10 = kc[0] * c[R + 1].x, t11 = kc[0] * c[R + 1].y;
+#pragma unroll
+        for (int q = 1; q <= R; q++) {
+            t00 += kc[q] * (c[R + q].x + c[R - q].x);
+            t01 += kc[q] * (c[R + q].y + c[R - q].y);
+            t10 += kc[q] * (c[R + 1 + q].x + c[R + 1 - q].x);
+            t11 += kc[q] * (c[R + 1 + q].y + c[R + 1 - q].y);
+        }
+        I[(size_t)dy * lw + dx] = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, 0);
+    }
+}
+
 // 3-tap levels (k = 0: sigma 0 -> [1/4 1/2 1/4], identity resize; k = 1: sigma 0.5, half size): the footprint of an
 // output sample is at most 4x4 source bytes, so each lane simply reads it through the L1 -- no staging, no barriers.
 // Same operations in the same order as the generic kernels.
@@ -2309,6 +2401,20 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
                            gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3_kernel");
         return OFXCV_OK;
+    }
+    // the default pyramid's coarse levels: exactly a quarter / an eighth of the frame, 9 / 19 taps
+    if (!no_fused && !ctx->fb_pyr_bytewise && aligned && ntap == 2 && W >= 64 && H >= 64) {
+        const dim3 g(ofxcv_div_up(lw, 32), ofxcv_div_up(lh, 8), nimg);
+        if (W == 4 * lw && H == 4 * lh && ksize == 9) {
+            hipLaunchKernelGGL((pyr_fused_al_kernel<4, 9>), g, dim3(256), 0, s, imgs, W, H, lw, lh, gk, d_I, I_stride);
+            OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_al_kernel");
+            return OFXCV_OK;
+        }
+        if (W == 8 * lw && H == 8 * lh && ksize == 19) {
+            hipLaunchKernelGGL((pyr_fused_al_kernel<8, 19>), g, dim3(256), 0, s, imgs, W, H, lw, lh, gk, d_I, I_stride);
+            OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_al_kernel");
+            return OFXCV_OK;
+        }
     }
     // fused tile kernel when the source footprint of a 32x8 (64x8 for small decimation) tile fits in LDS
     PyrTile t;

@@ -54,6 +54,34 @@ def test_pyr_image_bit_exact(oracle, ofxcv, direct_ctx, w, h):
         assert np.array_equal(ref, got), "level %d max diff %g" % (k, np.abs(ref - got).max())
 
 
+@pytest.mark.parametrize("w,h", [(64, 64), (256, 64), (72, 200), (328, 200), (1000, 568), (1920, 1080)])
+def test_pyr_image_quarter_and_eighth_levels(oracle, ofxcv, w, h):
+    """The coarse levels of the default pyramid (exactly 1/4 and 1/8 of the frame, 9 / 19 taps) take pyr_fused_al_kernel (aligned
+    dword staging, both filtered columns of an output column from one byte run): bit-identical to the oracle and to the
+    byte-wise tile kernel (option farneback.pyr_bytewise), with partial tiles, reflected edges on all four sides, and a source whose
+    rows are not dword-aligned (which must fall back by itself)."""
+    import torch
+    ga, _ = _gray_pair(oracle, w, h)
+    ctx = ofxcv.Context(0)
+    try:
+        for k in (2, 3):
+            lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
+            assert (w, h) == (lw << k, lh << k) and ks == (9, 19)[k - 2]
+            ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
+            ctx.set_option("farneback.pyr_bytewise", 0)
+            got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+            ctx.set_option("farneback.pyr_bytewise", 1)
+            other = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+            ctx.set_option("farneback.pyr_bytewise", 0)
+            padded = torch.zeros((h, w + 3), dtype=torch.uint8, device="cuda")  # row step w + 3: not a multiple of 4
+            padded[:, :w] = _dev(ga)
+            odd = ctx.farneback_pyr_image(padded[:, :w], lw, lh, sigma, ks).cpu().numpy()
+            assert np.array_equal(ref, got), "level %d max diff %g" % (k, np.abs(ref - got).max())
+            assert np.array_equal(ref, other) and np.array_equal(ref, odd)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (98, 74), (640, 480)])
 def test_pyr_image_generations_bit_exact(oracle, ofxcv, w, h):
     """The two places where OpenCV generations are known (from their published sources) to differ in the last bit, as matching
