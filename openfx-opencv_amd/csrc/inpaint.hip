@@ -253,32 +253,45 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
 // other, so all of them must be resident at once: the caller caps the number of tiles (kMaxTileGroups x kMaxConcurrentFills
 // workgroups of 1024 threads fit the chip one per CU) and picks the tile size for it; returns -1 if even the largest does not do.
 constexpr int kMaxTileGroups = 48;
-int build_tile_portion(const March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
+int build_tile_portion(March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
                        std::vector<int> &cell, int &ts_out) {
     const int ec = m.w + 2, er = m.h + 2;
     const int n = k1 - k0;
     if (n <= 0) return 0;
     static const int sizes[] = {32, 48, 64, 96, 128, 192, 256, 384, 512};
+    // row and column of every pixel once (one division each), the tile of a row / column from a table per tile size: the passes
+    // below cost no division per pixel (they had four each: 1.2 of the 11.5 ms of a 1080p call)
+    std::vector<int> &pr = m.sc_r, &pc = m.sc_c, &rt = m.sc_rt, &ct = m.sc_ct, &tile = m.sc_tile;  // scratch kept with the context
+    pr.resize(n); pc.resize(n); tile.resize(n);
+    for (int k = 0; k < n; k++) {
+        const int p = m.pix[k0 + k], i = p / ec;
+        pr[k] = i;
+        pc[k] = p - i * ec;
+    }
+    rt.resize(er); ct.resize(ec);
     for (int ts : sizes) {
         const int gw = (ec + ts - 1) / ts, gh = (er + ts - 1) / ts;
+        for (int i = 0; i < er; i++) rt[i] = (i / ts) * gw;
+        for (int j = 0; j < ec; j++) ct[j] = j / ts;
         cell.assign((size_t)gw * gh, -1);
-        int ntile = 0;
-        for (int k = k0; k < k1 && ntile <= kMaxTileGroups; k++) {
-            int &c = cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts];
+        int ntile = 0, k = 0;
+        for (; k < n && ntile <= kMaxTileGroups; k++) {
+            int &c = cell[(size_t)rt[pr[k]] + ct[pc[k]]];
             if (c < 0) c = ntile++;
+            tile[k] = c;
         }
         if (ntile > kMaxTileGroups) continue;
         std::vector<int> off(ntile + 1, 0);
-        for (int k = k0; k < k1; k++) off[cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts] + 1]++;
+        for (k = 0; k < n; k++) off[tile[k] + 1]++;
         for (int t = 0; t < ntile; t++) off[t + 1] += off[t];
         const int base = (int)sched_pix.size();
         sched_pix.resize(base + n);
         sched_ord.resize(base + n);
         std::vector<int> fillp(off.begin(), off.end() - 1);
-        for (int k = k0; k < k1; k++) {  // ascending k: fill order is kept inside a tile
-            const int q = base + fillp[cell[(size_t)(m.pix[k] / ec / ts) * gw + (m.pix[k] % ec) / ts]]++;
-            sched_pix[q] = m.pix[k];
-            sched_ord[q] = k + 1;
+        for (k = 0; k < n; k++) {  // ascending k: fill order is kept inside a tile
+            const int q = base + fillp[tile[k]]++;
+            sched_pix[q] = m.pix[k0 + k];
+            sched_ord[q] = k0 + k + 1;
         }
         for (int t = 0; t < ntile; t++) {
             const int rec[4] = {base + off[t], base + off[t + 1], 0, kFillWavesHost};
@@ -823,7 +836,12 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
                  off_fi = align_up(off_so + (size_t)n_static * 4, a256), off_ft = align_up(off_fi + (size_t)n_holes * 4, a256),
                  off_fo = align_up(off_ft + (size_t)n_holes * 4, a256), off_pix = align_up(off_fo + (size_t)n_holes * 4, a256),
                  off_po = align_up(off_pix + (size_t)n_holes * 4, a256), off_wg = align_up(off_po + (size_t)n_holes * 4, a256),
-                 off_lo = align_up(off_wg + (size_t)n_holes * 16 + 16, a256), total = align_up(off_lo + ((size_t)n_holes + 2) * 8 + 256, a256);
+                 off_lo = align_up(off_wg + (size_t)n_holes * 16 + 16, a256), off_stream = align_up(off_lo + ((size_t)n_holes + 2) * 8 + 256, a256);
+    // pipelined fill: everything a portion hands over (pixel indices, distances, schedule pixels, their order numbers, workgroup
+    // records -- five arrays, each 16-byte aligned) is packed one portion after the other, so that a portion is ONE copy
+    const int portion_px = ctx->ip_portion > 0 ? ctx->ip_portion : kFillPortion;
+    const size_t stream_bytes = (size_t)n_holes * 32 + ((size_t)n_holes / portion_px + 2) * 5 * 16 + 256;
+    const size_t total = align_up(off_stream + stream_bytes, a256);
     rc = ofxcv_reserve(ctx, ctx->ip_maps, total);
     if (rc) return rc;
     char *dp = (char *)ctx->ip_maps.ptr;
@@ -934,7 +952,9 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         // no reallocation while asynchronous copies from these arrays may be in flight
         sp.reserve(n_holes); so.reserve(n_holes); sw.reserve((size_t)n_holes * 4 + 4);
         m.pix.reserve(n_holes);
-        const int portion = ctx->ip_portion > 0 ? ctx->ip_portion : kFillPortion;
+        const int portion = portion_px;
+        size_t cursor = 0;  // into the stream area, the same on the pinned mirror and on the device
+        char *const hs = hp + off_stream, *const ds = dp + off_stream;
         for (;;) {
             const double ta = trace ? now() : 0;
             const int k0 = (int)m.pix.size();
@@ -956,15 +976,33 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             }
             fa.k0 = k0;
             fa.ts = ts;
+            // the portion's block: [pixel index | distance | schedule pixel | schedule order number] x got, [workgroup record] x nwg
+            const size_t a16 = 16, q = align_up((size_t)got * 4, a16);
+            const size_t b_idx = cursor, b_t = b_idx + q, b_pix = b_t + q, b_ord = b_pix + q, b_wg = b_ord + q, b_end = b_wg + align_up((size_t)nwg * 16, a16);
+            if (b_end > stream_bytes) return ofxcv_fail(ctx, OFXCV_ERR_HIP, "inpaint: portion schedule larger than its scratch");
+            {
+                int *pi = (int *)(hs + b_idx);
+                float *pt = (float *)(hs + b_t);
+                const float *tm = m.t.data();
+                for (int k = 0; k < got; k++) {
+                    const int px = m.pix[k0 + k];
+                    pi[k] = px;
+                    pt[k] = tm[px];
+                }
+            }
+            std::memcpy(hs + b_pix, sp.data() + k0, (size_t)got * 4);
+            std::memcpy(hs + b_ord, so.data() + k0, (size_t)got * 4);
+            std::memcpy(hs + b_wg, sw.data() + wg0 * 4, (size_t)nwg * 16);
             t_sched += trace ? now() - tb : 0;
-            if ((rc = scatter_front(k0, k1))) return rc;
-            std::memcpy(hp + off_pix + (size_t)k0 * 4, sp.data() + k0, (size_t)got * 4);
-            std::memcpy(hp + off_po + (size_t)k0 * 4, so.data() + k0, (size_t)got * 4);
-            std::memcpy(hp + off_wg + wg0 * 16, sw.data() + wg0 * 4, (size_t)nwg * 16);
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_pix + (size_t)k0 * 4, hp + off_pix + (size_t)k0 * 4, (size_t)got * 4, hipMemcpyHostToDevice, s));
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po + (size_t)k0 * 4, hp + off_po + (size_t)k0 * 4, (size_t)got * 4, hipMemcpyHostToDevice, s));
-            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_wg + wg0 * 16, hp + off_wg + wg0 * 16, (size_t)nwg * 16, hipMemcpyHostToDevice, s));
-            fa.cmp_off = (const int *)(dp + off_wg) + wg0 * 4;
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(ds + cursor, hs + cursor, b_end - cursor, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(map_scatter_front_kernel, dim3((got + 255) / 256), dim3(256), 0, s, (const int *)(ds + b_idx), (const float *)(ds + b_t), k0 + 1, got,
+                               d_t, d_ord);
+            OFXCV_LAUNCH_CHECK(ctx, "map_scatter_front_kernel");
+            // the workgroup records address the schedule arrays of the whole call (entry k0 is this block's first)
+            fa.lvl_pix = fa.cmp_pix = (const int *)((uintptr_t)(ds + b_pix) - (uintptr_t)k0 * 4);
+            fa.lvl_ord = fa.cmp_ord = (const int *)((uintptr_t)(ds + b_ord) - (uintptr_t)k0 * 4);
+            fa.lvl_off = fa.cmp_off = (const int *)(ds + b_wg);
+            cursor = b_end;
             if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
             else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
             OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
@@ -994,6 +1032,8 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_po, m.lvl_ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_wg, m.lvl_off.data(), m.lvl_off.size() * 4, hipMemcpyHostToDevice, s));
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(dp + off_lo, m.comp_off.data(), m.comp_off.size() * 4, hipMemcpyHostToDevice, s));
+        fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);  // (the pipelined fill had pointed these at its portions)
+        fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
         fa.lvl_off = fa.cmp_off = (const int *)(dp + off_wg);
         fa.err = nullptr;
         const int nwg = (int)m.comp_off.size() - 1;

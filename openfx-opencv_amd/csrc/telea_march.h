@@ -26,22 +26,57 @@ constexpr int kNeverFilled = INT_MAX;  // hole pixel the march never reaches (im
 // Pop order of CvPriorityQueueFloat: smallest T first, equal T in push order.  T is never negative while it is queued,
 // so its bit pattern orders like its value: one 64-bit key (T bits << 32 | push number) replaces the two-field compare,
 // and the pixel is looked up by push number.
+//
+// The queue itself is a bucket queue, not a binary heap (round 4; 111 -> 60 ns per hole pixel for the whole inward march on the
+// build host, tools/march_bench.cpp).  A pixel is pushed when one of its four neighbours pops, with a distance of at least that
+// neighbour's + 0.707 (FastMarching_solve with both arguments >= the popped distance; every other non-INSIDE neighbour is
+// still queued, i.e. not smaller either), so with buckets of 1/16 a push practically always lands in a LATER bucket than the
+// one being popped: it is appended there unsorted, and a bucket is sorted once, when the front reaches it, and then read off
+// in order.  Nothing depends on that argument: a key that does belong to the current bucket or an earlier one is inserted
+// into the sorted remainder where it belongs, so pop() returns the smallest queued key in every case -- the order of a heap.
 struct FrontQueue {
-    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> q;
-    std::vector<int> pi, pj;
+    static constexpr int kPerUnit = 16, kBuckets = 16 * 2048;  // distances >= 2048 share the last bucket
+    std::vector<std::vector<uint64_t>> later;  // later[b]: keys of bucket b > cb, in push order
+    std::vector<uint64_t> cur;                 // keys of the buckets <= cb, ascending; cur[0 .. ci) have popped
+    size_t ci = 0;
+    int cb = -1, hi = -1;                      // current bucket, highest bucket ever used
+    std::vector<uint64_t> px;                  // push number -> (i << 32 | j)
+    void clear() {
+        for (int b = 0; b <= hi && b < (int)later.size(); b++) later[b].clear();
+        cur.clear();
+        px.clear();
+        ci = 0;
+        cb = hi = -1;
+    }
     void push(int i, int j, float T) {
         uint32_t bits;
         std::memcpy(&bits, &T, 4);
-        q.push(((uint64_t)bits << 32) | (uint32_t)pi.size());
-        pi.push_back(i);
-        pj.push_back(j);
+        const uint64_t key = ((uint64_t)bits << 32) | (uint32_t)px.size();
+        px.push_back(((uint64_t)(uint32_t)i << 32) | (uint32_t)j);
+        const float s = T * (float)kPerUnit;
+        const int b = s >= (float)(kBuckets - 1) ? kBuckets - 1 : (int)s;  // monotone in T (T >= 0 while queued)
+        if (b > cb) {
+            if (later.empty()) later.resize(kBuckets);
+            later[b].push_back(key);
+            if (b > hi) hi = b;
+        } else {
+            cur.insert(std::lower_bound(cur.begin() + (ptrdiff_t)ci, cur.end(), key), key);
+        }
     }
     bool pop(int &i, int &j) {
-        if (q.empty()) return false;
-        const uint32_t seq = (uint32_t)q.top();
-        q.pop();
-        i = pi[seq];
-        j = pj[seq];
+        while (ci == cur.size()) {  // on to the next occupied bucket
+            int b = cb + 1;
+            while (b <= hi && later[b].empty()) b++;
+            if (b > hi) return false;
+            cur.clear();
+            cur.swap(later[b]);
+            std::sort(cur.begin(), cur.end());
+            ci = 0;
+            cb = b;
+        }
+        const uint64_t p = px[(uint32_t)cur[ci++]];
+        i = (int)(p >> 32);
+        j = (int)(uint32_t)p;
         return true;
     }
 };
@@ -92,14 +127,17 @@ struct March {
     // dataflow schedule (radius <= kMaxLdsRange): the pixels of each component in fill order, no levels
     std::vector<int> cmp_pix, cmp_ord, cmp_off;
     std::vector<int> touched;  // scratch of the ring march
+    std::vector<int> edge;     // hole pixels with a non-hole 8-neighbour (scratch of march_begin)
     std::vector<int> cmp_wg;   // per workgroup: {first pixel, end, first wavefront slot, slots in total}
     FrontQueue heap;           // the inward front
+    FrontQueue ringq;          // the outward front of the ring (Telea), emptied by march_begin itself
     int filled = 0;
     bool dirty = false;
     struct Par *par = nullptr;  // scratch of the component-parallel form of the inward march (march_parallel_run), kept between calls
     bool par_on = false;        // this call's order comes from the merged component streams
     std::vector<int> up_idx, up_ord, cell, stack;  // upload / scheduling scratch kept between calls
     std::vector<float> up_t, up_ft;
+    std::vector<int> sc_r, sc_c, sc_rt, sc_ct, sc_tile;  // scratch of the tile schedule (inpaint.hip: build_tile_portion)
 
     ~March() { par_free(par); }
     March() = default;
@@ -111,7 +149,7 @@ struct March {
         for (int p : seeds) { t[p] = 1.0e6f; band[p] = 0; }
         for (int p : ring_px) { t[p] = 1.0e6f; ring[p] = 0; }
         holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
-        heap = FrontQueue();
+        heap.clear();
         filled = 0;
         dirty = false;
     }
@@ -123,9 +161,10 @@ struct March {
             w = w_; h = h_;
             t.assign(en, 1.0e6f);
             ord.assign(en, 0);
-            mask.assign(en, 0); band.assign(en, 0); ring.assign(en, 0);
+            mask.assign(en + 8, 0);  // (+8: march_begin reads the map in 4-byte words)
+            band.assign(en, 0); ring.assign(en, 0);
             holes.clear(); seeds.clear(); ring_px.clear(); pix.clear(); touched.clear();
-            heap = FrontQueue(); filled = 0; dirty = false;
+            heap.clear(); filled = 0; dirty = false;
         } else if (dirty) {
             clear_sparse();
         }
@@ -140,28 +179,52 @@ inline bool march_begin(const uint8_t *mask_in, bool outside_ring, March &m) {
     m.dirty = true;
     uint8_t *mask = m.mask.data(), *band = m.band.data();
     std::vector<int> &holes = m.holes, &seeds = m.seeds;
-    for (int i = 0; i < h; i++) {
+    for (int i = 0; i < h; i++) {  // the hole pixels in row-major order; a frame is mostly zeros: eight bytes per test
         const uint8_t *row = mask_in + (size_t)i * w;
-        for (int j = 0; j < w; j++)
+        const int base = (i + 1) * ec + 1;
+        auto take = [&](int j) {
             if (row[j]) {
-                mask[(i + 1) * ec + j + 1] = INSIDE;
-                holes.push_back((i + 1) * ec + j + 1);
+                mask[base + j] = INSIDE;
+                holes.push_back(base + j);
             }
+        };
+        int j = 0;
+        for (; j + 8 <= w; j += 8) {
+            uint64_t v;
+            std::memcpy(&v, row + j, 8);
+            if (!v) continue;
+            for (int k = 0; k < 8; k++) take(j + k);
+        }
+        for (; j < w; j++) take(j);
     }
     if (holes.empty()) return false;
-    // band = dilate(mask, 3x3 cross) - mask, frame zeroed; seeds in row-major order
-    const int d4[4] = {-ec, -1, 1, ec};
-    for (int p : holes)
+    // band = dilate(mask, 3x3 cross) - mask, frame zeroed; seeds in row-major order.  Only hole pixels with a non-hole
+    // 8-neighbour have anything to add (to the band here, to the ring below): the map holds only KNOWN (0) and INSIDE (2) at this
+    // point, so the three 3-byte rows around p are all INSIDE exactly when their AND is -- one test per interior pixel.
+    const int d4[4] = {-ec, -1, 1, ec}, di4[4] = {-1, 0, 0, 1}, dj4[4] = {0, -1, 1, 0};
+    std::vector<int> &edge = m.edge;
+    edge.clear();
+    auto row3 = [&](int q) {
+        uint32_t v;
+        std::memcpy(&v, mask + q, 4);
+        return v;
+    };
+    for (int p : holes) {
+        if (((row3(p - ec - 1) & row3(p - 1) & row3(p + ec - 1)) & 0xFFFFFFu) == 0x010101u * (unsigned)INSIDE) continue;
+        edge.push_back(p);
+        const int pi = p / ec, pj = p - pi * ec;
         for (int q = 0; q < 4; q++) {
             const int n = p + d4[q];  // a hole pixel is never on the frame: its 4 neighbours are inside the map
-            const int ni = n / ec, nj = n - ni * ec;
+            const int ni = pi + di4[q], nj = pj + dj4[q];
             if (!mask[n] && !band[n] && ni > 0 && nj > 0 && ni < er - 1 && nj < ec - 1) {
                 band[n] = INSIDE;
                 seeds.push_back(n);
             }
         }
+    }
     std::sort(seeds.begin(), seeds.end());
-    FrontQueue outq;
+    FrontQueue &outq = m.ringq;
+    outq.clear();
     for (int n : seeds) {
         const int i = n / ec, j = n - i * ec;
         m.heap.push(i, j, 0);
@@ -175,12 +238,8 @@ inline bool march_begin(const uint8_t *mask_in, bool outside_ring, March &m) {
         // the hole is within r of a hole pixel that has a non-hole 8-neighbour, so only those spread the ring.
         uint8_t *ring = m.ring.data();
         bool any_ring = false;
-        for (int p : holes) {
+        for (int p : edge) {
             const int pi = p / ec, pj = p - pi * ec;
-            bool edge = false;
-            for (int di = -1; di <= 1 && !edge; di++)
-                for (int dj = -1; dj <= 1 && !edge; dj++) edge = !mask[(pi + di) * ec + pj + dj];
-            if (!edge) continue;
             any_ring = true;
             for (int a = std::max(pi - range, 1); a <= std::min(pi + range, er - 2); a++)
                 for (int c = std::max(pj - range, 1); c <= std::min(pj + range, ec - 2); c++)

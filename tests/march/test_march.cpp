@@ -54,8 +54,64 @@ static int run_case(int w, int h, unsigned seed, int blobs, int rmax, bool touch
     return par ? 0 : -1;  // -1: one piece, the serial form ran
 }
 
+// the bucket queue against a binary heap on arbitrary push / pop sequences: equal distances (push order decides), pushes
+// below the distance that popped last (never produced by a front, served all the same), distances beyond the last bucket
+static int queue_case(unsigned seed) {
+    std::mt19937 rng(seed);
+    FrontQueue q;
+    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> ref;
+    std::vector<std::pair<int, int>> who;
+    float last = 0.f;
+    for (int step = 0; step < 20000; step++) {
+        const unsigned r = rng() % 100;
+        if (r < 55 || ref.empty()) {
+            float T;
+            const unsigned kind = rng() % 20;
+            if (kind == 0) T = last * (float)(rng() % 1000) / 1000.f;               // behind the front
+            else if (kind == 1) T = last;                                            // a tie with what just popped
+            else if (kind == 2) T = 1.0e6f + (float)(rng() % 3);                      // the last bucket
+            else if (kind == 3) T = (float)(rng() % 64) / 16.f;                       // exact bucket edges, many ties
+            else T = last + (float)(rng() % 4000) / 1000.f;
+            const int i = (int)(rng() % 5000), j = (int)(rng() % 5000);
+            uint32_t bits;
+            std::memcpy(&bits, &T, 4);
+            ref.push(((uint64_t)bits << 32) | (uint32_t)who.size());
+            who.push_back({i, j});
+            q.push(i, j, T);
+        } else {
+            const uint64_t k = ref.top();
+            ref.pop();
+            int i = -1, j = -1;
+            if (!q.pop(i, j) || i != who[(uint32_t)k].first || j != who[(uint32_t)k].second) return 1;
+            const uint32_t bits = (uint32_t)(k >> 32);
+            std::memcpy(&last, &bits, 4);
+            if (last > 1000.f) last = 0.f;
+        }
+    }
+    while (!ref.empty()) {
+        const uint64_t k = ref.top();
+        ref.pop();
+        int i, j;
+        if (!q.pop(i, j) || i != who[(uint32_t)k].first || j != who[(uint32_t)k].second) return 1;
+    }
+    int i, j;
+    if (q.pop(i, j)) return 1;
+    q.clear();  // and again on the cleared queue
+    q.push(3, 4, 2.5f);
+    q.push(5, 6, 0.25f);
+    if (!q.pop(i, j) || i != 5 || !q.pop(i, j) || i != 3 || q.pop(i, j)) return 1;
+    return 0;
+}
+
 int main() {
     int bad = 0, parallel = 0, cases = 0;
+    for (unsigned seed = 1; seed <= 40; seed++) {
+        cases++;
+        if (queue_case(seed)) {
+            std::printf("bucket queue differs from the heap, seed %u\n", seed);
+            bad++;
+        }
+    }
     for (unsigned seed = 1; seed <= 60; seed++) {
         const int w = 40 + (seed * 37) % 300, h = 30 + (seed * 53) % 200;
         for (int touching = 0; touching < 2; touching++) {
