@@ -82,6 +82,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
  *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
+ *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share
+ *                                    of the chip: 192 over the fills in flight, at least 48);
  *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back.
  * Unknown names and values outside an option's range are rejected with OFXCV_ERR_INVALID.  (Geometry hooks of the two strip-parallel
  * kernels used by the tests -- "farneback.halo_*", "farneback.col_geom", "farneback.col_trace" -- are listed in csrc/common.h; they select

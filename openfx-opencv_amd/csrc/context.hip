@@ -257,6 +257,11 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_parallel_march = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "inpaint.max_tiles")) {
+        if (value < 0 || value > 240) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint.max_tiles: 0 (automatic) .. 240");
+        ctx->ip_max_tiles = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "inpaint.tiles")) {
         ctx->ip_tiles = value != 0;
         return OFXCV_OK;

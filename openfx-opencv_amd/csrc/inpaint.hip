@@ -250,15 +250,18 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
 // occupied tile, its 16 wavefronts taking the tile's pixels round-robin in fill order.  Dependencies are spatially local (window
 // radius range + 2), so most of a pixel's predecessors lie in its own tile and reach it through the workgroup's LDS slots
 // (telea_fill_kernel: `ts`); only those across a tile edge go through the L2.  Every workgroup of the launch can wait for any
-// other, so all of them must be resident at once: the caller caps the number of tiles (kMaxTileGroups x kMaxConcurrentFills
-// workgroups of 1024 threads fit the chip one per CU) and picks the tile size for it; returns -1 if even the largest does not do.
-constexpr int kMaxTileGroups = 48;
+// other, so all of them must be resident at once: the caller caps the number of tiles (`max_tiles`: this call's share of the
+// kTileBudget workgroups of 1024 threads the chip holds one per CU with room to spare) and the smallest tile size that stays under
+// the cap is taken; returns -1 if even the largest does not do.  A launch takes as long as its fullest tile (16 wavefronts, ~10 us
+// per pixel and wavefront): more and smaller tiles shorten it (48 -> 192 tiles, 16-pixel tiles allowed: the launches of the
+// middle of a 1080p fill 240-390 -> 110-230 us; the last two, the dense centres of the holes, stay chain-bound at ~600 us each).
+constexpr int kTileBudget = 192, kMinTileGroups = 48;
 int build_tile_portion(March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
-                       std::vector<int> &cell, int &ts_out) {
+                       std::vector<int> &cell, int &ts_out, int max_tiles) {
     const int ec = m.w + 2, er = m.h + 2;
     const int n = k1 - k0;
     if (n <= 0) return 0;
-    static const int sizes[] = {32, 48, 64, 96, 128, 192, 256, 384, 512};
+    static const int sizes[] = {16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512};
     // row and column of every pixel once (one division each), the tile of a row / column from a table per tile size: the passes
     // below cost no division per pixel (they had four each: 1.2 of the 11.5 ms of a 1080p call)
     std::vector<int> &pr = m.sc_r, &pc = m.sc_c, &rt = m.sc_rt, &ct = m.sc_ct, &tile = m.sc_tile;  // scratch kept with the context
@@ -275,12 +278,12 @@ int build_tile_portion(March &m, int k0, int k1, std::vector<int> &sched_pix, st
         for (int j = 0; j < ec; j++) ct[j] = j / ts;
         cell.assign((size_t)gw * gh, -1);
         int ntile = 0, k = 0;
-        for (; k < n && ntile <= kMaxTileGroups; k++) {
+        for (; k < n && ntile <= max_tiles; k++) {
             int &c = cell[(size_t)rt[pr[k]] + ct[pc[k]]];
             if (c < 0) c = ntile++;
             tile[k] = c;
         }
-        if (ntile > kMaxTileGroups) continue;
+        if (ntile > max_tiles) continue;
         std::vector<int> off(ntile + 1, 0);
         for (k = 0; k < n; k++) off[tile[k] + 1]++;
         for (int t = 0; t < ntile; t++) off[t + 1] += off[t];
@@ -409,6 +412,63 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 {
                 const int i = p / ec, j = p - i * ec;
                 const int wi0 = i - range - 1, wj0 = j - range - 1;  // padded coordinates of the staged window's corner
+                auto ORD = [&](int r, int c) -> int { return LDSWIN ? s_word[wave][(r - wi0) * ws + (c - wj0)] : a.ord[r * ec + c]; };
+                auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
+                // What a window tap (one per lane and chunk of 64) needs of the maps alone: is it a tap at all, which neighbours
+                // of it count as known, and -- Telea -- its weight.  With the window in LDS this runs before the polls.
+                struct TapSetup {
+                    bool on;
+                    int km, kp, lm, lp;
+                    float rx, ry, vl, wgt;
+                    bool r_in, l_in, d_in, u_in;
+                };
+                constexpr int kChunks = LDSWIN ? (kWinMax + 63) / 64 : 1;
+                TapSetup pre[kChunks];
+                float Tij = 0.f, gTx = 0.f, gTy = 0.f;
+                auto tap_setup = [&](int tap) -> TapSetup {
+                    TapSetup ts_;
+                    ts_.on = false;
+                    ts_.km = ts_.kp = ts_.lm = ts_.lp = 0;
+                    ts_.rx = ts_.ry = ts_.vl = ts_.wgt = 0.f;
+                    ts_.r_in = ts_.l_in = ts_.d_in = ts_.u_in = false;
+                    if (tap >= ntap) return ts_;
+                    const int k = i - range + tap / side, l = j - range + tap % side;
+                    if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1 && (l - j) * (l - j) + (k - i) * (k - i) <= range * range && ORD(k, l) < o)) return ts_;
+                    ts_.on = true;
+                    ts_.km = k - 1 + (k == 1);
+                    ts_.kp = k - 1 - (k == er - 2);
+                    ts_.lm = l - 1 + (l == 1);
+                    ts_.lp = l - 1 - (l == ec - 2);
+                    ts_.ry = (float)(i - k);
+                    ts_.rx = (float)(j - l);
+                    ts_.vl = ts_.rx * ts_.rx + ts_.ry * ts_.ry;
+                    ts_.r_in = ORD(k, l + 1) >= o;
+                    ts_.l_in = ORD(k, l - 1) >= o;
+                    ts_.d_in = ORD(k + 1, l) >= o;
+                    ts_.u_in = ORD(k - 1, l) >= o;
+                    if (!NS) {
+                        const float dst = (float)(1. / (ts_.vl * sqrt((double)ts_.vl)));
+                        const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
+                        float dir = ts_.rx * gTx + ts_.ry * gTy;
+                        if (fabs(dir) <= 0.01) dir = 0.000001f;
+                        ts_.wgt = (float)fabs(dst * lev * dir);
+                    }
+                    return ts_;
+                };
+                auto centre = [&]() {  // the pixel's own distance and the gradient of the distance map at it
+                    Tij = TT(i, j);
+                    const bool r_in = ORD(i, j + 1) >= o, l_in = ORD(i, j - 1) >= o, d_in = ORD(i + 1, j) >= o, u_in = ORD(i - 1, j) >= o;
+                    if (!r_in) gTx = !l_in ? (TT(i, j + 1) - TT(i, j - 1)) * 0.5f : (TT(i, j + 1) - Tij);
+                    else gTx = !l_in ? (Tij - TT(i, j - 1)) : 0.f;
+                    if (!d_in) gTy = !u_in ? (TT(i + 1, j) - TT(i - 1, j)) * 0.5f : (TT(i + 1, j) - Tij);
+                    else gTy = !u_in ? (Tij - TT(i - 1, j)) : 0.f;
+                };
+                auto pre_taps = [&]() {
+                    centre();
+#pragma unroll
+                    for (int c = 0; c < kChunks; c++)
+                        if (64 * c < ntap) pre[c] = tap_setup(64 * c + lane);
+                };
                 if (LDSWIN) {
                     // all loads that do not depend on other pixels' results first (maps, original colours), then the
                     // polls: the only thing on the dependency chain is the round trip of the awaited colours
@@ -445,6 +505,19 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                             }
                         }
                     }
+                    // order numbers and distances do not depend on anybody's colour: staged now, so that everything the taps need of
+                    // them (the weights with their two double divisions and the square root, Telea) is computed BEFORE the polls --
+                    // off the dependency chain between a pixel and the pixels that wait for it
+#pragma unroll
+                    for (int u = 0; u < kEl; u++) {
+                        const int e = lane + 64 * u;
+                        if (e < ws * ws) {
+                            s_word[wave][e] = q[u];
+                            s_wt[wave][e] = tv[u];
+                        }
+                    }
+                    wave_lds_sync();
+                    pre_taps();
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         int spins = 0;
@@ -480,75 +553,49 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         const int e = lane + 64 * u;
-                        if (e < ws * ws) {
-                            s_word[wave][e] = q[u];
-                            s_wt[wave][e] = tv[u];
-                            s_wrgb[wave][e] = rgb[u];
-                        }
+                        if (e < ws * ws) s_wrgb[wave][e] = rgb[u];
                     }
                     wave_lds_sync();
                 }
-                auto ORD = [&](int r, int c) -> int { return LDSWIN ? s_word[wave][(r - wi0) * ws + (c - wj0)] : a.ord[r * ec + c]; };
-                auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
                 // image pixel (ir,ic) [image coordinates], channel ch
                 auto IMG = [&](int ir, int ic, int ch) -> float {
                     uint32_t v = LDSWIN ? s_wrgb[wave][(ir + 1 - wi0) * ws + (ic + 1 - wj0)] : resolve(ir + 1, ic + 1, a.ord[(ir + 1) * ec + ic + 1], o);
                     return (float)((v >> (8 * ch)) & 255u);
                 };
-                const float Tij = TT(i, j);
-                float gTx, gTy;
-                {
-                    const bool r_in = ORD(i, j + 1) >= o, l_in = ORD(i, j - 1) >= o, d_in = ORD(i + 1, j) >= o, u_in = ORD(i - 1, j) >= o;
-                    if (!r_in) gTx = !l_in ? (TT(i, j + 1) - TT(i, j - 1)) * 0.5f : (TT(i, j + 1) - Tij);
-                    else gTx = !l_in ? (Tij - TT(i, j - 1)) : 0.f;
-                    if (!d_in) gTy = !u_in ? (TT(i + 1, j) - TT(i - 1, j)) * 0.5f : (TT(i + 1, j) - Tij);
-                    else gTy = !u_in ? (Tij - TT(i - 1, j)) : 0.f;
-                }
+                if (!LDSWIN) centre();
                 // lanes 0..9: the sequential accumulator they own (s starts at 1e-20)
                 float run = (NS ? (lane >= 3 && lane < 6) : lane == kAcc - 1) ? 1.0e-20f : 0.f;
-                for (int t0 = 0; t0 < ntap; t0 += 64) {
+                auto chunk = [&](const int t0, const TapSetup &tp) {
                     // phase 1: one window tap per lane
                     float term[kAcc];
 #pragma unroll
                     for (int q = 0; q < kAcc; q++) term[q] = 0.f;
-                    const int tap = t0 + lane;
-                    if (tap < ntap) {
-                        const int k = i - range + tap / side, l = j - range + tap % side;
-                        if (k > 0 && l > 0 && k < er - 1 && l < ec - 1 && (l - j) * (l - j) + (k - i) * (k - i) <= range * range && ORD(k, l) < o) {
-                            const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
-                            const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
-                            const float ry = (float)(i - k), rx = (float)(j - l);
-                            const float vl = rx * rx + ry * ry;
-                            if (NS) {
-                                const float dst = 1 / (vl * vl + 1);
-                                const bool r_in = ORD(k, l + 1) >= o, l_in = ORD(k, l - 1) >= o;
-                                const bool d_in = ORD(k + 1, l) >= o, u_in = ORD(k - 1, l) >= o;
+                    if (tp.on) {
+                        const int km = tp.km, kp = tp.kp, lm = tp.lm, lp = tp.lp;
+                        const float rx = tp.rx, ry = tp.ry, vl = tp.vl;
+                        const bool r_in = tp.r_in, l_in = tp.l_in, d_in = tp.d_in, u_in = tp.u_in;
+                        if (NS) {
+                            const float dst = 1 / (vl * vl + 1);
 #pragma unroll
-                                for (int ch = 0; ch < 3; ch++) {
-                                    auto I = [&](int r, int c) { return (int)IMG(r, c, ch); };
-                                    float gx, gy;
-                                    if (!d_in) gx = !u_in ? (float)(abs(I(kp + 1, lm) - I(kp, lm)) + abs(I(kp, lm) - I(km - 1, lm)))
-                                                          : (float)(abs(I(kp + 1, lm) - I(kp, lm))) * 2.0f;
-                                    else gx = !u_in ? (float)(abs(I(kp, lm) - I(km - 1, lm))) * 2.0f : 0.f;
-                                    if (!r_in) gy = !l_in ? (float)(abs(I(km, lp + 1) - I(km, lm)) + abs(I(km, lm) - I(km, lm - 1)))
-                                                          : (float)(abs(I(km, lp + 1) - I(km, lm))) * 2.0f;
-                                    else gy = !l_in ? (float)(abs(I(km, lm) - I(km, lm - 1))) * 2.0f : 0.f;
-                                    gx = -gx;
-                                    float dir = rx * gx + ry * gy;
-                                    if (fabs(dir) <= 0.01) dir = 0.000001f;
-                                    else dir = (float)fabs((rx * gx + ry * gy) / sqrt((double)(vl * (gx * gx + gy * gy))));
-                                    const float wgt = dst * dir;
-                                    term[ch] = wgt * IMG(km, lm, ch);
-                                    term[3 + ch] = wgt;
-                                }
-                            } else {
-                            const float dst = (float)(1. / (vl * sqrt((double)vl)));
-                            const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
-                            float dir = rx * gTx + ry * gTy;
-                            if (fabs(dir) <= 0.01) dir = 0.000001f;
-                            const float wgt = (float)fabs(dst * lev * dir);
-                            const bool r_in = ORD(k, l + 1) >= o, l_in = ORD(k, l - 1) >= o;
-                            const bool d_in = ORD(k + 1, l) >= o, u_in = ORD(k - 1, l) >= o;
+                            for (int ch = 0; ch < 3; ch++) {
+                                auto I = [&](int r, int c) { return (int)IMG(r, c, ch); };
+                                float gx, gy;
+                                if (!d_in) gx = !u_in ? (float)(abs(I(kp + 1, lm) - I(kp, lm)) + abs(I(kp, lm) - I(km - 1, lm)))
+                                                      : (float)(abs(I(kp + 1, lm) - I(kp, lm))) * 2.0f;
+                                else gx = !u_in ? (float)(abs(I(kp, lm) - I(km - 1, lm))) * 2.0f : 0.f;
+                                if (!r_in) gy = !l_in ? (float)(abs(I(km, lp + 1) - I(km, lm)) + abs(I(km, lm) - I(km, lm - 1)))
+                                                      : (float)(abs(I(km, lp + 1) - I(km, lm))) * 2.0f;
+                                else gy = !l_in ? (float)(abs(I(km, lm) - I(km, lm - 1))) * 2.0f : 0.f;
+                                gx = -gx;
+                                float dir = rx * gx + ry * gy;
+                                if (fabs(dir) <= 0.01) dir = 0.000001f;
+                                else dir = (float)fabs((rx * gx + ry * gy) / sqrt((double)(vl * (gx * gx + gy * gy))));
+                                const float wgt = dst * dir;
+                                term[ch] = wgt * IMG(km, lm, ch);
+                                term[3 + ch] = wgt;
+                            }
+                        } else {
+                            const float wgt = tp.wgt;
 #pragma unroll
                             for (int ch = 0; ch < 3; ch++) {
                                 float gIx, gIy;
@@ -561,7 +608,6 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                                 term[6 + ch] = wgt * (gIy * ry);
                             }
                             term[9] = wgt;
-                            }
                         }
                     }
 #pragma unroll
@@ -571,20 +617,35 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     if (lane < kAcc) {
                         const bool minus = !NS && lane >= 3 && lane < 9;  // Telea: Jx, Jy are accumulated with -=
                         const int lim = min(64, ntap - t0);
-                        int tt = 0;
-                        for (; tt + 8 <= lim; tt += 8) {  // batches of independent LDS reads, then the ordered adds
-                            float v[8];
+                        // The ordered adds are the chain; the LDS reads are not: batch b+1 is requested before batch b is added up.
+                        // Rows lim .. 63 hold zeros (lanes without a tap store zero terms): whole batches, no per-row conditions.
+                        constexpr int kB = 8;
+                        const int nb = (lim + kB - 1) / kB;
+                        float v0[kB], v1[kB];
 #pragma unroll
-                            for (int u = 0; u < 8; u++) v[u] = s_terms[wave][tt + u][lane];
+                        for (int u = 0; u < kB; u++) v0[u] = s_terms[wave][u][lane];
+                        for (int b = 0; b < nb; b++) {
+                            if (b + 1 < nb) {
 #pragma unroll
-                            for (int u = 0; u < 8; u++) run = minus ? run - v[u] : run + v[u];
-                        }
-                        for (; tt < lim; tt++) {
-                            float v = s_terms[wave][tt][lane];
-                            run = minus ? run - v : run + v;
+                                for (int u = 0; u < kB; u++) v1[u] = s_terms[wave][(b + 1) * kB + u][lane];
+                            }
+                            // run - v is run + (-v) exactly: the sign is applied to the term (off the chain), the chain is one add per tap
+#pragma unroll
+                            for (int u = 0; u < kB; u++) v0[u] = minus ? -v0[u] : v0[u];
+#pragma unroll
+                            for (int u = 0; u < kB; u++) run = run + v0[u];
+#pragma unroll
+                            for (int u = 0; u < kB; u++) v0[u] = v1[u];
                         }
                     }
                     wave_lds_sync();
+                };
+                if (LDSWIN) {
+#pragma unroll
+                    for (int c = 0; c < kChunks; c++)  // (constant indices into `pre`: it stays in registers)
+                        if (64 * c < ntap) chunk(64 * c, pre[c]);
+                } else {
+                    for (int t0 = 0; t0 < ntap; t0 += 64) chunk(t0, tap_setup(t0 + lane));
                 }
                 if (lane < kAcc) s_acc[wave][lane] = run;
                 wave_lds_sync();
@@ -711,6 +772,10 @@ public:
     ~FillSlot() {
         { std::lock_guard<std::mutex> lk(mu()); --in_flight(); }
         cv().notify_one();
+    }
+    static int active() {  // fills in flight right now, this one included
+        std::lock_guard<std::mutex> lk(mu());
+        return in_flight();
     }
     FillSlot(const FillSlot &) = delete;
     FillSlot &operator=(const FillSlot &) = delete;
@@ -967,7 +1032,11 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             // tile schedule (default): a workgroup per occupied tile, hand-offs inside a tile through LDS; the component schedule
             // (1..8 workgroups per connected group of pixels, every hand-off through the L2) where the tiles do not fit
             int nwg = -1, ts = 0;
-            if (ctx->ip_tiles && got <= kFillSlots) nwg = build_tile_portion(m, k0, k1, sp, so, sw, m.cell, ts);
+            // This call's share of the chip, re-read per portion: 192 resident workgroups over the fills in flight (four at most:
+            // 48 each).  A fill that starts while another one's larger launch is still running finds some of its workgroups queued
+            // behind it for the rest of that launch (a fraction of a millisecond: the older launch is resident and waits for nobody).
+            const int max_tiles = ctx->ip_max_tiles > 0 ? ctx->ip_max_tiles : std::max(kMinTileGroups, kTileBudget / std::max(1, FillSlot::active()));
+            if (ctx->ip_tiles && got <= kFillSlots) nwg = build_tile_portion(m, k0, k1, sp, so, sw, m.cell, ts, max_tiles);
             if (nwg < 0) {
                 ts = 0;
                 m.cell.clear();  // the tile pass leaves the grid in another geometry

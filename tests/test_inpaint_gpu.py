@@ -163,6 +163,43 @@ def test_concurrent_inpaint_calls(oracle, ofxcv):
         assert np.array_equal(results[k], ref), k
 
 
+@pytest.mark.timeout(300)
+def test_concurrent_large_fills_share_the_tile_budget(oracle, ofxcv):
+    """Four host threads inpaint a 1280x720 frame at once.  A fill launch takes its share of the chip's resident workgroups
+    (192 over the fills in flight, re-read per portion of the fill order), so calls that start while another call's larger
+    launch is running overlap with it: every result must still be the oracle's, and so must a call with the cap forced to
+    its extremes."""
+    import threading
+    fr = _frame(1280, 720, holes=12)
+    ref = oracle.inpaint_render(fr, 3.0, 1.0)
+    results, errors, fallbacks = {}, [], []
+
+    def work(k):
+        try:
+            c = ofxcv.Context(0)
+            for _ in range(3):
+                results[k] = c.inpaint_render_host(fr, 3.0, 1.0)
+            fallbacks.append(c.inpaint_fallback_count())
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        assert np.array_equal(results[k], ref), k
+    print("fallbacks of the four concurrent contexts:", fallbacks)
+    for cap in (1, 48, 240):
+        c = ofxcv.Context(0)
+        c.set_option("inpaint.max_tiles", cap)
+        assert np.array_equal(c.inpaint_render_host(fr, 3.0, 1.0), ref), cap
+        c.close()
+
+
 def test_index_map_known_answers_on_the_hip_path(gpu_ctx):
     """The analytic known-answer tests that pin the oracle (tests/test_oracle_inpaint_segment.py) run against the maps
     ofxcv_inpaint_telea itself returns, so the distance / fill-order parity is not only oracle-vs-product: straight-edge
