@@ -80,6 +80,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "host.register"           0|1|2  how ofxcv_vectorgen_flow(s)_host moves host images: 1 (default) asynchronous copies straight from / into
  *                                    the host's pageable images; 2 the host's buffers registered (hipHostRegister) for the duration of the
  *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
+ *   "host.split"              0|1|2  ofxcv_vectorgen_flows_host with two directions: 0 one batched Farneback call after the third upload; 1 two
+ *                                    single-pair calls, the first while the third frame is still on the wire; 2 (default) 1 while this is the
+ *                                    only host-image call in flight in the process, else 0 (several render threads keep the link busy anyway);
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
  *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
  *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share
@@ -89,7 +92,8 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  * kernels used by the tests -- "farneback.halo_*", "farneback.col_geom", "farneback.col_trace" -- are listed in csrc/common.h; they select
  * forms the library otherwise picks by level size and never change a result.) */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
-/* current value of "farneback.opencv_rounding", "farneback.graph", "farneback.fuse_iterations", "host.register", "farneback.batch_mb",
+/* current value of "farneback.opencv_rounding", "farneback.graph", "farneback.fuse_iterations", "host.register", "host.split",
+ * "host.split_calls" (host-image calls that took the split form), "farneback.batch_mb",
  * "farneback.col", "farneback.col_min", "farneback.gaussian_kernel_generation", "farneback.resize_generation", and "farneback.col_aborts":
  * 1 if a bounded wait inside iterate_col_kernel ever ran out (waits for the context's streams: a test hook) */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);

@@ -127,6 +127,10 @@ struct ofxcv_ctx {
 
     int host_register = 1;         // option "host.register": 0 stage through the pinned ring; 1 (default) copies straight from / into the host's
                                    // pageable images; 2 the host's images registered for the duration of the call (zero copy)
+    int host_split = 2;            // option "host.split": the two flows of an output frame as two single-pair calls, the first one while the
+                                   // third frame is still on the wire (1), as one batched call after the third upload (0), or 1 when this
+                                   // is the only host-image call in flight in the process and 0 otherwise (2, default)
+    long host_split_calls = 0;
     long host_direct_calls = 0;
     long host_zero_copy_calls = 0, host_staged_calls = 0;
 

@@ -241,6 +241,11 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->host_register = value < 0 ? 0 : (value > 2 ? 1 : value);
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "host.split")) {
+        if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "host.split: 0, 1 or 2");
+        ctx->host_split = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "inpaint.pixels_per_workgroup")) {
         ctx->ip_per_wg = value;
         return OFXCV_OK;
@@ -314,6 +319,8 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
+    else if (!std::strcmp(name, "host.split")) *value = ctx->host_split;
+    else if (!std::strcmp(name, "host.split_calls")) *value = (int)ctx->host_split_calls;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;
     else if (!std::strcmp(name, "farneback.col_min")) *value = ctx->fb_col_min;

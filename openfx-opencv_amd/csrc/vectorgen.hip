@@ -340,6 +340,20 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         }
     } drain{ctx};
 
+    // Two directions, one calling thread: a synchronous call cannot overlap its uploads with anybody else's kernels, but it can
+    // with its own -- the forward pair only needs the first two frames, so it runs as a single-pair call while the third frame
+    // is still on the wire (0.7 ms of a 1080p frame), and the backward pair after it.  Two single-pair calls take ~0.3 ms more GPU
+    // time than one batched call of two, which is why several render threads at once (they keep link and GPU busy between them)
+    // stay with the batched form.  Same results either way (a batch is bit-identical to its single calls).
+    // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+    const size_t gsteps[2] = {gray_pitch, gray_pitch}, fsteps[2] = {(size_t)width * 8, (size_t)width * 8};
+    struct InFlight {
+        static std::atomic<int> &n() { static std::atomic<int> v{0}; return v; }
+        int mine;
+        InFlight() : mine(n().fetch_add(1) + 1) {}
+        ~InFlight() { n().fetch_sub(1); }
+    } in_flight;
+    const bool split = n_other == 2 && (ctx->host_split == 1 || (ctx->host_split == 2 && in_flight.mine == 1));
     // uploads on the copy stream; the compute stream converts frame f as soon as it has arrived
     const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ring: ~4 MiB per DMA
     for (int f = 0; f < nf; f++) {
@@ -360,18 +374,26 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
                                                     hipMemcpyHostToDevice, ctx->copy));
             }
         }
+        // (a copy from pageable memory returns when the runtime has staged the frame: the kernels of the frames before it are
+        // enqueued before the next upload starts, and run during it)
         OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
         rc = ofxcv_to_byte_grayscale(ctx, (const float *)d_frame[f], (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
         if (rc) return rc;
+        if (split && f >= 1) {  // frames 0 and f are there: direction f-1
+            const uint8_t *prevs[1] = {d_gray[0]}, *nexts[1] = {d_gray[f]};
+            rc = ofxcv_calc_optical_flow_farneback_batch(ctx, 1, prevs, gsteps, nexts, gsteps, &d_flow[f - 1], fsteps, width, height, 0.5, levels, 3,
+                                                         iterations, poly_n, poly_sigma, 0, ctx->compute);
+            if (rc) return rc;
+        }
     }
     if (direct_up) ctx->host_direct_calls++;
     else ctx->host_staged_calls++;
+    if (split) ctx->host_split_calls++;
     // The two flows of an output frame are independent pairs with the same first frame: one batched call (every launch of
-    // the level walk carries both).  VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
-    {
+    // the level walk carries both).
+    if (!split) {
         const uint8_t *prevs[2] = {d_gray[0], d_gray[0]}, *nexts[2] = {d_gray[1], n_other > 1 ? d_gray[2] : nullptr};
-        const size_t gsteps[2] = {gray_pitch, gray_pitch}, fsteps[2] = {(size_t)width * 8, (size_t)width * 8};
         rc = ofxcv_calc_optical_flow_farneback_batch(ctx, n_other, prevs, gsteps, nexts, gsteps, d_flow, fsteps, width, height, 0.5, levels, 3,
                                                      iterations, poly_n, poly_sigma, 0, ctx->compute);
         if (rc) return rc;

@@ -248,3 +248,31 @@ def test_host_path_forms_agree(ofxcv):
     assert zc.host_zero_copy_calls() == n_reg + 1
     for c in (direct, zc, ring):
         c.close()
+
+
+def test_host_path_split_form_gives_the_same_frame(ofxcv):
+    """With two directions the forward pair can run as a single-pair call while the third frame is still being uploaded
+    (option host.split = 1; 2 = only while no other host-image call is in flight, the default) instead of one batched call after
+    the last upload (0): the same output frame, through the direct copies and through the pinned ring, and the counter tells
+    which form ran."""
+    from openfx_opencv_amd import synth
+    w, h = 333, 200
+    ref, nxt = synth.flow_pair(w, h, seed=7)
+    prev, _ = synth.flow_pair(w, h, seed=19)
+    outs = {}
+    for reg in (1, 0):
+        for split in (0, 1, 2):
+            c = ofxcv.Context(0)
+            c.set_option("host.register", reg)
+            c.set_option("host.split", split)
+            for fu, fv, bu, bv in ((1, 2, 4, 8), (1, 0, 0, 8)):
+                o = np.full((h, w, 4), -3.0, np.float32)
+                c.vectorgen_flows_host(ref, nxt, prev, o, fu, fv, bu, bv)
+                outs[(reg, split, fu)] = o
+            assert c.get_option("host.split_calls") == (0 if split == 0 else 2), (reg, split)
+            one = np.zeros((h, w, 4), np.float32)       # one direction: nothing to split
+            c.vectorgen_flow_host(ref, nxt, one, 0b0101, 0b1010)
+            assert c.get_option("host.split_calls") == (0 if split == 0 else 2)
+            c.close()
+    for key, o in outs.items():
+        assert np.array_equal(o, outs[(1, 0, key[2])]), key
