@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--separate-f7", action="store_true", help="A/B: flow -> RGBA as its own launch per pair (ofxcv_flow_to_rgba) instead of "
                                                                "inside the Farneback call (ofxcv_calc_optical_flow_farneback_batch_rgba)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
+    ap.add_argument("--no-batch16", action="store_true", help="skip the batches-of-16 leg (counter passes: its launches have the grids of other levels' launches of 8)")
     ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
                     "3840x2160 is configs[4] (64 pairs over 8 GPUs)")
     ap.add_argument("--config", type=int, default=0, help="5 = BASELINE configs[4]: --size 3840x2160 --batch 8 (64 pairs over 8 GPUs, seeds 1234...1297)")
@@ -371,6 +372,7 @@ def main():
         for c in c3:
             c.close()
         del b3
+    if world == 1 and not args.no_batch16:
         # twice the pairs per call: the 960x540 level then has 256 workgroups as well and takes the column-owning form
         c16 = make_ctxs(1, direct=False)
         b16 = make_bufs(c16, W, H, 16)

@@ -379,7 +379,6 @@ __global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__rest
 template <bool LDSWIN, bool NS>
 __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
     __shared__ float s_terms[kFillWaves][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
-    __shared__ float s_acc[kFillWaves][kAcc];
     __shared__ int s_word[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
     __shared__ float s_wt[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
     __shared__ uint32_t s_wrgb[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
@@ -647,21 +646,32 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 } else {
                     for (int t0 = 0; t0 < ntap; t0 += 64) chunk(t0, tap_setup(t0 + lane));
                 }
-                if (lane < kAcc) s_acc[wave][lane] = run;
-                wave_lds_sync();
-                // phase 3: lane ch finishes channel ch, lane 0 stores the pixel as one dword
+                // phase 3: lane ch finishes channel ch, lane 0 stores the pixel as one dword.  The sums travel between lanes by DPP row
+                // shifts and readlane, the three bytes by readlane: this stretch is on the pixel -> pixel chain (it went through LDS
+                // and ds_bpermute before).
+                auto from_lane_plus = [&](float v, int d) {  // lane l <- lane l + d (d = 3 or 6, inside a row of 16)
+                    const int iv = __builtin_bit_cast(int, v);
+                    return __builtin_bit_cast(float, d == 3 ? __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xf, 0xf, true)
+                                                            : __builtin_amdgcn_update_dpp(0, iv, 0x106, 0xf, 0xf, true));
+                };
                 uint32_t byte = 0;
-                if (NS && lane < 3) {
-                    const float Ia = s_acc[wave][lane], sw = s_acc[wave][3 + lane];
-                    int iv = (int)rint((double)Ia / sw);  // saturate_cast<uchar>(double)
-                    byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
-                } else if (lane < 3) {
-                    const float Ia = s_acc[wave][lane], Jx = s_acc[wave][3 + lane], Jy = s_acc[wave][6 + lane], sw = s_acc[wave][9];
-                    const float sat = (float)((Ia / sw + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
-                    int iv = (int)rintf(sat);  // cvRound, then saturate
-                    byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+                if (NS) {
+                    const float sw = from_lane_plus(run, 3);
+                    if (lane < 3) {
+                        int iv = (int)rint((double)run / sw);  // saturate_cast<uchar>(double)
+                        byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+                    }
+                } else {
+                    const float Jx = from_lane_plus(run, 3), Jy = from_lane_plus(run, 6);
+                    const float sw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, run), 9));
+                    if (lane < 3) {
+                        const float Ia = run;
+                        const float sat = (float)((Ia / sw + (Jx + Jy) / (sqrtf(Jx * Jx + Jy * Jy) + 1.0e-20f) + 0.5f));
+                        int iv = (int)rintf(sat);  // cvRound, then saturate
+                        byte = (uint32_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+                    }
                 }
-                const uint32_t g = __shfl(byte, 1), bl = __shfl(byte, 2);
+                const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)byte, 1), bl = (uint32_t)__builtin_amdgcn_readlane((int)byte, 2);
                 if (lane == 0) {
                     const size_t at = (size_t)(i - 1) * a.w + (j - 1);
                     const uint32_t px = byte | (g << 8) | (bl << 16) | 0x01000000u;

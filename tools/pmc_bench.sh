@@ -7,7 +7,7 @@ CALLS=2; BATCH=8
 i=0
 for set in "$@"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --output-format csv -d $RAW/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-legs > $RAW/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
+  timeout 300 rocprofv3 --pmc $set --output-format csv -d $RAW/p$i -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline --no-extra-legs --no-batch16 > $RAW/p$i.log 2>&1 || echo "pass $i ($set) failed/timeout"
   timeout 300 rocprofv3 --pmc $set --output-format csv -d $RAW/c$i -o p -- python $GRAFT_REPO_ROOT/tools/run_batch_calls.py --batch $BATCH --calls $CALLS > $RAW/c$i.log 2>&1 || echo "calls pass $i ($set) failed/timeout"
 done
 python - $CALLS $BATCH <<'PY'

@@ -17,7 +17,7 @@ python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 for cfg in "default" "single" "b16"; do
   if [ $cfg = default ]; then ARGS=""; elif [ $cfg = b16 ]; then ARGS="--batch 16"; else ARGS="--batch 1 --streams 1"; fi
   RAW=/tmp/prof_$cfg; rm -rf $RAW
-  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o b -- python $R/bench.py $ARGS --steps 40 --warmup 10 --repeats 2 --no-cpu-baseline --no-extra-legs > $OUT/prof_$cfg.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW -o b -- python $R/bench.py $ARGS --steps 40 --warmup 10 --repeats 2 --no-cpu-baseline --no-extra-legs --no-batch16 > $OUT/prof_$cfg.log 2>&1
   cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_${cfg}_kernel_stats.csv
   [ $cfg = default ] && cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv  # the timed workload under the plain name as well
   python $R/tools/trace_by_grid.py $RAW/b_kernel_trace.csv > $OUT/${TAG}_bench_${cfg}_by_grid.txt
