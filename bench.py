@@ -521,9 +521,14 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
     a, b = synth.flow_pair(1920, 1080)
     prev, _ = synth.flow_pair(1920, 1080, seed=11)
 
-    def host_rate(nthreads, seconds=1.5):
-        """every calling thread renders output frames (own context, own host buffers) for `seconds`; >= 1 s per leg"""
+    def host_rate(nthreads, seconds=1.5, named=False):
+        """every calling thread renders output frames (own context, own host buffers) for `seconds`; >= 1 s per leg.
+        named: the threads render the output frames of ONE endless sequence in order (thread i takes frames i, i + threads, ...) and
+        pass a name with every frame (ofxcv_vectorgen_flows_host_keyed; an OFX host's kOfxImagePropUniqueIdentifier): per output frame
+        one frame the device has not seen, two it has."""
         cs = [ofxcv.Context(dev) for _ in range(nthreads)]
+        if named:
+            cs[0].host_cache_clear()
         outs = [np.zeros((1080, 1920, 4), np.float32) for _ in range(nthreads)]
         srcs = [(a.copy(), b.copy(), prev.copy()) for _ in range(nthreads)]  # a host hands every render thread its own frames
         for c, o, (x, y, z) in zip(cs, outs, srcs):
@@ -532,10 +537,17 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
         counts = [0] * nthreads
         stop = threading.Event()
 
+        ring = [a, b, prev]  # the buffers come round again under new names
+
         def work(i):
             c, o, (x, y, z) = cs[i], outs[i], srcs[i]
+            t = i
             while not stop.is_set():
-                c.vectorgen_flows_host(x, y, z, o, 1, 2, 4, 8)
+                if named:
+                    c.vectorgen_flows_host(ring[t % 3], ring[(t + 1) % 3], ring[(t - 1) % 3], o, 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
+                    t += nthreads
+                else:
+                    c.vectorgen_flows_host(x, y, z, o, 1, 2, 4, 8)
                 counts[i] += 1
         t0 = time.perf_counter()
         th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
@@ -550,7 +562,13 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
     out["end_to_end"] = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs, one "
                                      "batched Farneback call), three 1920x1080 f32 RGBA host frames in, one host RGBA frame out, PCIe inclusive; "
                                      "every calling thread renders for 1.5 s",
-                         "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_2": host_rate(2), "calling_threads_4": host_rate(4)}
+                         "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_2": host_rate(2), "calling_threads_4": host_rate(4),
+                         "playback_named_frames": {
+                             "workload": "the same output frames as consecutive frames of a sequence whose frames the caller names "
+                                         "(ofxcv_vectorgen_flows_host_keyed; an OFX host's kOfxImagePropUniqueIdentifier): the 8-bit gray image of a "
+                                         "named frame stays on the device, so each output frame uploads ONE f32 frame instead of three",
+                             "calling_threads_1": host_rate(1, named=True), "calling_threads_2": host_rate(2, named=True),
+                             "calling_threads_4": host_rate(4, named=True)}}
 
     # ---- Telea inpaint (configs[0] size and configs[1]) ----
     ctx = ofxcv.Context(dev)

@@ -155,6 +155,7 @@ OfxExport int OfxGetNumberOfPlugins(void);
 #define kOfxImagePropBounds "OfxImagePropBounds"
 #define kOfxImagePropRowBytes "OfxImagePropRowBytes"
 #define kOfxImagePropField "OfxImagePropField"
+#define kOfxImagePropUniqueIdentifier "OfxImagePropUniqueIdentifier"  /* string: changes whenever the image's pixels change */
 /* getFramesNeeded outArgs: "OfxImageClipPropFrameRange_" + clip name */
 #define kOfxImageClipPropFrameRangePrefix "OfxImageClipPropFrameRange_"
 

@@ -83,6 +83,7 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "host.split"              0|1|2  ofxcv_vectorgen_flows_host with two directions: 0 one batched Farneback call after the third upload; 1 two
  *                                    single-pair calls, the first while the third frame is still on the wire; 2 (default) 1 while this is the
  *                                    only host-image call in flight in the process, else 0 (several render threads keep the link busy anyway);
+ *   "host.cache_mb"           n      budget of the device's cache of named frames (ofxcv_vectorgen_flows_host_keyed), default 512, 0 = off;
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
  *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
  *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share
@@ -192,6 +193,29 @@ int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref
                                unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x,
                                double render_scale_y, int levels, int iterations, int poly_n,
                                double poly_sigma);
+
+/* The same with the frames NAMED.  Consecutive output frames of a sequence share two of their three source frames, and all
+ * the flow needs of a source frame is its 8-bit gray image (F0: 1/16 of the f32 RGBA pixels): a frame whose name -- together
+ * with the geometry -- was seen before on this device is neither uploaded nor converted again; its gray image is kept in a
+ * per-device cache shared by all contexts (option "host.cache_mb", default 512 MB = 240 frames at 1920x1080; least-recently
+ * used entries go first).  The name must identify the PIXELS: it has to change whenever they do -- OFX hosts provide exactly
+ * that as kOfxImagePropUniqueIdentifier, which is what the plugin passes; the library trusts it.  NULL or "" = unnamed (the
+ * frame takes the plain path; with all three unnamed the call is ofxcv_vectorgen_flows_host).  The reference has no
+ * counterpart: it re-marshals every frame of every render() (VectorGenerator.cpp:601-637, GenericOpenCVPlugin.cpp:58-165). */
+int ofxcv_vectorgen_flows_host_keyed(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes,
+                                     const float *h_fwd, ptrdiff_t fwd_row_bytes, const float *h_bwd,
+                                     ptrdiff_t bwd_row_bytes, int ncomp, int width, int height, float *h_dst,
+                                     ptrdiff_t dst_row_bytes, unsigned fwd_u_mask, unsigned fwd_v_mask,
+                                     unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x,
+                                     double render_scale_y, int levels, int iterations, int poly_n,
+                                     double poly_sigma, const char *ref_key, const char *fwd_key,
+                                     const char *bwd_key);
+/* named frames of this context's calls that were found on the device / that were uploaded, converted and kept */
+long ofxcv_host_cache_hits(const ofxcv_ctx *ctx);
+long ofxcv_host_cache_misses(const ofxcv_ctx *ctx);
+/* the cache of the context's device: bytes and frames held; ofxcv_host_cache_clear drops every entry no call is using */
+int ofxcv_host_cache_stats(ofxcv_ctx *ctx, size_t *bytes, int *frames);
+int ofxcv_host_cache_clear(ofxcv_ctx *ctx);
 
 /* How the host-image calls on this context moved their frames (context option "host.register"): copied straight from the
  * host's pageable images (1, default: ofxcv_host_direct_calls), with the host's buffers registered for the call and addressed

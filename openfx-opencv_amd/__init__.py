@@ -59,7 +59,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
     "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
-    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
+    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
     "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_fallback_count", "ofxcv_inpaint_render_host",
@@ -255,8 +255,9 @@ class Context:
         return dst
 
     def vectorgen_flows_host(self, ref, fwd, bwd, dst, fwd_u, fwd_v, bwd_u, bwd_v, rs_x=1.0, rs_y=1.0, levels=3, iterations=15,
-                             poly_n=5, poly_sigma=1.1):
-        """Both directions of a VectorGenerator output frame in one call; fwd or bwd may be None."""
+                             poly_n=5, poly_sigma=1.1, keys=None):
+        """Both directions of a VectorGenerator output frame in one call; fwd or bwd may be None.  keys = (ref, fwd, bwd) names
+        of the frames' pixels (str or None): ofxcv_vectorgen_flows_host_keyed."""
         import numpy as np
         h, w, nc = ref.shape
         for a in (ref, fwd, bwd):
@@ -264,11 +265,32 @@ class Context:
         assert dst.dtype == np.float32 and dst.shape == (h, w, 4) and dst.strides[1] == 16
         ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else None
         rb = lambda a: C.c_ssize_t(a.strides[0] if a is not None else 0)
-        self._check(lib().ofxcv_vectorgen_flows_host(
-            self._h, ptr(ref), rb(ref), ptr(fwd), rb(fwd), ptr(bwd), rb(bwd), C.c_int(nc), C.c_int(w), C.c_int(h), ptr(dst), rb(dst),
-            C.c_uint(fwd_u), C.c_uint(fwd_v), C.c_uint(bwd_u), C.c_uint(bwd_v), C.c_double(rs_x), C.c_double(rs_y),
-            C.c_int(levels), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma)))
+        args = (self._h, ptr(ref), rb(ref), ptr(fwd), rb(fwd), ptr(bwd), rb(bwd), C.c_int(nc), C.c_int(w), C.c_int(h), ptr(dst), rb(dst),
+                C.c_uint(fwd_u), C.c_uint(fwd_v), C.c_uint(bwd_u), C.c_uint(bwd_v), C.c_double(rs_x), C.c_double(rs_y),
+                C.c_int(levels), C.c_int(iterations), C.c_int(poly_n), C.c_double(poly_sigma))
+        if keys is None:
+            self._check(lib().ofxcv_vectorgen_flows_host(*args))
+        else:
+            kk = [C.c_char_p(k.encode()) if k else C.c_char_p(None) for k in keys]
+            self._check(lib().ofxcv_vectorgen_flows_host_keyed(*args, *kk))
         return dst
+
+    def host_cache_hits(self):
+        lib().ofxcv_host_cache_hits.restype = C.c_long
+        return int(lib().ofxcv_host_cache_hits(self._h))
+
+    def host_cache_misses(self):
+        lib().ofxcv_host_cache_misses.restype = C.c_long
+        return int(lib().ofxcv_host_cache_misses(self._h))
+
+    def host_cache_stats(self):
+        """(bytes, frames) held by the cache of this context's device"""
+        b, n = C.c_size_t(), C.c_int()
+        self._check(lib().ofxcv_host_cache_stats(self._h, C.byref(b), C.byref(n)))
+        return b.value, n.value
+
+    def host_cache_clear(self):
+        self._check(lib().ofxcv_host_cache_clear(self._h))
 
     # ---- inpaint ----
     def inpaint_mask(self, rgba, dilate_iters=1):

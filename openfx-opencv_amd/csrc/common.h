@@ -131,6 +131,8 @@ struct ofxcv_ctx {
                                    // third frame is still on the wire (1), as one batched call after the third upload (0), or 1 when this
                                    // is the only host-image call in flight in the process and 0 otherwise (2, default)
     long host_split_calls = 0;
+    int host_cache_mb = 512;       // option "host.cache_mb": budget of the device's cache of named frames' gray images (0 = off)
+    long host_cache_hits = 0, host_cache_misses = 0;  // named frames of this context's calls found on the device / uploaded and kept
     long host_direct_calls = 0;
     long host_zero_copy_calls = 0, host_staged_calls = 0;
 

@@ -241,6 +241,11 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->host_register = value < 0 ? 0 : (value > 2 ? 1 : value);
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "host.cache_mb")) {
+        if (value < 0 || value > (1 << 18)) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "host.cache_mb: 0 (off) .. 262144");
+        ctx->host_cache_mb = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "host.split")) {
         if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "host.split: 0, 1 or 2");
         ctx->host_split = value;
@@ -320,6 +325,7 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
     else if (!std::strcmp(name, "host.split")) *value = ctx->host_split;
+    else if (!std::strcmp(name, "host.cache_mb")) *value = ctx->host_cache_mb;
     else if (!std::strcmp(name, "host.split_calls")) *value = (int)ctx->host_split_calls;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;

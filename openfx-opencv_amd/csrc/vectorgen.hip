@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <functional>
+#include <string>
 #include <thread>
 
 #include "common.h"
@@ -120,6 +121,139 @@ int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+}  // namespace
+
+// ---- converted frames kept in HBM across calls ----
+// Consecutive output frames of a sequence share two of their three source frames (frame t needs t-1, t, t+1), and what the
+// flow needs of a source frame is its 8-bit gray image: 1/16 of the f32 RGBA pixels the host hands over.  A caller that can
+// NAME the pixels of a frame (OFX hosts do: kOfxImagePropUniqueIdentifier changes whenever an image's pixels change) passes
+// that name with the frame (ofxcv_vectorgen_flows_host_keyed); the gray image of a named frame stays on the device -- one
+// cache per device, shared by the contexts of all render threads, `host.cache_mb` of the 288 GB (512 MB = 240 frames at
+// 1920x1080) -- and a frame that is found there is neither uploaded nor converted again: per output frame of a sequence one
+// upload instead of three.  Entries are pinned while a call uses them and evicted least-recently-used; an entry is
+// published to other threads only after the work that fills it has been enqueued and its event recorded (they wait for the
+// event on their own stream).  The cache trusts the names: a caller that reuses a name for different pixels gets the old
+// frame -- exactly the contract of the OFX property.
+namespace {
+struct GrayEntry {
+    std::string key;
+    int w = 0, h = 0, ncomp = 0;
+    size_t bytes = 0;
+    uint8_t *ptr = nullptr;
+    hipEvent_t ready = nullptr;
+    int pins = 0;
+    bool recorded = false, failed = false;
+    unsigned long stamp = 0;
+};
+class GrayCache {
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<GrayEntry *> entries_;
+    size_t bytes_ = 0;
+    unsigned long clock_ = 0;
+
+    void drop(size_t i, ofxcv_ctx *ctx) {  // mu_ held; entry unpinned: nothing of it is in flight (its users synchronised before unpinning)
+        GrayEntry *e = entries_[i];
+        {
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            if (e->ptr) (void)hipFree(e->ptr);
+            if (e->ready) (void)hipEventDestroy(e->ready);
+            (void)hipGetLastError();
+        }
+        bytes_ -= e->bytes;
+        delete e;
+        entries_.erase(entries_.begin() + (ptrdiff_t)i);
+    }
+
+public:
+    static GrayCache &of(int device) {
+        static GrayCache *c = new GrayCache[64];  // intentionally leaked (no static destructor while a host unloads the plugin)
+        return c[device & 63];
+    }
+    // The entry of (key, geometry), pinned; *fill = the caller has to produce it (and call published()).  nullptr: not cacheable
+    // right now (budget used up by pinned entries, allocation failure, a producer that failed) -- the caller takes the plain path.
+    GrayEntry *acquire(ofxcv_ctx *ctx, const char *key, int w, int h, int ncomp, size_t bytes, size_t budget, bool *fill, bool *pending) {
+        *fill = *pending = false;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (GrayEntry *e : entries_)
+            if (e->w == w && e->h == h && e->ncomp == ncomp && !e->failed && e->key == key) {
+                // Another thread may still be enqueueing the work that fills it (*pending).  Not waited for here: a caller takes all its
+                // frames first, and two callers that each fill what the other waits for would wait for ever -- wait_published() is
+                // called after the caller has published its own entries.
+                *pending = !e->recorded;
+                e->pins++;
+                e->stamp = ++clock_;
+                return e;
+            }
+        // failed entries nobody uses any more, then least-recently-used ones, make room
+        for (size_t i = entries_.size(); i-- > 0;)
+            if (entries_[i]->failed && entries_[i]->pins == 0) drop(i, ctx);
+        GrayEntry *e = nullptr;
+        while (bytes_ + bytes > budget) {
+            size_t lru = entries_.size();
+            for (size_t i = 0; i < entries_.size(); i++)
+                if (entries_[i]->pins == 0 && (lru == entries_.size() || entries_[i]->stamp < entries_[lru]->stamp)) lru = i;
+            if (lru == entries_.size()) return nullptr;
+            if (entries_[lru]->bytes == bytes) {
+                // the usual case (a sequence has one frame size): the evicted entry's buffer and event are taken over as they are --
+                // no hipFree (it waits for the whole device) and no hipMalloc on the path of a render call
+                e = entries_[lru];
+                entries_.erase(entries_.begin() + (ptrdiff_t)lru);
+                bytes_ -= bytes;
+                break;
+            }
+            drop(lru, ctx);
+        }
+        if (!e) {
+            e = new GrayEntry();
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            if (hipMalloc((void **)&e->ptr, bytes) != hipSuccess || hipEventCreateWithFlags(&e->ready, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                if (e->ptr) (void)hipFree(e->ptr);
+                delete e;
+                return nullptr;
+            }
+        }
+        e->recorded = e->failed = false;
+        e->key = key;
+        e->w = w; e->h = h; e->ncomp = ncomp;
+        e->bytes = bytes;
+        e->pins = 1;
+        e->stamp = ++clock_;
+        bytes_ += bytes;
+        entries_.push_back(e);
+        *fill = true;
+        return e;
+    }
+    void published(GrayEntry *e, bool ok) {  // the producer has recorded e->ready behind the work that fills the entry (or given up)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            e->recorded = ok;
+            e->failed = !ok;
+        }
+        cv_.notify_all();
+    }
+    bool wait_published(GrayEntry *e) {  // false: its producer gave up
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return e->recorded || e->failed; });
+        return e->recorded;
+    }
+    void release(GrayEntry *e) {
+        std::lock_guard<std::mutex> lk(mu_);
+        e->pins--;
+    }
+    void stats(size_t &bytes, int &n) {
+        std::lock_guard<std::mutex> lk(mu_);
+        bytes = bytes_;
+        n = (int)entries_.size();
+    }
+    // every unpinned entry (tests; a host that wants the memory back)
+    void clear(ofxcv_ctx *ctx) {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (size_t i = entries_.size(); i-- > 0;)
+            if (entries_[i]->pins == 0) drop(i, ctx);
+    }
+};
 }  // namespace
 
 // ---- registered host buffers ----
@@ -282,7 +416,7 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
 static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, int n_other, const float *const h_other[2],
                       const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
                       const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
-                      int levels, int iterations, int poly_n, double poly_sigma) {
+                      int levels, int iterations, int poly_n, double poly_sigma, const char *const keys[3] = nullptr) {
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
@@ -331,6 +465,27 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         h_flow[k] = direct_down ? nullptr : (float *)(hp + pin_frames + k * flow_bytes);
     }
     float *d_rgba = direct_down ? (float *)(dp + nf * (frame + gray) + n_other * flow_bytes) : nullptr;
+    // Frames the caller named (keys): their gray images live in the device's cache.  Declared before `drain`: the entries are
+    // unpinned only after this call's streams have drained.
+    struct Pins {
+        GrayCache *cache;
+        GrayEntry *e[3] = {nullptr, nullptr, nullptr};
+        bool fill[3] = {false, false, false}, done[3] = {false, false, false}, pending[3] = {false, false, false};
+        ~Pins() {
+            for (int f = 0; f < 3; f++)
+                if (e[f]) {
+                    if (fill[f] && !done[f]) cache->published(e[f], false);  // a way out before the entry was filled: nobody may use it
+                    cache->release(e[f]);
+                }
+        }
+    } pins{&GrayCache::of(ctx->device)};
+    if (keys && ctx->host_cache_mb > 0)
+        for (int f = 0; f < nf; f++)
+            if (keys[f] && keys[f][0]) {
+                bool dup = false;  // the same frame twice in one call (a still): the second one takes the plain path
+                for (int g = 0; g < f; g++) dup = dup || (pins.e[g] && pins.e[g]->key == keys[f]);
+                if (!dup) pins.e[f] = pins.cache->acquire(ctx, keys[f], width, height, ncomp, gray, (size_t)ctx->host_cache_mb << 20, &pins.fill[f], &pins.pending[f]);
+            }
     // whatever happens below, nothing of this call may still be reading the host's frames or writing its image on return
     struct Drain {
         ofxcv_ctx *c;
@@ -353,10 +508,45 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         InFlight() : mine(n().fetch_add(1) + 1) {}
         ~InFlight() { n().fetch_sub(1); }
     } in_flight;
-    const bool split = n_other == 2 && (ctx->host_split == 1 || (ctx->host_split == 2 && in_flight.mine == 1));
+    bool avail[3] = {false, false, false}, pair_done[2] = {false, false};
+    int to_upload = 0;
+    for (int f = 0; f < nf; f++) to_upload += !(pins.e[f] && !pins.fill[f]);
+    // (with every frame already on the device there is no upload to hide a pair behind: one batched call)
+    const bool split = n_other == 2 && to_upload > 0 && (ctx->host_split == 1 || (ctx->host_split == 2 && in_flight.mine == 1));
+    auto enqueue_ready_pairs = [&]() -> int {  // split form: direction k as soon as the reference frame and frame k+1 are there
+        for (int k = 0; split && k < n_other; k++)
+            if (!pair_done[k] && avail[0] && avail[k + 1]) {
+                const uint8_t *prevs[1] = {d_gray[0]}, *nexts[1] = {d_gray[k + 1]};
+                int r = ofxcv_calc_optical_flow_farneback_batch(ctx, 1, prevs, gsteps, nexts, gsteps, &d_flow[k], fsteps, width, height, 0.5, levels, 3,
+                                                                iterations, poly_n, poly_sigma, 0, ctx->compute);
+                if (r) return r;
+                pair_done[k] = true;
+            }
+        return OFXCV_OK;
+    };
+    // A frame that is on the device already: nothing to upload, nothing to convert -- its gray image (1 B/px) is copied into this
+    // call's own slot, so that the Farneback call sees the same pointers as ever (its launch graph is cached by pointer) and the
+    // entry is only read here.  The event belongs to another context's stream: waited for under the runtime lock, like
+    // everything that must not run beside another thread's stream capture on ROCm 7.2 (outside it the wait failed with
+    // "dependency created on uncaptured work in another stream" while another thread was capturing).
+    auto take_cached = [&](int f) -> int {
+        {
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, pins.e[f]->ready, 0));
+        }
+        OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_gray[f], pins.e[f]->ptr, gray, hipMemcpyDeviceToDevice, ctx->compute));
+        avail[f] = true;
+        ctx->host_cache_hits++;
+        return OFXCV_OK;
+    };
+    // Cached frames first: whatever only needs them is enqueued BEFORE the first copy call (a copy from pageable memory returns
+    // when the runtime has staged the frame).  Frames another thread is filling right now come last.
+    for (int f = 0; f < nf; f++)
+        if (pins.e[f] && !pins.fill[f] && !pins.pending[f] && (rc = take_cached(f))) return rc;
+    if ((rc = enqueue_ready_pairs())) return rc;
     // uploads on the copy stream; the compute stream converts frame f as soon as it has arrived
     const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ring: ~4 MiB per DMA
-    for (int f = 0; f < nf; f++) {
+    auto upload = [&](int f) -> int {
         if (direct_up) {
             if ((size_t)src_rb[f] == row)  // contiguous rows: one linear copy
                 OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_frame[f], src[f], row * height, hipMemcpyHostToDevice, ctx->copy));
@@ -374,19 +564,38 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
                                                     hipMemcpyHostToDevice, ctx->copy));
             }
         }
-        // (a copy from pageable memory returns when the runtime has staged the frame: the kernels of the frames before it are
-        // enqueued before the next upload starts, and run during it)
+        // (the kernels of the frames before it are enqueued before the next upload starts, and run during it)
         OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_h2d[f], ctx->copy));
         OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, ctx->ev_h2d[f], 0));
         rc = ofxcv_to_byte_grayscale(ctx, (const float *)d_frame[f], (ptrdiff_t)row, ncomp, width, height, d_gray[f], (ptrdiff_t)gray_pitch, ctx->compute);
         if (rc) return rc;
-        if (split && f >= 1) {  // frames 0 and f are there: direction f-1
-            const uint8_t *prevs[1] = {d_gray[0]}, *nexts[1] = {d_gray[f]};
-            rc = ofxcv_calc_optical_flow_farneback_batch(ctx, 1, prevs, gsteps, nexts, gsteps, &d_flow[f - 1], fsteps, width, height, 0.5, levels, 3,
-                                                         iterations, poly_n, poly_sigma, 0, ctx->compute);
-            if (rc) return rc;
+        if (pins.e[f]) {  // a named frame: its gray image goes into the cache entry as well
+            OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(pins.e[f]->ptr, d_gray[f], gray, hipMemcpyDeviceToDevice, ctx->compute));
+            {
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+                OFXCV_HIP_CHECK(ctx, hipEventRecord(pins.e[f]->ready, ctx->compute));
+            }
+            pins.cache->published(pins.e[f], true);
+            pins.done[f] = true;
+            ctx->host_cache_misses++;
         }
-    }
+        avail[f] = true;
+        return enqueue_ready_pairs();
+    };
+    for (int f = 0; f < nf; f++)
+        if (!avail[f] && !pins.pending[f] && (rc = upload(f))) return rc;
+    // Frames some other thread was filling when this call looked them up.  Its own entries are published by now, so waiting is
+    // safe; should the other thread have given up, the frame is uploaded after all (unnamed).
+    for (int f = 0; f < nf; f++)
+        if (!avail[f]) {
+            if (pins.cache->wait_published(pins.e[f])) {
+                if ((rc = take_cached(f)) || (rc = enqueue_ready_pairs())) return rc;
+            } else {
+                pins.cache->release(pins.e[f]);
+                pins.e[f] = nullptr;
+                if ((rc = upload(f))) return rc;
+            }
+        }
     if (direct_up) ctx->host_direct_calls++;
     else ctx->host_staged_calls++;
     if (split) ctx->host_split_calls++;
@@ -491,4 +700,43 @@ extern "C" int ofxcv_vectorgen_flows_host(ofxcv_ctx *ctx, const float *h_ref, pt
     if (h_bwd) { others[n] = h_bwd; rbs[n] = bwd_row_bytes; mu[n] = bwd_u_mask; mv[n++] = bwd_v_mask; }
     return flows_host(ctx, h_ref, ref_row_bytes, n, others, rbs, ncomp, width, height, h_dst, dst_row_bytes, mu, mv, render_scale_x,
                       render_scale_y, levels, iterations, poly_n, poly_sigma);
+}
+
+extern "C" int ofxcv_vectorgen_flows_host_keyed(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, const float *h_fwd,
+                                                ptrdiff_t fwd_row_bytes, const float *h_bwd, ptrdiff_t bwd_row_bytes, int ncomp, int width,
+                                                int height, float *h_dst, ptrdiff_t dst_row_bytes, unsigned fwd_u_mask, unsigned fwd_v_mask,
+                                                unsigned bwd_u_mask, unsigned bwd_v_mask, double render_scale_x, double render_scale_y, int levels,
+                                                int iterations, int poly_n, double poly_sigma, const char *ref_key, const char *fwd_key,
+                                                const char *bwd_key) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (!h_ref || (!h_fwd && !h_bwd) || !h_dst || width <= 0 || height <= 0 || render_scale_x == 0 || render_scale_y == 0)
+        return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "vectorgen_flows_host_keyed: bad argument");
+    if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "vectorgen_flows_host_keyed: RGB or RGBA sources only");
+    const float *others[2];
+    ptrdiff_t rbs[2];
+    unsigned mu[2], mv[2];
+    const char *keys[3] = {ref_key, nullptr, nullptr};
+    int n = 0;
+    if (h_fwd) { others[n] = h_fwd; rbs[n] = fwd_row_bytes; mu[n] = fwd_u_mask; mv[n] = fwd_v_mask; keys[++n] = fwd_key; }
+    if (h_bwd) { others[n] = h_bwd; rbs[n] = bwd_row_bytes; mu[n] = bwd_u_mask; mv[n] = bwd_v_mask; keys[++n] = bwd_key; }
+    return flows_host(ctx, h_ref, ref_row_bytes, n, others, rbs, ncomp, width, height, h_dst, dst_row_bytes, mu, mv, render_scale_x,
+                      render_scale_y, levels, iterations, poly_n, poly_sigma, keys);
+}
+
+extern "C" long ofxcv_host_cache_hits(const ofxcv_ctx *ctx) { return ctx ? ctx->host_cache_hits : 0; }
+extern "C" long ofxcv_host_cache_misses(const ofxcv_ctx *ctx) { return ctx ? ctx->host_cache_misses : 0; }
+extern "C" int ofxcv_host_cache_stats(ofxcv_ctx *ctx, size_t *bytes, int *frames) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    size_t b = 0;
+    int n = 0;
+    GrayCache::of(ctx->device).stats(b, n);
+    if (bytes) *bytes = b;
+    if (frames) *frames = n;
+    return OFXCV_OK;
+}
+extern "C" int ofxcv_host_cache_clear(ofxcv_ctx *ctx) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GrayCache::of(ctx->device).clear(ctx);
+    return OFXCV_OK;
 }

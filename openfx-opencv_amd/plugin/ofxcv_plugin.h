@@ -132,6 +132,7 @@ struct Image {
     std::string depth, components;
     double scale_x = 1, scale_y = 1;
     std::string field;
+    std::string unique_id;  // kOfxImagePropUniqueIdentifier where the host provides it ("" otherwise): names the pixels
     int width() const { return bounds.x2 - bounds.x1; }
     int height() const { return bounds.y2 - bounds.y1; }
 };
@@ -155,6 +156,7 @@ struct ImageGuard {
             img.scale_y = sc[1];
         }
         if (s.prop->propGetString(img.handle, kOfxImagePropField, 0, &str) == kOfxStatOK && str) img.field = str;
+        if (s.prop->propGetString(img.handle, kOfxImagePropUniqueIdentifier, 0, &str) == kOfxStatOK && str) img.unique_id = str;
     }
     ~ImageGuard() {
         if (img.handle) s.effect->clipReleaseImage(img.handle);

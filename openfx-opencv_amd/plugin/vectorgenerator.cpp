@@ -308,9 +308,14 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
             }
             ofxcv_ctx *ctx = ThreadContext::get();
             float *d0 = (float *)((char *)o.data + (ptrdiff_t)(r.bounds.y1 - o.bounds.y1) * o.row_bytes) + (size_t)(r.bounds.x1 - o.bounds.x1) * 4;
-            check_hip(ctx, ofxcv_vectorgen_flows_host(ctx, (const float *)r.data, r.row_bytes, (const float *)next.img.data, next.img.row_bytes,
-                                                      (const float *)prev.img.data, prev.img.row_bytes, ncomp, r.width(), r.height(), d0,
-                                                      o.row_bytes, fu, fv, bu, bv, rs[0], rs[1], levels, iterations, poly_n, poly_sigma));
+            // The frames travel with the names the host gives their pixels (kOfxImagePropUniqueIdentifier; "" = none): rendering
+            // frame t+1 after frame t finds two of its three source frames on the device already.  A name covers the whole image:
+            // it is only passed where the image IS the frame the library sees (same bounds as the reference, which `same` checked
+            // by size, and the data pointer at its origin).
+            check_hip(ctx, ofxcv_vectorgen_flows_host_keyed(ctx, (const float *)r.data, r.row_bytes, (const float *)next.img.data, next.img.row_bytes,
+                                                            (const float *)prev.img.data, prev.img.row_bytes, ncomp, r.width(), r.height(), d0,
+                                                            o.row_bytes, fu, fv, bu, bv, rs[0], rs[1], levels, iterations, poly_n, poly_sigma,
+                                                            r.unique_id.c_str(), next.img.unique_id.c_str(), prev.img.unique_id.c_str()));
             return kOfxStatOK;
         }
     }

@@ -460,6 +460,16 @@ int mh_set_image(void *inst, const char *clip, double time, void *data, int x1, 
     c->images[time] = std::move(im);
     return 0;
 }
+// the name of the pixels of the image a clip returns at `time` (kOfxImagePropUniqueIdentifier; hosts change it with the pixels)
+int mh_set_image_id(void *inst, const char *clip, double time, const char *id) {
+    Clip *c = ((Effect *)inst)->find_clip(clip);
+    if (!c) return -1;
+    std::lock_guard<std::mutex> lk(g_lock);
+    auto it = c->images.find(time);
+    if (it == c->images.end()) return -1;
+    propSetString((OfxPropertySetHandle)it->second.get(), kOfxImagePropUniqueIdentifier, 0, id);
+    return 0;
+}
 int mh_render(void *h, void *inst, double time, int x1, int y1, int x2, int y2, double rsx, double rsy) {
     PropSet in;
     OfxPropertySetHandle p = (OfxPropertySetHandle)&in;

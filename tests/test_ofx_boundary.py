@@ -351,3 +351,43 @@ def test_vectorgenerator_render_through_ofx(host, oracle):
     host.mh_set_param_double(inst, b"method", C.c_double(2))
     assert pl.render(inst, 5.0, w, h, rs=(0.5, 0.5)) == STAT_FAILED
     pl.destroy(inst)
+
+
+@pytest.mark.gpu
+def test_vectorgenerator_sequence_with_image_identifiers(host):
+    """A host that names its images' pixels (kOfxImagePropUniqueIdentifier): rendering the frames of a sequence one after the
+    other through the OFX boundary gives the frames a host without identifiers gets.  That the names reach the library (whose
+    cache lives inside the bundle) shows in the contract itself: pixels that change under an UNCHANGED identifier are not
+    looked at again -- the host must rename them, as the OFX property says -- and under a new identifier they are."""
+    from openfx_opencv_amd import synth
+    w, h = 288, 160
+    seq = [synth.flow_pair(w, h, seed=20 + i)[0].copy() for i in range(5)]
+    pl = Plugin(host, "VectorGenerator")
+    outs = {}
+
+    def render(inst, t, ids):
+        out = np.full((h, w, 4), -9.0, np.float32)
+        for u in (t - 1, t, t + 1):
+            pl.set_image(inst, "Source", float(u), seq[u], "OfxBitDepthFloat")
+            if ids:
+                assert host.mh_set_image_id(inst, b"Source", C.c_double(float(u)), ids[u].encode()) == 0
+        pl.set_image(inst, "Output", float(t), out, "OfxBitDepthFloat")
+        assert pl.render(inst, float(t), w, h) == STAT_OK
+        return out
+
+    ids = ["ofxcv-test-seq-%d-v1" % u for u in range(5)]
+    for named in (False, True):
+        inst = pl.instance()
+        for t in (1, 2, 3):
+            outs[(named, t)] = render(inst, t, ids if named else None)
+        pl.destroy(inst)
+    for t in (1, 2, 3):
+        assert np.array_equal(outs[(True, t)], outs[(False, t)]), t
+    inst = pl.instance()
+    seq[3][...] = synth.flow_pair(w, h, seed=91)[0]                 # new pixels in frame 3 ...
+    stale = render(inst, 2, ids)                                    # ... under its old name: the frame on the device is used
+    assert np.array_equal(stale, outs[(True, 2)])
+    ids[3] = "ofxcv-test-seq-3-v2"                                  # renamed, as a host does when pixels change
+    fresh = render(inst, 2, ids)
+    assert np.array_equal(fresh, render(inst, 2, None)) and not np.array_equal(fresh, stale)
+    pl.destroy(inst)

@@ -276,3 +276,111 @@ def test_host_path_split_form_gives_the_same_frame(ofxcv):
             c.close()
     for key, o in outs.items():
         assert np.array_equal(o, outs[(1, 0, key[2])]), key
+
+
+def test_named_frames_stay_on_the_device(ofxcv):
+    """ofxcv_vectorgen_flows_host_keyed: a frame whose name was seen before (same geometry, same device) is neither uploaded nor
+    converted again -- rendering a sequence in order uploads ONE frame per output frame instead of three -- and the output is
+    the unnamed call's, pixel for pixel.  The cache is per device and shared by contexts; a new name for new pixels gives the
+    new frame; the budget evicts least-recently-used frames; unnamed / partly named calls work as before."""
+    from openfx_opencv_amd import synth
+    w, h = 256, 144
+    seq = [synth.flow_pair(w, h, seed=40 + i)[0] for i in range(6)]
+    plain, a, b = ofxcv.Context(0), ofxcv.Context(0), ofxcv.Context(0)
+    a.host_cache_clear()
+    want = {}
+    for t in range(1, 5):
+        o = np.zeros((h, w, 4), np.float32)
+        plain.vectorgen_flows_host(seq[t], seq[t + 1], seq[t - 1], o, 1, 2, 4, 8)
+        want[t] = o
+    name = lambda t, gen=0: "clipA:%d:%d" % (t, gen)
+    for c, frames in ((a, (1, 2)), (b, (3, 4))):          # two contexts (two render threads) share the device's cache
+        for t in frames:
+            o = np.full((h, w, 4), 7.0, np.float32)
+            c.vectorgen_flows_host(seq[t], seq[t + 1], seq[t - 1], o, 1, 2, 4, 8, keys=(name(t), name(t + 1), name(t - 1)))
+            assert np.array_equal(o, want[t]), t
+    assert (a.host_cache_misses(), a.host_cache_hits()) == (4, 2)     # t=1: three uploads; t=2: only frame 3
+    assert (b.host_cache_misses(), b.host_cache_hits()) == (2, 4)     # t=3: frame 4, t=4: frame 5 -- the rest came from `a`'s calls
+    nbytes, nframes = a.host_cache_stats()
+    assert nframes == 6 and nbytes == 6 * 256 * h                     # gray rows padded to 256 bytes
+    # all three on the device: one batched call, no upload at all
+    o = np.zeros((h, w, 4), np.float32)
+    a.vectorgen_flows_host(seq[2], seq[3], seq[1], o, 1, 2, 4, 8, keys=(name(2), name(3), name(1)))
+    assert np.array_equal(o, want[2]) and a.host_cache_hits() == 5
+    # the pixels of frame 3 change and so does its name: the new frame is used (the old entry just ages)
+    new3 = synth.flow_pair(w, h, seed=99)[0]
+    ref = np.zeros((h, w, 4), np.float32)
+    plain.vectorgen_flows_host(seq[2], new3, seq[1], ref, 1, 2, 4, 8)
+    a.vectorgen_flows_host(seq[2], new3, seq[1], o, 1, 2, 4, 8, keys=(name(2), name(3, 1), name(1)))
+    assert np.array_equal(o, ref) and not np.array_equal(o, want[2])
+    # partly named, one direction, the same frame twice in a call
+    a.vectorgen_flows_host(seq[2], seq[3], seq[1], o, 1, 2, 4, 8, keys=(None, name(3), ""))
+    assert np.array_equal(o, want[2])
+    one, one_ref = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    plain.vectorgen_flows_host(seq[2], seq[3], None, one_ref, 1, 2, 0, 0)
+    a.vectorgen_flows_host(seq[2], seq[3], None, one, 1, 2, 0, 0, keys=(name(2), name(3), None))
+    assert np.array_equal(one, one_ref)
+    plain.vectorgen_flows_host(seq[2], seq[2], seq[2], ref, 1, 2, 4, 8)
+    a.vectorgen_flows_host(seq[2], seq[2], seq[2], o, 1, 2, 4, 8, keys=(name(2), name(2), name(2)))
+    assert np.array_equal(o, ref)
+    # a budget of three frames (rounded down to whole MB: use frames of >= 1/3 MB): least-recently-used entries go
+    a.host_cache_clear()
+    assert a.host_cache_stats() == (0, 0)
+    W2, H2 = 1024, 400                                                # 400 KB of gray per frame
+    big = [synth.flow_pair(W2, H2, seed=60 + i)[0] for i in range(5)]
+    small = ofxcv.Context(0)
+    small.set_option("host.cache_mb", 1)                              # two frames fit, the third of a call does not
+    ref = np.zeros((H2, W2, 4), np.float32)
+    o = np.zeros((H2, W2, 4), np.float32)
+    for t in (1, 2, 3):
+        plain.vectorgen_flows_host(big[t], big[t + 1], big[t - 1], ref, 1, 2, 4, 8)
+        small.vectorgen_flows_host(big[t], big[t + 1], big[t - 1], o, 1, 2, 4, 8, keys=("b%d" % t, "b%d" % (t + 1), "b%d" % (t - 1)))
+        assert np.array_equal(o, ref), t
+        assert small.host_cache_stats()[0] <= 1 << 20
+    off = ofxcv.Context(0)
+    off.set_option("host.cache_mb", 0)
+    off.vectorgen_flows_host(big[1], big[2], big[0], o, 1, 2, 4, 8, keys=("b1", "b2", "b0"))
+    assert off.host_cache_hits() == 0 and off.host_cache_misses() == 0
+    for c in (plain, a, b, small, off):
+        c.close()
+
+
+@pytest.mark.timeout(300)
+def test_named_frames_from_several_threads(ofxcv):
+    """Four render threads, one context each, render neighbouring output frames of one sequence at the same time, again and
+    again: they find, fill and wait for each other's frames in the device's cache; every output frame is the unnamed call's."""
+    import threading
+    from openfx_opencv_amd import synth
+    w, h = 320, 200
+    n = 8
+    seq = [synth.flow_pair(w, h, seed=70 + i)[0] for i in range(n + 2)]
+    plain = ofxcv.Context(0)
+    plain.host_cache_clear()
+    want = []
+    for t in range(1, n + 1):
+        o = np.zeros((h, w, 4), np.float32)
+        plain.vectorgen_flows_host(seq[t], seq[t + 1], seq[t - 1], o, 1, 2, 4, 8)
+        want.append(o)
+    errors, counts = [], []
+
+    def work(k):
+        try:
+            c = ofxcv.Context(0)
+            c.set_option("host.cache_mb", 1)       # small enough that entries are evicted while other threads run
+            for rep in range(3):
+                for t in range(1 + k, n + 1, 4):
+                    o = np.full((h, w, 4), -1.0, np.float32)
+                    c.vectorgen_flows_host(seq[t], seq[t + 1], seq[t - 1], o, 1, 2, 4, 8, keys=("s%d" % t, "s%d" % (t + 1), "s%d" % (t - 1)))
+                    if not np.array_equal(o, want[t - 1]):
+                        errors.append((k, rep, t))
+            counts.append((c.host_cache_hits(), c.host_cache_misses()))
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    print("hits / misses per thread:", counts)
+    plain.close()

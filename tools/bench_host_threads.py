@@ -12,6 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--devices", type=int, default=1)
 ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--threads", default="1,2,4,8")
+ap.add_argument("--sequence", type=int, default=0, help="N > 0: the threads render the output frames of ONE sequence of N distinct frames in order "
+                "(thread i takes frames i, i + threads, ...), every frame named (ofxcv_vectorgen_flows_host_keyed): what an OFX host that provides "
+                "kOfxImagePropUniqueIdentifier gets during playback")
 args = ap.parse_args()
 W, H = 1920, 1080
 ref, nxt = synth.flow_pair(W, H, seed=11)
@@ -29,10 +32,23 @@ for nt in [int(v) for v in args.threads.split(",")]:
             c.vectorgen_flows_host(f[0], f[1], f[2], f[3], 1, 2, 4, 8)
     counts = [0] * nt
     stop = threading.Event()
+    if args.sequence:
+        seq = [synth.flow_pair(W, H, seed=200 + k)[0] for k in range(min(args.sequence, 8))]
+        seq = [seq[k % len(seq)].copy() for k in range(args.sequence)]     # N buffers (distinct names; the pixels repeat: generation is slow)
+        ctxs[0].host_cache_clear()
     def work(i):
         c, f = ctxs[i], frames[i]
+        t = i
         while not stop.is_set():
-            c.vectorgen_flows_host(f[0], f[1], f[2], f[3], 1, 2, 4, 8)
+            if args.sequence:
+                n = args.sequence
+                a, b, p = t % n, (t + 1) % n, (t - 1) % n
+                # names by position in an endless sequence (the N buffers come round again under new names): every output frame
+                # has ONE frame the device has not seen, as in playback
+                c.vectorgen_flows_host(seq[a], seq[b], seq[p], f[3], 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
+                t += nt
+            else:
+                c.vectorgen_flows_host(f[0], f[1], f[2], f[3], 1, 2, 4, 8)
             counts[i] += 1
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
@@ -43,6 +59,7 @@ for nt in [int(v) for v in args.threads.split(",")]:
     el = time.perf_counter() - t0
     n = sum(counts)
     print("%d devices, %d calling threads: %.1f output frames/s = %.0f pairs/s (%.2f ms per call per thread; zero-copy calls %s)" %
-          (ndev, nt, n / el, 2 * n / el, el * nt / max(1, n) * 1e3, [c.host_zero_copy_calls() for c in ctxs]), flush=True)
+          (ndev, nt, n / el, 2 * n / el, el * nt / max(1, n) * 1e3, [c.host_zero_copy_calls() for c in ctxs]) +
+          ("  named frames found on the device / uploaded: %d / %d" % (sum(c.host_cache_hits() for c in ctxs), sum(c.host_cache_misses() for c in ctxs)) if args.sequence else ""), flush=True)
     for c in ctxs:
         c.close()
