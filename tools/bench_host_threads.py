@@ -12,11 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--devices", type=int, default=1)
 ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--threads", default="1,2,4,8")
+ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--sequence", type=int, default=0, help="N > 0: the threads render the output frames of ONE sequence of N distinct frames in order "
                 "(thread i takes frames i, i + threads, ...), every frame named (ofxcv_vectorgen_flows_host_keyed): what an OFX host that provides "
                 "kOfxImagePropUniqueIdentifier gets during playback")
 args = ap.parse_args()
-W, H = 1920, 1080
+W, H = (int(v) for v in args.size.split("x"))
 ref, nxt = synth.flow_pair(W, H, seed=11)
 prev, _ = synth.flow_pair(W, H, seed=12)
 ndev = max(1, min(args.devices, torch.cuda.device_count()))
