@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate-f7", action="store_true", help="A/B: flow -> RGBA as its own launch per pair (ofxcv_flow_to_rgba) instead of "
                                                                "inside the Farneback call (ofxcv_calc_optical_flow_farneback_batch_rgba)")
+    ap.add_argument("--separate-lut", action="store_true", help="A/B: the gray LUT as one launch per frame (ofxcv_to_byte_grayscale) instead of one per call "
+                                                                "(ofxcv_to_byte_grayscale_batch)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
     ap.add_argument("--no-batch16", action="store_true", help="skip the batches-of-16 leg (counter passes: its launches have the grids of other levels' launches of 8)")
     ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
@@ -284,9 +286,12 @@ def main():
         # Farneback call; frame pairs never exchange data, so they shard across batches and streams exactly as across GPUs
         for c, t in zip(cs, bufs):
             with torch.cuda.stream(c.stream):
-                for a, b, ga, gb in zip(t["a"], t["b"], t["ga"], t["gb"]):
-                    c.to_byte_grayscale(a, ga)
-                    c.to_byte_grayscale(b, gb)
+                if args.separate_lut:
+                    for a, b, ga, gb in zip(t["a"], t["b"], t["ga"], t["gb"]):
+                        c.to_byte_grayscale(a, ga)
+                        c.to_byte_grayscale(b, gb)
+                else:  # F0 for the 2n frames of the call in one launch
+                    c.to_byte_grayscale_batch(t["a"] + t["b"], t["ga"] + t["gb"])
                 if args.separate_f7:
                     c.calc_optical_flow_farneback_batch(t["ga"], t["gb"], t["flow"], PYR_SCALE, LEVELS, WINSIZE, ITERS, POLY_N, POLY_SIGMA, 0)
                     for fl, o in zip(t["flow"], t["out"]):
@@ -431,6 +436,9 @@ def main():
                    "box_window": "OpenCV order (library default): running f64 column sums of f32-rounded row differences, strip-parallel",
                    "call_form": "batched: one ofxcv_calc_optical_flow_farneback_batch_rgba call of %d different pairs at a time per stream (BASELINE configs[4]'s 8 pairs per GPU); "
                                 "rounds 1 and 2 quoted three single-pair calls in flight: value_three_single_pair_calls_in_flight" % B,
+                   "gray_lut": ("one launch per frame (ofxcv_to_byte_grayscale; --separate-lut)" if args.separate_lut else
+                                "the 2n frames of a call in one launch (ofxcv_to_byte_grayscale_batch; one launch per frame, as in rounds 1-3 and the first "
+                                "half of round 4: --separate-lut, 1.2 % less)"),
                    "parallelism": "independent frame pairs per GPU, no collective"},
         "value_stats": dict(stats(rates), note="each repeat = one timed region of `steps` steps bracketed by barrier + synchronize; value = median"),
         "value_opencv_order": value,  # the timed mode IS the OpenCV-order mode (library default); kept as an explicit key

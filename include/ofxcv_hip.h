@@ -114,6 +114,13 @@ int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int res
 int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_row_bytes, int ncomp,
                             int width, int height, uint8_t *d_dst, ptrdiff_t dst_row_bytes, void *stream);
 
+/* the same for n frames of one size in one launch (the 2n frames of a batched Farneback call; host arrays of device pointers).
+ * Same bytes as n single calls; frames the four-pixel kernel cannot take (RGB, widths not a multiple of 4, unaligned rows)
+ * are converted one by one. */
+int ofxcv_to_byte_grayscale_batch(ofxcv_ctx *ctx, int n, const float *const *d_src, const ptrdiff_t *src_row_bytes,
+                                  int ncomp, int width, int height, uint8_t *const *d_dst,
+                                  const ptrdiff_t *dst_row_bytes, void *stream);
+
 /* ---- F1-F6: dense Farneback optical flow --------------------------------------------------
  * replaces cv::calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize,
  * iterations, poly_n, poly_sigma, flags) at VectorGenerator/VectorGenerator.cpp:403

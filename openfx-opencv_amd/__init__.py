@@ -58,7 +58,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
+    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_to_byte_grayscale_batch", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -157,6 +157,22 @@ class Context:
         self._call(lib().ofxcv_to_byte_grayscale, _ptr(src), C.c_ssize_t(src.stride(0) * 4), C.c_int(nc), C.c_int(w), C.c_int(h),
                    _ptr(out), C.c_ssize_t(out.stride(0)))
         return out
+
+    def to_byte_grayscale_batch(self, srcs, outs):
+        """n frames of one size in one launch: srcs HxWx{3,4} float32 CUDA tensors, outs HxW uint8 (written)."""
+        import torch
+        n = len(srcs)
+        assert n >= 1 and len(outs) == n
+        h, w, nc = srcs[0].shape
+        for s_, o in zip(srcs, outs):
+            assert s_.is_cuda and s_.dtype == torch.float32 and tuple(s_.shape) == (h, w, nc) and s_.stride(2) == 1 and s_.stride(1) == nc
+            assert o.is_cuda and o.dtype == torch.uint8 and tuple(o.shape) == (h, w) and o.stride(1) == 1
+        ps = (C.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+        po = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+        rs = (C.c_ssize_t * n)(*[s_.stride(0) * 4 for s_ in srcs])
+        ro = (C.c_ssize_t * n)(*[o.stride(0) for o in outs])
+        self._call(lib().ofxcv_to_byte_grayscale_batch, C.c_int(n), ps, rs, C.c_int(nc), C.c_int(w), C.c_int(h), po, ro)
+        return outs
 
     # ---- F1-F6 ----
     def calc_optical_flow_farneback(self, prev, nxt, flow=None, pyr_scale=0.5, levels=3, winsize=3, iterations=15,

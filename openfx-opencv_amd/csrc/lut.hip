@@ -114,6 +114,24 @@ __global__ __launch_bounds__(256) void gray_lut4_kernel(const float *__restrict_
     *(unsigned *)(dst + (ptrdiff_t)y * dst_row_bytes + (size_t)q * 4) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 
+// The same for the frames of a batched call (grid z = frame): one launch for the 2n frames of n pairs.
+constexpr int kLutBatch = 2 * OFXCV_FB_MAX_BATCH;
+struct LutTab {
+    const float *src[kLutBatch];
+    uint8_t *dst[kLutBatch];
+    ptrdiff_t src_rb[kLutBatch], dst_rb[kLutBatch];
+};
+__global__ __launch_bounds__(256) void gray_lut4_batch_kernel(LutTab t, int width, int height, const uint16_t *__restrict__ lut) {
+    const int y = blockIdx.y, z = blockIdx.z;
+    const int q = blockIdx.x * 256 + threadIdx.x;  // group of four pixels
+    if (q * 4 >= width) return;
+    const float4 *srow = (const float4 *)((const char *)t.src[z] + (ptrdiff_t)y * t.src_rb[z]) + (size_t)q * 4;
+    const float4 p0 = srow[0], p1 = srow[1], p2 = srow[2], p3 = srow[3];
+    const unsigned b0 = lut_byte(lut, p0.x, p0.y, p0.z), b1 = lut_byte(lut, p1.x, p1.y, p1.z), b2 = lut_byte(lut, p2.x, p2.y, p2.z),
+                   b3 = lut_byte(lut, p3.x, p3.y, p3.z);
+    *(unsigned *)(t.dst[z] + (ptrdiff_t)y * t.dst_rb[z] + (size_t)q * 4) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
 __global__ __launch_bounds__(256) void flow_to_rgba_kernel(const float *__restrict__ flow, size_t flow_step, int width,
                                                            int height, float *__restrict__ dst, ptrdiff_t dst_row_bytes,
                                                            unsigned mu, unsigned mv, double rsx, double rsy) {
@@ -171,6 +189,36 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
     else
         hipLaunchKernelGGL((gray_lut_kernel<3, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
     OFXCV_LAUNCH_CHECK(ctx, "gray_lut_kernel");
+    return OFXCV_OK;
+}
+
+int ofxcv_to_byte_grayscale_batch(ofxcv_ctx *ctx, int n, const float *const *d_src, const ptrdiff_t *src_row_bytes, int ncomp, int width,
+                                  int height, uint8_t *const *d_dst, const ptrdiff_t *dst_row_bytes, void *stream) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (n <= 0 || !d_src || !src_row_bytes || !d_dst || !dst_row_bytes) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "to_byte_grayscale_batch: bad argument");
+    bool fast = ncomp == 4 && ctx->lut4 && n <= kLutBatch && width > 0 && height > 0 && !(width & 3);
+    for (int i = 0; fast && i < n; i++)
+        fast = d_src[i] && d_dst[i] && !(((uintptr_t)d_src[i]) & 15) && !(src_row_bytes[i] & 15) && !(((uintptr_t)d_dst[i]) & 3) && !(dst_row_bytes[i] & 3);
+    if (!fast) {  // whatever the four-pixel kernel cannot take (RGB, odd widths, unaligned rows), and every argument check: frame by frame
+        for (int i = 0; i < n; i++) {
+            int rc = ofxcv_to_byte_grayscale(ctx, d_src[i], src_row_bytes[i], ncomp, width, height, d_dst[i], dst_row_bytes[i], stream);
+            if (rc) return rc;
+        }
+        return OFXCV_OK;
+    }
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ofxcv_stream(ctx, stream);
+    int rc = ensure_lut(ctx, s);
+    if (rc) return rc;
+    LutTab t = {};
+    for (int i = 0; i < n; i++) {
+        t.src[i] = d_src[i];
+        t.dst[i] = d_dst[i];
+        t.src_rb[i] = src_row_bytes[i];
+        t.dst_rb[i] = dst_row_bytes[i];
+    }
+    hipLaunchKernelGGL(gray_lut4_batch_kernel, dim3(ofxcv_div_up(width / 4, 256), height, n), dim3(256), 0, s, t, width, height, ctx->d_srgb_lut);
+    OFXCV_LAUNCH_CHECK(ctx, "gray_lut4_batch_kernel");
     return OFXCV_OK;
 }
 

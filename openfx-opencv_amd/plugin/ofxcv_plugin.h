@@ -189,7 +189,10 @@ class ThreadContext {
         std::lock_guard<std::mutex> lock(registry_mu());
         for (Holder *h : registry()) {
             std::lock_guard<std::mutex> hl(h->mu);
-            if (h->ctx) ofxcv_ctx_destroy(h->ctx);
+            if (h->ctx) {
+                (void)ofxcv_host_cache_clear(h->ctx);  // the named frames kept on its device (no call is using any: nothing is in flight)
+                ofxcv_ctx_destroy(h->ctx);
+            }
             h->ctx = nullptr;
         }
     }

@@ -699,3 +699,20 @@ def test_batch_initial_flow_and_argument_checks(oracle, ofxcv):
     with pytest.raises(ofxcv.OfxcvError):   # more pairs than the pointer tables hold
         ctx.calc_optical_flow_farneback_batch([_dev(prs[0][0])] * 17, [_dev(prs[0][1])] * 17)
     ctx.close()
+
+
+def test_gray_lut_batch_equals_single_calls(gpu_ctx):
+    """ofxcv_to_byte_grayscale_batch: the frames of a batched call in one launch -- the same bytes as one call per frame; RGB
+    frames, odd widths and unaligned views take the per-frame path behind the same entry point."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (h, w, nc, n) in ((120, 256, 4, 16), (67, 130, 4, 3), (40, 96, 3, 4), (33, 125, 4, 2), (64, 64, 4, 32)):
+        srcs = [(torch.rand((h, w, nc), generator=g) * 1.4 - 0.2).cuda() for _ in range(n)]
+        srcs[0][0, 0, 0] = float("nan")
+        srcs[-1][1, 1, :3] = float("inf")
+        want = [gpu_ctx.to_byte_grayscale(s) for s in srcs]
+        outs = [torch.full((h, w), 7, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        gpu_ctx.to_byte_grayscale_batch(srcs, outs)
+        torch.cuda.synchronize()
+        for a, b in zip(want, outs):
+            assert torch.equal(a, b), (h, w, nc, n)
