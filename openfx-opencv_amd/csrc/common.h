@@ -78,7 +78,9 @@ struct ofxcv_ctx {
     // reached at particular level sizes; validated in ofxcv_ctx_set_option.  Option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
     // 3 eight of 8 or 9; "farneback.halo_min8" / "halo_min4": workgroups from which the eight- / four-wavefront tall form is used;
     // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
-    int fb_halo_geom = 0, fb_halo_min8 = 250, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
+    // (halo_min8 300, was 250: a launch of exactly 256 tall workgroups -- 960x540 x 2 pairs, 480x270 x 8 -- is one round at half occupancy;
+    // the five-row form takes those: batches of 2 958 -> 1 024 pairs/s, batches of 8 +0.9 %, single calls and batches of 4 unchanged)
+    int fb_halo_geom = 0, fb_halo_min8 = 300, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
     int lut4 = 1;                // option "lut.four": gray LUT with four pixels per lane where the images are aligned for it
     int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
