@@ -37,7 +37,7 @@
 namespace {
 
 using namespace ofxcv_telea;            // flags, March, march_begin / march_advance (telea_march.h)
-constexpr int kFillWavesHost = 16;     // wavefronts per fill workgroup (kFillThreads / 64)
+constexpr int kFillWavesHost = 16;     // wavefronts per fill workgroup (kFillThreads / 64); 8 for the large-window instantiation
 
 // ------------------------------------------------------------------ I0-I2 kernels
 
@@ -183,7 +183,7 @@ void build_levels(March &m, bool dataflow) {
 // launch starts (stream order), later ones still carry kNeverFilled in the order map: the polls only ever wait inside
 // the portion.
 int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
-                           std::vector<int> &cell, std::vector<int> &stack, int per_wg, int max_wg) {
+                           std::vector<int> &cell, std::vector<int> &stack, int per_wg, int max_wg, int waves = kFillWavesHost) {
     const int ec = m.w + 2, er = m.h + 2, R = m.range + 2;
     const int cs = 2 * R + 1, gw = (ec + cs - 1) / cs, gh = (er + cs - 1) / cs;
     const int n = k1 - k0;
@@ -237,7 +237,7 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
         const int nc = off[c + 1] - off[c];
         const int g = std::min(max_wg, std::max(1, (nc + per_wg - 1) / per_wg));
         for (int r = 0; r < g; r++) {
-            const int rec[4] = {base + off[c], base + off[c + 1], r * kFillWavesHost, g * kFillWavesHost};
+            const int rec[4] = {base + off[c], base + off[c + 1], r * waves, g * waves};
             sched_wg.insert(sched_wg.end(), rec, rec + 4);
             nwg++;
         }
@@ -257,7 +257,7 @@ int build_dataflow_portion(const March &m, int k0, int k1, std::vector<int> &sch
 // middle of a 1080p fill 240-390 -> 110-230 us; the last two, the dense centres of the holes, stay chain-bound at ~600 us each).
 constexpr int kTileBudget = 192, kMinTileGroups = 48;
 int build_tile_portion(March &m, int k0, int k1, std::vector<int> &sched_pix, std::vector<int> &sched_ord, std::vector<int> &sched_wg,
-                       std::vector<int> &cell, int &ts_out, int max_tiles) {
+                       std::vector<int> &cell, int &ts_out, int max_tiles, int waves = kFillWavesHost) {
     const int ec = m.w + 2, er = m.h + 2;
     const int n = k1 - k0;
     if (n <= 0) return 0;
@@ -297,7 +297,7 @@ int build_tile_portion(March &m, int k0, int k1, std::vector<int> &sched_pix, st
             sched_ord[q] = k0 + k + 1;
         }
         for (int t = 0; t < ntile; t++) {
-            const int rec[4] = {base + off[t], base + off[t + 1], 0, kFillWavesHost};
+            const int rec[4] = {base + off[t], base + off[t + 1], 0, waves};
             sched_wg.insert(sched_wg.end(), rec, rec + 4);
         }
         ts_out = ts;
@@ -312,8 +312,9 @@ constexpr int kFillThreads = 1024;             // 16 wavefronts: 16 pixels of a 
 constexpr int kFillWaves = kFillThreads / 64;
 static_assert(kFillWaves == kFillWavesHost, "the host schedule assumes 16 wavefronts per workgroup");
 constexpr int kAcc = 10;                       // Ia[3], Jx[3], Jy[3], s
-constexpr int kMaxLdsRange = 5;                // (2r+3)^2 <= 169 neighbourhood entries staged in LDS
-constexpr int kWinMax = (2 * kMaxLdsRange + 3) * (2 * kMaxLdsRange + 3);
+constexpr int kMaxLdsRange = 5;                // (2r+3)^2 <= 169 neighbourhood entries staged in LDS: sixteen wavefronts per workgroup
+constexpr int kBigLdsRange = 12;               // ... <= 729 entries: the large-window instantiation, eight wavefronts per workgroup (radius 6 .. 12)
+constexpr int kBigFillWaves = 8;
 constexpr int kFillSlots = 8192;               // tile schedule: one LDS dword per fill-order pixel of a launch (the default portion)
 
 // The fill works on 4-byte pixels (R | G<<8 | B<<16 | X<<24), w*h dwords: one aligned load / store per pixel.
@@ -376,19 +377,20 @@ __global__ __launch_bounds__(256) void unpack_rgbx_kernel(const uint32_t *__rest
 //    trip through the L2 instead of a workgroup-wide level barrier.
 //  * otherwise (radius above kMaxLdsRange): the pixels of a component are grouped into dependency levels by the host
 //    and a workgroup barrier separates the levels.
-template <bool LDSWIN, bool NS>
-__global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
-    __shared__ float s_terms[kFillWaves][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
-    __shared__ int s_word[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
-    __shared__ float s_wt[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
-    __shared__ uint32_t s_wrgb[LDSWIN ? kFillWaves : 1][LDSWIN ? kWinMax : 1];
+template <bool LDSWIN, bool NS, int RMAX = kMaxLdsRange, int NWAVES = kFillWaves>
+__global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
+    constexpr int kWinMax = (2 * RMAX + 3) * (2 * RMAX + 3), kTapMax = (2 * RMAX + 1) * (2 * RMAX + 1);
+    __shared__ float s_terms[NWAVES][64][kAcc + 1];  // +1: odd stride, conflict-free column walks
+    __shared__ int s_word[LDSWIN ? NWAVES : 1][LDSWIN ? kWinMax : 1];
+    __shared__ float s_wt[LDSWIN ? NWAVES : 1][LDSWIN ? kWinMax : 1];
+    __shared__ uint32_t s_wrgb[LDSWIN ? NWAVES : 1][LDSWIN ? kWinMax : 1];
     // Tile schedule: slot q - k0 - 1 receives the colour | tag of the pixel with fill-order number q the moment it is final; the
     // wavefronts of this workgroup that need it poll the slot -- an LDS round trip where the store -> L2 -> poll path costs
     // microseconds per link of the dependency chain.  Only pixels of this workgroup's tile are ever looked up here.
     __shared__ uint32_t s_slot[LDSWIN ? kFillSlots : 1];
     const int ts = LDSWIN ? a.ts : 0;
     if (ts) {
-        for (int e = threadIdx.x; e < kFillSlots; e += kFillThreads) s_slot[e] = 0;
+        for (int e = threadIdx.x; e < kFillSlots; e += 64 * NWAVES) s_slot[e] = 0;
         __syncthreads();
     }
     const int ec = a.w + 2, er = a.h + 2, range = a.range;
@@ -415,40 +417,27 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                 auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
                 // What a window tap (one per lane and chunk of 64) needs of the maps alone: is it a tap at all, which neighbours
                 // of it count as known, and -- Telea -- its weight.  With the window in LDS this runs before the polls.
-                struct TapSetup {
-                    bool on;
-                    int km, kp, lm, lp;
-                    float rx, ry, vl, wgt;
-                    bool r_in, l_in, d_in, u_in;
+                struct TapSetup {  // bit 0: a tap at all; bits 1..4: right / left / down / up neighbour not known yet
+                    unsigned bits;
+                    float wgt;
                 };
-                constexpr int kChunks = LDSWIN ? (kWinMax + 63) / 64 : 1;
+                constexpr int kChunks = LDSWIN ? (kTapMax + 63) / 64 : 1;
                 TapSetup pre[kChunks];
                 float Tij = 0.f, gTx = 0.f, gTy = 0.f;
                 auto tap_setup = [&](int tap) -> TapSetup {
                     TapSetup ts_;
-                    ts_.on = false;
-                    ts_.km = ts_.kp = ts_.lm = ts_.lp = 0;
-                    ts_.rx = ts_.ry = ts_.vl = ts_.wgt = 0.f;
-                    ts_.r_in = ts_.l_in = ts_.d_in = ts_.u_in = false;
+                    ts_.bits = 0;
+                    ts_.wgt = 0.f;
                     if (tap >= ntap) return ts_;
                     const int k = i - range + tap / side, l = j - range + tap % side;
                     if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1 && (l - j) * (l - j) + (k - i) * (k - i) <= range * range && ORD(k, l) < o)) return ts_;
-                    ts_.on = true;
-                    ts_.km = k - 1 + (k == 1);
-                    ts_.kp = k - 1 - (k == er - 2);
-                    ts_.lm = l - 1 + (l == 1);
-                    ts_.lp = l - 1 - (l == ec - 2);
-                    ts_.ry = (float)(i - k);
-                    ts_.rx = (float)(j - l);
-                    ts_.vl = ts_.rx * ts_.rx + ts_.ry * ts_.ry;
-                    ts_.r_in = ORD(k, l + 1) >= o;
-                    ts_.l_in = ORD(k, l - 1) >= o;
-                    ts_.d_in = ORD(k + 1, l) >= o;
-                    ts_.u_in = ORD(k - 1, l) >= o;
+                    ts_.bits = 1u | (ORD(k, l + 1) >= o ? 2u : 0u) | (ORD(k, l - 1) >= o ? 4u : 0u) | (ORD(k + 1, l) >= o ? 8u : 0u) | (ORD(k - 1, l) >= o ? 16u : 0u);
                     if (!NS) {
-                        const float dst = (float)(1. / (ts_.vl * sqrt((double)ts_.vl)));
+                        const float ry = (float)(i - k), rx = (float)(j - l);
+                        const float vl = rx * rx + ry * ry;
+                        const float dst = (float)(1. / (vl * sqrt((double)vl)));
                         const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
-                        float dir = ts_.rx * gTx + ts_.ry * gTy;
+                        float dir = rx * gTx + ry * gTy;
                         if (fabs(dir) <= 0.01) dir = 0.000001f;
                         ts_.wgt = (float)fabs(dst * lev * dir);
                     }
@@ -569,10 +558,14 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
                     float term[kAcc];
 #pragma unroll
                     for (int q = 0; q < kAcc; q++) term[q] = 0.f;
-                    if (tp.on) {
-                        const int km = tp.km, kp = tp.kp, lm = tp.lm, lp = tp.lp;
-                        const float rx = tp.rx, ry = tp.ry, vl = tp.vl;
-                        const bool r_in = tp.r_in, l_in = tp.l_in, d_in = tp.d_in, u_in = tp.u_in;
+                    if (tp.bits & 1u) {
+                        const int tap = t0 + lane;
+                        const int k = i - range + tap / side, l = j - range + tap % side;
+                        const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
+                        const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
+                        const float ry = (float)(i - k), rx = (float)(j - l);
+                        const float vl = rx * rx + ry * ry;
+                        const bool r_in = tp.bits & 2u, l_in = tp.bits & 4u, d_in = tp.bits & 8u, u_in = tp.bits & 16u;
                         if (NS) {
                             const float dst = 1 / (vl * vl + 1);
 #pragma unroll
@@ -694,7 +687,7 @@ __global__ __launch_bounds__(kFillThreads) void telea_fill_kernel(FillArgs a) {
         int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
         for (int seg = seg_beg; seg < seg_end; seg++) {
             const int end = a.lvl_off[seg + 1];
-            for (int base = beg; base < end; base += kFillWaves) {
+            for (int base = beg; base < end; base += NWAVES) {
                 const int id = base + wave;
                 if (id < end) fill_pixel(a.lvl_pix[id], a.lvl_ord[id]);  // wave-uniform
             }
@@ -886,7 +879,9 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     }
     March &m = *(March *)ctx->ip_host_state;
     m.prepare(w, h, range);
-    const bool dataflow = range <= kMaxLdsRange;
+    const bool dataflow = range <= kBigLdsRange;  // the window fits LDS: sixteen wavefronts per workgroup up to radius 5, eight up to 12
+    const bool big_window = range > kMaxLdsRange;
+    const int fill_waves = big_window ? kBigFillWaves : kFillWaves;
     const bool any = march_begin(mask.data(), !ns, m);
     // large holes in several pieces: the pieces' fronts are marched side by side on host threads and their pop sequences merged
     // into the exact sequential fill order (telea_march.h); march_advance() below hands that order out in the same portions
@@ -1046,12 +1041,12 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             // 48 each).  A fill that starts while another one's larger launch is still running finds some of its workgroups queued
             // behind it for the rest of that launch (a fraction of a millisecond: the older launch is resident and waits for nobody).
             const int max_tiles = ctx->ip_max_tiles > 0 ? ctx->ip_max_tiles : std::max(kMinTileGroups, kTileBudget / std::max(1, FillSlot::active()));
-            if (ctx->ip_tiles && got <= kFillSlots) nwg = build_tile_portion(m, k0, k1, sp, so, sw, m.cell, ts, max_tiles);
+            if (ctx->ip_tiles && got <= kFillSlots) nwg = build_tile_portion(m, k0, k1, sp, so, sw, m.cell, ts, max_tiles, fill_waves);
             if (nwg < 0) {
                 ts = 0;
                 m.cell.clear();  // the tile pass leaves the grid in another geometry
                 nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256,
-                                             ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8);
+                                             ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8, fill_waves);
             }
             fa.k0 = k0;
             fa.ts = ts;
@@ -1082,7 +1077,10 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             fa.lvl_ord = fa.cmp_ord = (const int *)((uintptr_t)(ds + b_ord) - (uintptr_t)k0 * 4);
             fa.lvl_off = fa.cmp_off = (const int *)(ds + b_wg);
             cursor = b_end;
-            if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
+            if (big_window) {
+                if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true, kBigLdsRange, kBigFillWaves>), dim3(nwg), dim3(64 * kBigFillWaves), 0, s, fa);
+                else hipLaunchKernelGGL((telea_fill_kernel<true, false, kBigLdsRange, kBigFillWaves>), dim3(nwg), dim3(64 * kBigFillWaves), 0, s, fa);
+            } else if (ns) hipLaunchKernelGGL((telea_fill_kernel<true, true>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
             else hipLaunchKernelGGL((telea_fill_kernel<true, false>), dim3(nwg), dim3(kFillThreads), 0, s, fa);
             OFXCV_LAUNCH_CHECK(ctx, "telea_fill_kernel");
             launches++;

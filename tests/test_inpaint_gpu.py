@@ -93,16 +93,30 @@ def test_render_host_1080p_properties(oracle, gpu_ctx):
     assert np.array_equal(again[~hole_left], got[~hole_left])
 
 
-def test_telea_large_radius_global_path(oracle, gpu_ctx):
-    """radius > 5 takes the kernel variant without the LDS-staged neighbourhood (two tap chunks at radius 6)."""
+def test_telea_large_radii(oracle, ofxcv, gpu_ctx):
+    """Radius 6 .. 12 takes the large-window instantiation of the dataflow fill (the (2r+3)^2 neighbourhood of a pixel still fits
+    LDS with eight wavefronts per workgroup: up to 729 entries, ten tap chunks at radius 12), larger radii the kernel variant without
+    the LDS-staged neighbourhood (barrier-scheduled levels).  Same maps and colours as the oracle either way, for both methods,
+    and when the large-window fill is made to give up (spin limit 0: the barrier-scheduled repeat)."""
     fr = _frame(120, 90, holes=4)
     mask = oracle.inpaint_mask(fr, 1)
     rgb = np.ascontiguousarray(fr[..., :3])
-    for radius in (6, 9):
+    for radius in (6, 9, 12, 14):
         ref, t_ref, _, ord_ref = oracle.inpaint_telea(rgb, mask, radius, maps=True)
         dst, t, order = gpu_ctx.inpaint_telea(_dev(rgb), _dev(mask), radius, maps=True)
-        assert np.array_equal(order.cpu().numpy(), ord_ref) and np.array_equal(t.cpu().numpy(), t_ref)
-        assert np.array_equal(dst.cpu().numpy(), ref)
+        assert np.array_equal(order.cpu().numpy(), ord_ref) and np.array_equal(t.cpu().numpy(), t_ref), radius
+        assert np.array_equal(dst.cpu().numpy(), ref), radius
+    for radius in (7, 13):
+        ref = oracle.inpaint(rgb, mask, radius, oracle.INPAINT_NS)
+        assert np.array_equal(gpu_ctx.inpaint(_dev(rgb), _dev(mask), radius, ofxcv.INPAINT_NS).cpu().numpy(), ref), radius
+    c = ofxcv.Context(0)
+    c.set_option("inpaint.spin_limit", 0)
+    ref = oracle.inpaint_telea(rgb, mask, 8)
+    assert np.array_equal(c.inpaint_telea(_dev(rgb), _dev(mask), 8).cpu().numpy(), ref) and c.inpaint_fallback_count() >= 1
+    c.close()
+    big = _frame(640, 360, holes=8)                      # several portions and many tiles at a large radius
+    ref = oracle.inpaint_render(big, 10.0, 1.0)
+    assert np.array_equal(gpu_ctx.inpaint_render_host(big, 10.0, 1.0), ref)
 
 
 # ---- CV_INPAINT_NS (SURVEY.md 8(f) rank 2): the other value of cvInpaint's method argument ----
