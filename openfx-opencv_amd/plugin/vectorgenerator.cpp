@@ -238,8 +238,10 @@ void calc_optical_flow(OfxImageEffectHandle effect, const Image &ref, const Imag
     ofxcv_ctx *ctx = ThreadContext::get();
     if (x1 == ref.bounds.x1 && y1 == ref.bounds.y1 && x2 == ref.bounds.x2 && y2 == ref.bounds.y2) {
         float *d0 = (float *)((char *)dst.data + (ptrdiff_t)(y1 - dst.bounds.y1) * dst.row_bytes) + (size_t)(x1 - dst.bounds.x1) * 4;
-        check_hip(ctx, ofxcv_vectorgen_flow_host(ctx, (const float *)ref.data, ref.row_bytes, (const float *)other.data, other.row_bytes, ncomp, w, h,
-                                                 d0, dst.row_bytes, mu, mv, rsx, rsy, levels, iterations, poly_n, poly_sigma));
+        // (the frames with the names the host gives their pixels, as in the two-direction call of render())
+        check_hip(ctx, ofxcv_vectorgen_flows_host_keyed(ctx, (const float *)ref.data, ref.row_bytes, (const float *)other.data, other.row_bytes, nullptr, 0,
+                                                        ncomp, w, h, d0, dst.row_bytes, mu, mv, 0, 0, rsx, rsy, levels, iterations, poly_n, poly_sigma,
+                                                        ref.unique_id.c_str(), other.unique_id.c_str(), nullptr));
     } else {
         std::vector<float> tmp((size_t)w * h * 4);
         // pre-load the window so unmapped channels keep the output image's content
