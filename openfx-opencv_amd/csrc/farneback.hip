@@ -233,12 +233,16 @@ __device__ __forceinline__ void xcd_tile(int &bx, int &by) {
 // only at the needed rows.  Values are identical to blur-then-resize because the column filter
 // never mixes columns.
 
-__global__ __launch_bounds__(256) void pyr_hblur_kernel(const uint8_t *__restrict__ img, size_t step, int W, int H,
+// (grid z = frame first + z of the table; its half-blurred rows at T1 + z * H * ncol)
+__global__ __launch_bounds__(256) void pyr_hblur_kernel(ImgTab imgs, int first, int W, int H,
                                                         int lw, int ntap, GaussTaps gk, float *__restrict__ T1) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
     int ncol = lw * ntap;
     if (c >= ncol) return;
+    const uint8_t *__restrict__ img = imgs.p[first + blockIdx.z];
+    const size_t step = imgs.step[first + blockIdx.z];
+    T1 += (size_t)blockIdx.z * H * ncol;
     int sx;
     if (ntap == 1) {
         sx = c;
@@ -275,11 +279,13 @@ __device__ __forceinline__ float col_filter(const float *__restrict__ T1, int nc
 }
 
 __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__restrict__ T1, int W, int H, int lw, int lh,
-                                                               int ntap, GaussTaps gk, float *__restrict__ I, int area) {
+                                                               int ntap, GaussTaps gk, float *__restrict__ I, size_t I_stride, int area) {
     int dx = blockIdx.x * blockDim.x + threadIdx.x;
     int dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= lw || dy >= lh) return;
     int ncol = lw * ntap;
+    T1 += (size_t)blockIdx.z * H * ncol;
+    I += (size_t)blockIdx.z * I_stride;
     float out;
     if (ntap == 1) {
         out = col_filter(T1, ncol, dx, dy, H, gk);
@@ -2364,7 +2370,7 @@ int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, 
         L.rtotal += 2 * 5 * (size_t)plane_pitch(w) * h;
     }
     L.planes = 2 * L.field0 + L.rtotal;
-    L.t1 = round_up((size_t)(width + 4) * height, 64);
+    L.t1 = round_up((size_t)2 * (width + 4) * height, 64);  // (twice a frame's rows at level 0: all 32 frames of a call at the levels the fall-back serves)
     L.img = round_up((size_t)width * height, 64);
     L.cflow = 0;
     if (levels > 0) {
@@ -2379,7 +2385,7 @@ int make_layout(ofxcv_ctx *ctx, int n, int width, int height, double pyr_scale, 
 
 // F1/F2 for `nimg` frames in one launch (grid z = frame); I of frame i at d_I + i * I_stride
 int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg, int W, int H, int lw, int lh, double sigma, int ksize,
-                     float *d_T1, float *d_I, size_t I_stride) {
+                     float *d_T1, size_t t1_floats, float *d_I, size_t I_stride) {
     if (ksize > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksize, kMaxGaussTaps);
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk, ctx->fb_gauss_generation);
@@ -2437,12 +2443,18 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
         OFXCV_LAUNCH_CHECK(ctx, "pyr_fused_kernel");
         return OFXCV_OK;
     }
-    int ncol = lw * ntap;
-    for (int i = 0; i < nimg; i++) {  // two-pass fall-back, frame by frame through the one row buffer
-        hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H), dim3(256), 0, s, imgs.p[i], imgs.step[i], W, H, lw, ntap, gk, d_T1);
+    // Two-pass fall-back (the levels beyond 1/8 of a deeper pyramid: 39 taps and more): as many frames per launch as the row buffer
+    // holds -- at these levels a frame's half-blurred rows are W * H / 8 floats or less, so the 2n frames of a call are one or two
+    // launch pairs (they were 2n pairs of launches, one frame at a time: 1.4 ms of a 6.8 ms call of 8 pairs at levels = 5).
+    const int ncol = lw * ntap;
+    const size_t per_frame = (size_t)H * ncol;
+    const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)nimg, t1_floats / std::max<size_t>(per_frame, 1)));
+    for (int i = 0; i < nimg; i += group) {
+        const int g = std::min(group, nimg - i);
+        hipLaunchKernelGGL(pyr_hblur_kernel, dim3(ofxcv_div_up(ncol, 256), H, g), dim3(256), 0, s, imgs, i, W, H, lw, ntap, gk, d_T1);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_hblur_kernel");
-        hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4)), dim3(64, 4), 0, s, d_T1, W, H,
-                           lw, lh, ntap, gk, d_I + (size_t)i * I_stride, area);
+        hipLaunchKernelGGL(pyr_vblur_resize_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4), g), dim3(64, 4), 0, s, d_T1, W, H,
+                           lw, lh, ntap, gk, d_I + (size_t)i * I_stride, I_stride, area);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_vblur_resize_kernel");
     }
     return OFXCV_OK;
@@ -2790,7 +2802,8 @@ int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step,
     ImgTab imgs = {};
     imgs.p[0] = d_img;
     imgs.step[0] = step;
-    return launch_pyr_image(ctx, ofxcv_stream(ctx, stream), imgs, 1, width, height, lw, lh, sigma, ksize, (float *)ctx->fb_tmp.ptr, d_I, 0);
+    return launch_pyr_image(ctx, ofxcv_stream(ctx, stream), imgs, 1, width, height, lw, lh, sigma, ksize, (float *)ctx->fb_tmp.ptr,
+                            (size_t)(2 * lw + 2) * height, d_I, 0);
 }
 
 int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n, double poly_sigma,
@@ -2864,7 +2877,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             R[k][0] = p;
             R[k][1] = p + field;
             p += 2 * field;
-            rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, I, L.img);
+            rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, L.t1, I, L.img);
             if (rc) return rc;
             rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field);
             if (rc) return rc;

@@ -716,3 +716,26 @@ def test_gray_lut_batch_equals_single_calls(gpu_ctx):
         torch.cuda.synchronize()
         for a, b in zip(want, outs):
             assert torch.equal(a, b), (h, w, nc, n)
+
+
+def test_deep_pyramid_and_two_pass_images_in_batches(oracle, ofxcv):
+    """The pyramid images of levels beyond 1/8 (levels = 5 at 1024x576: 39 and 79 blur taps) come from the two-pass kernels
+    (row filter into a buffer, column filter + resize), which take as many frames of a call per launch as the buffer holds; option
+    farneback.fused_pyramid 0 sends every level that way.  A batch equals its single calls bit for bit either way, the two-pass
+    images equal the fused ones, and pair 0 is within tolerance of the faithful oracle."""
+    w, h, n = 1024, 576, 5
+    prs = _pairs(oracle, w, h, range(300, 300 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    kw = dict(levels=5, iterations=2)
+    single = ofxcv.Context(0)
+    singles = [single.calc_optical_flow_farneback(x, y, **kw).cpu().numpy() for x, y in zip(da, db)]
+    for fused in (1, 0):
+        c = ofxcv.Context(0)
+        c.set_option("farneback.fused_pyramid", fused)
+        got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(da, db, **kw)]
+        for z in range(n):
+            assert np.array_equal(got[z], singles[z]), (fused, z)
+        c.close()
+    ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL, **kw)
+    assert (np.abs(singles[0] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
+    single.close()
