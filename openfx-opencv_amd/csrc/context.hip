@@ -288,7 +288,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             {"farneback.halo_deep", &ctx->fb_halo_deep, 0, 8},    {"farneback.halo_small", &ctx->fb_halo_small, 2, 6},
             {"farneback.halo_min5", &ctx->fb_halo_min5, 0, 1 << 30}, {"lut.four", &ctx->lut4, 0, 1},
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
-            {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1},
+            {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
             {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {

@@ -2935,12 +2935,43 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         // (one exception: a single iteration on a caller-supplied flow at level 0 would pair "first M from the given flow" with "last: flow
         // out" in ONE launch over the SAME buffer -- a workgroup's halo lanes read columns its neighbour overwrites; found by tests/perf/fuzz_halo.py)
         const bool given_in_place = k == 0 && !have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW) && iterations == 1;
-        const bool col = !given_in_place && col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian);
-        const int per_group = col ? n : ofxcv_div_up(n, ofxcv_div_up(n, fit));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
+        // How many pairs take the column-owning form.  One workgroup per tile column and pair, one workgroup per CU: a launch lasts
+        // ceil(workgroups / CUs) rounds, so 33 tile columns x 8 pairs = 264 workgroups on 256 CUs would be TWO rounds (a 1921-pixel-wide
+        // frame: 0.94 against 0.65 ms per pair at 1920).  The pairs that do not fill a round keep the overlapped strips instead -- the
+        // forms are per pair (their fields never meet).  Cost model in rounds of the column-owning launch: a pair in strips costs
+        // 0.196 x w / 1920 of a round (2 x 39.7 us against 405 us at 1920x1080; both scale with the level's height).
+        int ncol = 0;
+        if (!given_in_place && col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian)) {
+            const long T = ofxcv_div_up(w, kColW), cus = std::max(1, ctx->num_cus);
+            const double strip_cost = 0.196 * w / 1920.0;
+            double best = 0;
+            const long floor_wg = std::min<long>(ctx->fb_col_min, cus * 3 / 4);  // (a launch that fills less than three quarters of a round loses against the strips)
+            for (int g = n; g >= 1 && T * g >= floor_wg; g--) {
+                const double cost = (double)ofxcv_div_up(T * g, cus) + (n - g) * strip_cost;
+                if (ncol == 0 || cost < best - 1e-9) {
+                    best = cost;
+                    ncol = g;
+                }
+            }
+            if (ctx->fb_col_split == 0 && ncol) ncol = n;  // option: the whole call or nothing (rounds 4's first half)
+        }
+        struct Group {
+            int z0, gn;
+            bool col;
+        };
+        Group plan[kMaxBatch + 1];
+        int ngroups = 0;
+        if (ncol) plan[ngroups++] = {0, ncol, true};
+        if (ncol < n) {
+            const int rest = n - ncol;
+            const int per_group = ofxcv_div_up(rest, ofxcv_div_up(rest, std::min(fit, rest)));  // groups of equal size (4 pairs, 3 fit: 2 + 2, not 3 + 1)
+            for (int z = ncol; z < n; z += per_group) plan[ngroups++] = {z, std::min(per_group, n - z), false};
+        }
         const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
         const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
-        for (int z0 = 0; z0 < n; z0 += per_group) {
-            const int gn = std::min(per_group, n - z0);
+        for (int gi = 0; gi < ngroups; gi++) {
+            const int z0 = plan[gi].z0, gn = plan[gi].gn;
+            const bool col = plan[gi].col;
             Layout G = L;  // this group's view of the scratch: its first pair is "pair 0" of every launch
             G.n = gn;
             G.vsum_ptr = (double *)ctx->fb_vsum.ptr + (size_t)z0 * L.vsum;

@@ -739,3 +739,38 @@ def test_deep_pyramid_and_two_pass_images_in_batches(oracle, ofxcv):
     ref = oracle.calc_optical_flow_farneback(prs[0][0], prs[0][1], blur_mode=oracle.BLUR_FAITHFUL, **kw)
     assert (np.abs(singles[0] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
     single.close()
+
+
+def test_column_owning_form_for_part_of_a_batch(oracle, ofxcv):
+    """One workgroup per tile column and pair, one workgroup per CU: the pairs of a call that would start another round of the
+    chip keep the overlapped strips (farneback.col_split; a 1921-pixel-wide frame has 33 tile columns: 7 pairs fill the 256 CUs,
+    the eighth does not).  With the column-owning form forced from 3 workgroups on a small frame (6 tile columns) the split is
+    driven through the same plan: whatever mix of forms a batch is walked in, every pair equals its single call bit for bit."""
+    w, h, n = 333, 257, 7
+    prs = _pairs(oracle, w, h, range(400, 400 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    single = ofxcv.Context(0)
+    singles = [single.calc_optical_flow_farneback(x, y, iterations=4).cpu().numpy() for x, y in zip(da, db)]
+    single.close()
+    for opts in (dict(col_min=1), dict(col_min=1, col_split=0), dict(col_min=12), dict(col_min=30), dict(col_min=36), dict(col=0)):
+        c = ofxcv.Context(0)
+        for k, v in opts.items():
+            c.set_option("farneback." + k, v)
+        got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(da, db, iterations=4)]
+        for z in range(n):
+            assert np.array_equal(got[z], singles[z]), (opts, z)
+        assert c.get_option("farneback.col_aborts") == 0
+        c.close()
+    # the real thing: 33 tile columns x 8 pairs (7 in the column-owning form + 1 in strips), pairs 0 and 7 against single calls
+    w, h, n = 1921, 360, 8
+    prs = _pairs(oracle, w, h, range(500, 500 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    c = ofxcv.Context(0)
+    got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(da, db, iterations=3)]
+    s1 = ofxcv.Context(0)
+    for z in (0, 6, 7):
+        assert np.array_equal(got[z], s1.calc_optical_flow_farneback(da[z], db[z], iterations=3).cpu().numpy()), z
+    ref = oracle.calc_optical_flow_farneback(prs[7][0], prs[7][1], iterations=3, blur_mode=oracle.BLUR_FAITHFUL)
+    assert (np.abs(got[7] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
+    c.close()
+    s1.close()
