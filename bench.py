@@ -345,8 +345,9 @@ def main():
     # form: a level is walked in groups of pairs whose working set (80 B/px each) stays inside the Infinity Cache budget
     # (option farneback.batch_mb), one iteration per launch -- see enqueue_farneback
     pitch = ofxcv.farneback_plane_pitch(W) if hasattr(ofxcv, "farneback_plane_pitch") else (W + 63) // 64 * 64
-    col = bool(ctxs[0].get_option("farneback.col")) and H >= 64 and -(-W // COL_W) * B >= ctxs[0].get_option("farneback.col_min")
-    ppl = B if col else max(1, min(B, (ctxs[0].get_option("farneback.batch_mb") << 20) // (80 * pitch * H)))
+    ncol = ctxs[0].farneback_col_pairs(W, H, B)  # the library's own plan for level 0 (the pairs beyond it keep the overlapped strips)
+    col = ncol > 0
+    ppl = ncol if col else max(1, min(B, (ctxs[0].get_option("farneback.batch_mb") << 20) // (80 * pitch * H)))
     iters_per_launch = 2 if col else 1
     # the dominant kernel is timed on calls of as many pairs as one of its launches carries in the timed workload
     kl = {k: v[:ppl] for k, v in bufs[0].items()}

@@ -168,6 +168,11 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
                                                  const unsigned *chan_v_mask, double render_scale_x,
                                                  double render_scale_y, void *stream);
 
+/* how many of the n pairs of a batched call walk level 0 of a width x height frame in the column-owning form (two iterations per
+ * launch) with the context's current options -- the first that many; the others keep the overlapped strips (bench.py: which
+ * kernel dominates the timed workload) */
+int ofxcv_farneback_col_pairs(const ofxcv_ctx *ctx, int width, int height, int n);
+
 /* ---- F7: flow -> RGBA write-back ----------------------------------------------------------
  * replaces the loop at VectorGenerator/VectorGenerator.cpp:494-519.  chan_u_mask/chan_v_mask:
  * bit c set = RGBA channel c receives flow.x / flow.y (divided by the render scale); channels

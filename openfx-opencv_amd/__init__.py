@@ -59,7 +59,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
     "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_to_byte_grayscale_batch", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
-    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_num_levels",
+    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_col_pairs", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
     "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_fallback_count", "ofxcv_inpaint_render_host",
@@ -290,6 +290,10 @@ class Context:
             kk = [C.c_char_p(k.encode()) if k else C.c_char_p(None) for k in keys]
             self._check(lib().ofxcv_vectorgen_flows_host_keyed(*args, *kk))
         return dst
+
+    def farneback_col_pairs(self, width, height, n):
+        """pairs of a batched call of n that walk level 0 in the column-owning form (ofxcv_farneback_col_pairs)"""
+        return int(lib().ofxcv_farneback_col_pairs(self._h, C.c_int(width), C.c_int(height), C.c_int(n)))
 
     def host_cache_hits(self):
         lib().ofxcv_host_cache_hits.restype = C.c_long

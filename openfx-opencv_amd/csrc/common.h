@@ -86,7 +86,7 @@ struct ofxcv_ctx {
     int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
-    int fb_col_min = 250;        // option "farneback.col_min": workgroups (tile columns x pairs of the call) from which a level takes that form
+    int fb_col_min = 128;        // option "farneback.col_min": workgroups (tile columns x pairs) below which no launch takes that form; from there on a cost model decides per level how many pairs do (col_pairs in farneback.hip); values below the default force the form (tests)
     int fb_col_split = 1;        // option "farneback.col_split": the pairs of a call that do not fill a round of the chip in that form keep the overlapped strips (1); 0 = all pairs or none
     int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (A/B; same launch time, profiles/r04_experiments.md #19)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word

@@ -2706,6 +2706,32 @@ bool col_level(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
     if (!halo || !ctx->fb_col || h < 64) return false;
     return (long)ofxcv_div_up(w, kColW) * n >= ctx->fb_col_min;
 }
+// How many of the n pairs of a call walk a w x h level in the column-owning form (the first that many; the others keep the
+// overlapped strips -- the forms are per pair, their fields never meet).  One workgroup per tile column and pair, one workgroup per
+// CU: a launch lasts ceil(workgroups / CUs) rounds, so 33 tile columns x 8 pairs = 264 workgroups on 256 CUs would be TWO rounds
+// (a 1921-pixel-wide frame: 0.94 against 0.65 ms per pair at 1920), and 4 x 32 = 128 workgroups leave half the chip idle for a
+// whole round.  Cost model in rounds of the column-owning launch: a pair in strips costs 0.196 x w / 1920 of a round (2 x 39.7 us
+// against 405 us at 1920x1080; both scale with the level's height) -- it reproduces where the form was measured to pay
+// (profiles/r04_experiments.md: 1080p from 6 pairs, 3840x2160 from 3, not 1080p x 4 or 5).  A farneback.col_min below the default
+// (tests) forces the form wherever it reaches that many workgroups.
+constexpr int kColMinDefault = 128;
+int col_pairs(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
+    if (!col_level(ctx, w, h, n, halo)) return 0;
+    const long T = ofxcv_div_up(w, kColW), cus = std::max(1, ctx->num_cus);
+    const double strip_cost = 0.196 * w / 1920.0;
+    const bool forced = ctx->fb_col_min < kColMinDefault;
+    int ncol = 0;
+    double best = forced ? 1e30 : n * strip_cost;  // (all pairs in strips)
+    for (int g = n; g >= 1 && T * g >= ctx->fb_col_min; g--) {
+        const double cost = (double)ofxcv_div_up(T * g, cus) + (n - g) * strip_cost;
+        if (cost < best - 1e-9) {
+            best = cost;
+            ncol = g;
+        }
+    }
+    if (ctx->fb_col_split == 0 && ncol) ncol = n;  // option: the whole call or nothing (round 4's first half)
+    return ncol;
+}
 int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Din, float *Dout, const FlowTab &fin, const FlowTab &fout,
                      const Prolong &pr, int w, int h, int k1, int k2, const HaloScratch &hs, int slot, const Layout &L, const RgbaTab *rgba = nullptr) {
     RgbaTab rg = {};
@@ -2935,26 +2961,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
         // (one exception: a single iteration on a caller-supplied flow at level 0 would pair "first M from the given flow" with "last: flow
         // out" in ONE launch over the SAME buffer -- a workgroup's halo lanes read columns its neighbour overwrites; found by tests/perf/fuzz_halo.py)
         const bool given_in_place = k == 0 && !have_prev && (flags & OFXCV_OPTFLOW_USE_INITIAL_FLOW) && iterations == 1;
-        // How many pairs take the column-owning form.  One workgroup per tile column and pair, one workgroup per CU: a launch lasts
-        // ceil(workgroups / CUs) rounds, so 33 tile columns x 8 pairs = 264 workgroups on 256 CUs would be TWO rounds (a 1921-pixel-wide
-        // frame: 0.94 against 0.65 ms per pair at 1920).  The pairs that do not fill a round keep the overlapped strips instead -- the
-        // forms are per pair (their fields never meet).  Cost model in rounds of the column-owning launch: a pair in strips costs
-        // 0.196 x w / 1920 of a round (2 x 39.7 us against 405 us at 1920x1080; both scale with the level's height).
-        int ncol = 0;
-        if (!given_in_place && col_level(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian)) {
-            const long T = ofxcv_div_up(w, kColW), cus = std::max(1, ctx->num_cus);
-            const double strip_cost = 0.196 * w / 1920.0;
-            double best = 0;
-            const long floor_wg = std::min<long>(ctx->fb_col_min, cus * 3 / 4);  // (a launch that fills less than three quarters of a round loses against the strips)
-            for (int g = n; g >= 1 && T * g >= floor_wg; g--) {
-                const double cost = (double)ofxcv_div_up(T * g, cus) + (n - g) * strip_cost;
-                if (ncol == 0 || cost < best - 1e-9) {
-                    best = cost;
-                    ncol = g;
-                }
-            }
-            if (ctx->fb_col_split == 0 && ncol) ncol = n;  // option: the whole call or nothing (rounds 4's first half)
-        }
+        const int ncol = given_in_place ? 0 : col_pairs(ctx, w, h, n, ctx->fb_opencv_rounding == 1 && winsize == 3 && !gaussian);
         struct Group {
             int z0, gn;
             bool col;
@@ -3278,6 +3285,11 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
     }
     return OFXCV_OK;
+}
+
+int ofxcv_farneback_col_pairs(const ofxcv_ctx *ctx, int width, int height, int n) {
+    if (!ctx || width <= 0 || height <= 0 || n <= 0) return 0;
+    return col_pairs(ctx, width, height, n, ctx->fb_opencv_rounding == 1);
 }
 
 int ofxcv_calc_optical_flow_farneback(ofxcv_ctx *ctx, const uint8_t *d_prev, size_t prev_step, const uint8_t *d_next,
