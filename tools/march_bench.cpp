@@ -12,7 +12,24 @@ int main(int argc, char **argv) {
     const int w = argc > 1 ? atoi(argv[1]) : 1920, h = argc > 2 ? atoi(argv[2]) : 1080;
     std::mt19937 rng(42);
     std::vector<uint8_t> mask((size_t)w * h, 0);
-    for (int b = 0; b < 12; b++) {
+    const bool dust = argc > 3 && !strcmp(argv[3], "dust"), scratches = argc > 3 && !strcmp(argv[3], "scratches");
+    if (dust)  // 3000 specks of 3x3 .. 7x7 pixels
+        for (int b = 0; b < 3000; b++) {
+            const int x = 4 + rng() % (w - 8), y = 4 + rng() % (h - 8), r = 1 + rng() % 3;
+            for (int yy = y - r; yy <= y + r; yy++)
+                for (int xx = x - r; xx <= x + r; xx++) mask[(size_t)yy * w + xx] = 255;
+        }
+    if (scratches)  // 40 lines, 3 pixels wide
+        for (int b = 0; b < 40; b++) {
+            const double x0 = rng() % w, y0 = rng() % h, ang = (rng() % 3141) / 1000.0;
+            const int L = 200 + rng() % 700;
+            for (int t = 0; t < L; t++)
+                for (int d = 0; d < 3; d++) {
+                    const int x = (int)(x0 + t * std::cos(ang)), y = (int)(y0 + t * std::sin(ang)) + d;
+                    if (x >= 0 && y >= 0 && x < w && y < h) mask[(size_t)y * w + x] = 255;
+                }
+        }
+    for (int b = 0; b < 12 && !dust && !scratches; b++) {
         const int cx = rng() % w, cy = rng() % h, rx = w / 60 + rng() % (w / 26), ry = h / 60 + rng() % (h / 15);
         for (int y = std::max(0, cy - ry); y <= std::min(h - 1, cy + ry); y++)
             for (int x = std::max(0, cx - rx); x <= std::min(w - 1, cx + rx); x++) {
