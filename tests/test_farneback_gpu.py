@@ -774,3 +774,15 @@ def test_column_owning_form_for_part_of_a_batch(oracle, ofxcv):
     assert (np.abs(got[7] - ref) <= REL_TOL * np.maximum(1, np.abs(ref))).all()
     c.close()
     s1.close()
+
+
+def test_column_owning_plan(gpu_ctx):
+    """ofxcv_farneback_col_pairs: how many pairs of a call walk level 0 in the column-owning form (256 CUs, one workgroup per
+    tile column and pair, launches charged in rounds of the chip against 0.196 x w / 1920 of a round per pair in strips)."""
+    if gpu_ctx.get_option("farneback.col") != 1:
+        pytest.skip("column-owning form switched off on the shared context")
+    plan = lambda w, h, n: gpu_ctx.farneback_col_pairs(w, h, n)
+    assert [plan(1920, 1080, n) for n in (1, 4, 5, 6, 7, 8, 9, 12, 16)] == [0, 0, 0, 6, 7, 8, 8, 8, 16]
+    assert [plan(1921, 1081, n) for n in (8, 16)] == [7, 15]          # 33 tile columns: 264 workgroups would be two rounds
+    assert [plan(3840, 2160, n) for n in (1, 2, 3, 4, 5, 8)] == [0, 0, 3, 4, 4, 8]
+    assert plan(1920, 40, 8) == 0                                     # too few rows for a column walk
