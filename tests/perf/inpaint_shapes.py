@@ -2,7 +2,7 @@
 """Render-body time of the inpaint call over hole shapes at 1920x1080: the BASELINE frame (12 ellipses), one large blob, many small
 holes (dust), thin scratches, a wide border strip -- with the hole pixels and the CPU oracle's time of each."""
 import os, sys, time, statistics
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth
