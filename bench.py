@@ -340,8 +340,8 @@ def main():
     el = timed_regions(ctxs, bufs, args.steps, args.warmup, max(1, args.repeats))
     pairs_per_region = sharding.reduce_count_sum(args.steps * P, dist, red_dev)
     rates = [pairs_per_region / e for e in el]
-    # pairs one level-0 launch of the dominant kernel carries.  Column-owning form (iterate_col_kernel, taken when tile columns x pairs of
-    # the call reach farneback.col_min workgroups): every pair of the call, TWO iterations per launch.  Otherwise the overlapped-strip
+    # pairs one level-0 launch of the dominant kernel carries.  Column-owning form (iterate_col_kernel, taken by the pairs of the call that
+    # fill whole rounds of the chip: ofxcv_farneback_col_pairs): those pairs, TWO iterations per launch.  Otherwise the overlapped-strip
     # form: a level is walked in groups of pairs whose working set (80 B/px each) stays inside the Infinity Cache budget
     # (option farneback.batch_mb), one iteration per launch -- see enqueue_farneback
     pitch = ofxcv.farneback_plane_pitch(W) if hasattr(ofxcv, "farneback_plane_pitch") else (W + 63) // 64 * 64

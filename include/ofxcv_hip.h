@@ -49,10 +49,11 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 /* context options:
  *   "farneback.opencv_rounding" 1|0|2 how the 3x3 box window of FarnebackUpdateFlow_Blur is evaluated.
  *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical
- *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel: levels
- *                                      whose launches fill the chip (tile columns x pairs of the call >= "farneback.col_min")
- *                                      by column-owning workgroups that run TWO iterations per launch (iterate_col_kernel),
- *                                      the others by overlapped strips, one launch per iteration (iterate3h_kernel).
+ *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel: per level
+ *                                      the pairs of the call that fill whole rounds of the chip (one workgroup per tile column
+ *                                      and pair; ofxcv_farneback_col_pairs) by column-owning workgroups that run TWO iterations
+ *                                      per launch (iterate_col_kernel), the others by overlapped strips, one launch per iteration
+ *                                      (iterate3h_kernel).
  *                                      Reproduces the reference's rounding noise: every sample within 1e-4 (relative) of
  *                                      the CPU result.
  *                                    0: direct sums (each window summed on its own in f64, two iterations fused per launch):
@@ -62,7 +63,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
  *                                    Window sizes other than the reference's 3 always use direct sums.
  *   "farneback.col"             0|1  the column-owning form on the levels that qualify (default 1);
- *   "farneback.col_min"         n    workgroups (tile columns of 60 pixels x pairs of the call) from which a level takes it (250);
+ *   "farneback.col_min"         n    workgroups (tile columns of 60 pixels x pairs) below which no launch takes it (128; from there on a cost
+ *                                    model in rounds of the chip decides how many pairs do; smaller values force the form: tests);
+ *   "farneback.col_split"       0|1  the pairs that would start another round of the chip keep the overlapped strips (1) / all or none (0);
  *   "farneback.batch_mb"        MiB  the other levels are walked with as many pairs per launch as keep the level's working set
  *                                    under this (160: the Infinity Cache holds 256 MiB);
  *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x
