@@ -417,21 +417,29 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                 auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
                 // What a window tap (one per lane and chunk of 64) needs of the maps alone: is it a tap at all, which neighbours
                 // of it count as known, and -- Telea -- its weight.  With the window in LDS this runs before the polls.
-                struct TapSetup {  // bit 0: a tap at all; bits 1..4: right / left / down / up neighbour not known yet
+                // bit 0: a tap at all; bits 1..4: right / left / down / up neighbour not known yet; bit 5: inside the circle of the window
+                // (whatever the maps say), bits 8..13: its rank among the chunk's lanes inside the circle.  Only those taps can
+                // contribute, and only they are summed: 29 of the 49 window positions at radius 3 -- the ordered sum is the longest
+                // stretch of the pixel -> pixel chain, and skipping a term that is zero by construction does not change it.
+                struct TapSetup {
                     unsigned bits;
                     float wgt;
                 };
                 constexpr int kChunks = LDSWIN ? (kTapMax + 63) / 64 : 1;
                 TapSetup pre[kChunks];
                 float Tij = 0.f, gTx = 0.f, gTy = 0.f;
-                auto tap_setup = [&](int tap) -> TapSetup {
+                auto tap_setup = [&](int tap) -> TapSetup {  // (called by all lanes of the wavefront together: it takes a ballot)
                     TapSetup ts_;
                     ts_.bits = 0;
                     ts_.wgt = 0.f;
-                    if (tap >= ntap) return ts_;
                     const int k = i - range + tap / side, l = j - range + tap % side;
-                    if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1 && (l - j) * (l - j) + (k - i) * (k - i) <= range * range && ORD(k, l) < o)) return ts_;
-                    ts_.bits = 1u | (ORD(k, l + 1) >= o ? 2u : 0u) | (ORD(k, l - 1) >= o ? 4u : 0u) | (ORD(k + 1, l) >= o ? 8u : 0u) | (ORD(k - 1, l) >= o ? 16u : 0u);
+                    const bool circ = tap < ntap && (l - j) * (l - j) + (k - i) * (k - i) <= range * range;
+                    const unsigned long long cm = __builtin_amdgcn_ballot_w64(circ);
+                    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
+                    if (!circ) return ts_;
+                    ts_.bits = 32u | (rank << 8);
+                    if (!(k > 0 && l > 0 && k < er - 1 && l < ec - 1 && ORD(k, l) < o)) return ts_;
+                    ts_.bits |= 1u | (ORD(k, l + 1) >= o ? 2u : 0u) | (ORD(k, l - 1) >= o ? 4u : 0u) | (ORD(k + 1, l) >= o ? 8u : 0u) | (ORD(k - 1, l) >= o ? 16u : 0u);
                     if (!NS) {
                         const float ry = (float)(i - k), rx = (float)(j - l);
                         const float vl = rx * rx + ry * ry;
@@ -602,17 +610,27 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                             term[9] = wgt;
                         }
                     }
+                    // the terms of the taps inside the circle, compacted in tap order: row = rank; rows up to the next multiple of
+                    // eight are zero (the ordered sum below takes whole batches of eight)
+                    const int nc = __builtin_popcountll(__builtin_amdgcn_ballot_w64((tp.bits & 32u) != 0));
+                    const int nrows = (nc + 7) & ~7;
+                    if (tp.bits & 32u) {
+                        const int row = (int)((tp.bits >> 8) & 63u);
 #pragma unroll
-                    for (int q = 0; q < kAcc; q++) s_terms[wave][lane][q] = term[q];
+                        for (int q = 0; q < kAcc; q++) s_terms[wave][row][q] = term[q];
+                    }
+                    if (lane >= nc && lane < nrows) {
+#pragma unroll
+                        for (int q = 0; q < kAcc; q++) s_terms[wave][lane][q] = 0.f;
+                    }
                     wave_lds_sync();
                     // phase 2: lane q adds this chunk's terms of accumulator q in tap (row-major) order
                     if (lane < kAcc) {
                         const bool minus = !NS && lane >= 3 && lane < 9;  // Telea: Jx, Jy are accumulated with -=
-                        const int lim = min(64, ntap - t0);
                         // The ordered adds are the chain; the LDS reads are not: batch b+1 is requested before batch b is added up.
-                        // Rows lim .. 63 hold zeros (lanes without a tap store zero terms): whole batches, no per-row conditions.
+                        // Rows nc .. nrows-1 hold zeros: whole batches, no per-row conditions.
                         constexpr int kB = 8;
-                        const int nb = (lim + kB - 1) / kB;
+                        const int nb = nrows / kB;
                         float v0[kB], v1[kB];
 #pragma unroll
                         for (int u = 0; u < kB; u++) v0[u] = s_terms[wave][u][lane];
