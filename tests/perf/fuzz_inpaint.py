@@ -27,7 +27,7 @@ for case in range(40):
     else:
         yy, xx = np.mgrid[0:h, 0:w]
         mask[(xx - w / 2) ** 2 + (yy - h / 2) ** 2 < (min(w, h) / 3) ** 2] = 255
-    radius = float(rng.choice([1, 2, 3, 3, 4, 5, 7]))
+    radius = float(rng.choice([1, 2, 3, 3, 4, 5, 6, 7, 9, 12, 14]))  # 6 .. 12: the large-window fill; 14: the level schedule
     method = int(rng.integers(0, 2))
     ref, t_ref, f_ref, o_ref = oracle.inpaint(rgb, mask, radius, method, maps=True)
     got, t, order = ctx.inpaint(torch.from_numpy(rgb).cuda(), torch.from_numpy(mask).cuda(), radius, method, maps=True)
