@@ -101,6 +101,7 @@ struct ofxcv_ctx {
     DevBuf ip_img;   // device copies of the host images (render_host)
     DevBuf ip_work;  // 4-byte-per-pixel working images of the colour fill
     DevBuf ip_flag;  // error flag of the dataflow fill (a poll gave up)
+    DevBuf ip_trace; // OFXCV_FILL_TRACE: phase stamps of the fill (measurement hook)
     DevBuf ip_tmap, ip_omap;  // persistent padded distance / order maps (defaults everywhere between calls)
     int ip_map_w = 0, ip_map_h = 0;
     void *ip_host_state = nullptr;           // host state of the front march (inpaint.hip: March)

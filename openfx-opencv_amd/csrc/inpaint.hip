@@ -327,6 +327,7 @@ struct FillArgs {
     const int *lvl_pix, *lvl_ord, *lvl_off, *comp_off;   // level schedule (large radius)
     const int *cmp_pix, *cmp_ord, *cmp_off;              // dataflow schedule: the pixels of each component in fill order
     int *err;                                            // dataflow: set when a poll gave up (see the poll loop)
+    unsigned long long *trace;                           // measurement hook (OFXCV_FILL_TRACE): 8 shader-clock stamps per fill-order pixel, or null
     int spin_limit;                                      // polls a wavefront spends on one awaited colour before it gives up
     int k0;                                              // tile schedule: the order numbers of this launch's pixels are k0+1 .. k0+kFillSlots at most
     int ts;                                              // tile schedule: tile size (padded pixels); 0 = component schedule (all polls through the L2)
@@ -413,6 +414,12 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                 {
                 const int i = p / ec, j = p - i * ec;
                 const int wi0 = i - range - 1, wj0 = j - range - 1;  // padded coordinates of the staged window's corner
+                // measurement hook: lane 0 stamps the phases of this pixel (0 start, 1 maps staged + weights, 2 awaited colours there,
+                // 3 colours staged, 4 terms in LDS, 5 sums done, 6 pixel stored; 7 = the largest order number it waited for)
+                auto stamp = [&](int kx) __attribute__((always_inline)) {
+                    if (a.trace && lane == 0) a.trace[(size_t)(o - 1) * 8 + kx] = __builtin_amdgcn_s_memtime();
+                };
+                stamp(0);
                 auto ORD = [&](int r, int c) -> int { return LDSWIN ? s_word[wave][(r - wi0) * ws + (c - wj0)] : a.ord[r * ec + c]; };
                 auto TT = [&](int r, int c) -> float { return LDSWIN ? s_wt[wave][(r - wi0) * ws + (c - wj0)] : a.t[r * ec + c]; };
                 // What a window tap (one per lane and chunk of 64) needs of the maps alone: is it a tap at all, which neighbours
@@ -514,6 +521,15 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     }
                     wave_lds_sync();
                     pre_taps();
+                    if (a.trace) {  // the latest pixel this one waits for
+                        int wmax = 0;
+#pragma unroll
+                        for (int u = 0; u < kEl; u++)
+                            if (wait_slot[u] >= 0 || wait_on[u]) wmax = max(wmax, q[u]);
+                        for (int sh = 32; sh >= 1; sh >>= 1) wmax = max(wmax, __shfl_xor(wmax, sh));
+                        if (lane == 0) a.trace[(size_t)(o - 1) * 8 + 7] = (unsigned long long)wmax;
+                    }
+                    stamp(1);
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         int spins = 0;
@@ -546,18 +562,15 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                             }
                         }
                     }
+                    stamp(2);
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         const int e = lane + 64 * u;
                         if (e < ws * ws) s_wrgb[wave][e] = rgb[u];
                     }
                     wave_lds_sync();
+                    stamp(3);
                 }
-                // image pixel (ir,ic) [image coordinates], channel ch
-                auto IMG = [&](int ir, int ic, int ch) -> float {
-                    uint32_t v = LDSWIN ? s_wrgb[wave][(ir + 1 - wi0) * ws + (ic + 1 - wj0)] : resolve(ir + 1, ic + 1, a.ord[(ir + 1) * ec + ic + 1], o);
-                    return (float)((v >> (8 * ch)) & 255u);
-                };
                 if (!LDSWIN) centre();
                 // lanes 0..9: the sequential accumulator they own (s starts at 1e-20)
                 float run = (NS ? (lane >= 3 && lane < 6) : lane == kAcc - 1) ? 1.0e-20f : 0.f;
@@ -574,46 +587,52 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                         const float ry = (float)(i - k), rx = (float)(j - l);
                         const float vl = rx * rx + ry * ry;
                         const bool r_in = tp.bits & 2u, l_in = tp.bits & 4u, d_in = tp.bits & 8u, u_in = tp.bits & 16u;
+                        // The tap's pixel and its six neighbours, one dword each (three channels per load), loaded whatever the flags say --
+                        // they all lie inside the staged window -- and the gradient forms chosen by selects: the lanes of a wavefront
+                        // have different flags, and as branches the four forms per direction ran one after the other (the phase trace
+                        // had this stretch at 2 500 of the 4 300 cycles a pixel needs after its colours have arrived).
+                        auto PIX = [&](int ir, int ic) -> uint32_t {
+                            return LDSWIN ? s_wrgb[wave][(ir + 1 - wi0) * ws + (ic + 1 - wj0)] : resolve(ir + 1, ic + 1, a.ord[(ir + 1) * ec + ic + 1], o);
+                        };
+                        const uint32_t p_c = PIX(km, lm), p_xl = PIX(km, lm - 1), p_xr0 = PIX(km, lp), p_xr1 = PIX(km, lp + 1);
+                        const uint32_t p_yu = PIX(km - 1, lm), p_yd0 = PIX(kp, lm), p_yd1 = PIX(kp + 1, lm);
                         if (NS) {
                             const float dst = 1 / (vl * vl + 1);
 #pragma unroll
                             for (int ch = 0; ch < 3; ch++) {
-                                auto I = [&](int r, int c) { return (int)IMG(r, c, ch); };
-                                float gx, gy;
-                                if (!d_in) gx = !u_in ? (float)(abs(I(kp + 1, lm) - I(kp, lm)) + abs(I(kp, lm) - I(km - 1, lm)))
-                                                      : (float)(abs(I(kp + 1, lm) - I(kp, lm))) * 2.0f;
-                                else gx = !u_in ? (float)(abs(I(kp, lm) - I(km - 1, lm))) * 2.0f : 0.f;
-                                if (!r_in) gy = !l_in ? (float)(abs(I(km, lp + 1) - I(km, lm)) + abs(I(km, lm) - I(km, lm - 1)))
-                                                      : (float)(abs(I(km, lp + 1) - I(km, lm))) * 2.0f;
-                                else gy = !l_in ? (float)(abs(I(km, lm) - I(km, lm - 1))) * 2.0f : 0.f;
+                                auto CI = [&](uint32_t v) { return (int)((v >> (8 * ch)) & 255u); };
+                                const int c = CI(p_c), xl = CI(p_xl), xr1 = CI(p_xr1), yu = CI(p_yu), yd0 = CI(p_yd0), yd1 = CI(p_yd1);
+                                float gx = !d_in ? (!u_in ? (float)(abs(yd1 - yd0) + abs(yd0 - yu)) : (float)(abs(yd1 - yd0)) * 2.0f)
+                                                 : (!u_in ? (float)(abs(yd0 - yu)) * 2.0f : 0.f);
+                                const float gy = !r_in ? (!l_in ? (float)(abs(xr1 - c) + abs(c - xl)) : (float)(abs(xr1 - c)) * 2.0f)
+                                                       : (!l_in ? (float)(abs(c - xl)) * 2.0f : 0.f);
                                 gx = -gx;
                                 float dir = rx * gx + ry * gy;
                                 if (fabs(dir) <= 0.01) dir = 0.000001f;
                                 else dir = (float)fabs((rx * gx + ry * gy) / sqrt((double)(vl * (gx * gx + gy * gy))));
                                 const float wgt = dst * dir;
-                                term[ch] = wgt * IMG(km, lm, ch);
+                                term[ch] = wgt * (float)c;
                                 term[3 + ch] = wgt;
                             }
                         } else {
                             const float wgt = tp.wgt;
 #pragma unroll
                             for (int ch = 0; ch < 3; ch++) {
-                                float gIx, gIy;
-                                if (!r_in) gIx = !l_in ? (IMG(km, lp + 1, ch) - IMG(km, lm - 1, ch)) * 2.0f : (IMG(km, lp + 1, ch) - IMG(km, lm, ch));
-                                else gIx = !l_in ? (IMG(km, lp, ch) - IMG(km, lm - 1, ch)) : 0.f;
-                                if (!d_in) gIy = !u_in ? (IMG(kp + 1, lm, ch) - IMG(km - 1, lm, ch)) * 2.0f : (IMG(kp + 1, lm, ch) - IMG(km, lm, ch));
-                                else gIy = !u_in ? (IMG(kp, lm, ch) - IMG(km - 1, lm, ch)) : 0.f;
-                                term[ch] = wgt * IMG(km, lm, ch);
-                                term[3 + ch] = wgt * (gIx * rx);
-                                term[6 + ch] = wgt * (gIy * ry);
+                                auto CF = [&](uint32_t v) { return (float)((v >> (8 * ch)) & 255u); };
+                                const float c = CF(p_c), xl = CF(p_xl), xr0 = CF(p_xr0), xr1 = CF(p_xr1), yu = CF(p_yu), yd0 = CF(p_yd0), yd1 = CF(p_yd1);
+                                const float gIx = !r_in ? (!l_in ? (xr1 - xl) * 2.0f : (xr1 - c)) : (!l_in ? (xr0 - xl) : 0.f);
+                                const float gIy = !d_in ? (!u_in ? (yd1 - yu) * 2.0f : (yd1 - c)) : (!u_in ? (yd0 - yu) : 0.f);
+                                term[ch] = wgt * c;
+                                term[3 + ch] = -(wgt * (gIx * rx));  // Jx, Jy are accumulated with -=: run - t is run + (-t) exactly, and the
+                                term[6 + ch] = -(wgt * (gIy * ry));  // sign is applied here, by the tap's lane, not inside the ordered sum
                             }
                             term[9] = wgt;
                         }
                     }
                     // the terms of the taps inside the circle, compacted in tap order: row = rank; rows up to the next multiple of
-                    // eight are zero (the ordered sum below takes whole batches of eight)
+                    // sixteen are zero (the ordered sum below takes whole batches of sixteen)
                     const int nc = __builtin_popcountll(__builtin_amdgcn_ballot_w64((tp.bits & 32u) != 0));
-                    const int nrows = (nc + 7) & ~7;
+                    const int nrows = (nc + 15) & ~15;
                     if (tp.bits & 32u) {
                         const int row = (int)((tp.bits >> 8) & 63u);
 #pragma unroll
@@ -624,12 +643,12 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                         for (int q = 0; q < kAcc; q++) s_terms[wave][lane][q] = 0.f;
                     }
                     wave_lds_sync();
+                    stamp(4);
                     // phase 2: lane q adds this chunk's terms of accumulator q in tap (row-major) order
                     if (lane < kAcc) {
-                        const bool minus = !NS && lane >= 3 && lane < 9;  // Telea: Jx, Jy are accumulated with -=
                         // The ordered adds are the chain; the LDS reads are not: batch b+1 is requested before batch b is added up.
                         // Rows nc .. nrows-1 hold zeros: whole batches, no per-row conditions.
-                        constexpr int kB = 8;
+                        constexpr int kB = 16;
                         const int nb = nrows / kB;
                         float v0[kB], v1[kB];
 #pragma unroll
@@ -639,11 +658,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
 #pragma unroll
                                 for (int u = 0; u < kB; u++) v1[u] = s_terms[wave][(b + 1) * kB + u][lane];
                             }
-                            // run - v is run + (-v) exactly: the sign is applied to the term (off the chain), the chain is one add per tap
 #pragma unroll
-                            for (int u = 0; u < kB; u++) v0[u] = minus ? -v0[u] : v0[u];
-#pragma unroll
-                            for (int u = 0; u < kB; u++) run = run + v0[u];
+                            for (int u = 0; u < kB; u++) run = run + v0[u];  // one dependent add per tap: the chain
 #pragma unroll
                             for (int u = 0; u < kB; u++) v0[u] = v1[u];
                         }
@@ -665,6 +681,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     return __builtin_bit_cast(float, d == 3 ? __builtin_amdgcn_update_dpp(0, iv, 0x103, 0xf, 0xf, true)
                                                             : __builtin_amdgcn_update_dpp(0, iv, 0x106, 0xf, 0xf, true));
                 };
+                stamp(5);
                 uint32_t byte = 0;
                 if (NS) {
                     const float sw = from_lane_plus(run, 3);
@@ -689,6 +706,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     if (ts) __hip_atomic_store(&s_slot[o - a.k0 - 1], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // first: it is on the chain
                     __hip_atomic_store(a.out + at, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                stamp(6);
                 }
             }
     };
@@ -997,6 +1015,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     fa.h = h;
     fa.range = range;
     fa.err = nullptr;
+    fa.trace = nullptr;
     fa.spin_limit = 0;
     fa.k0 = 0;
     fa.ts = 0;
@@ -1033,6 +1052,13 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         rc = ofxcv_reserve(ctx, ctx->ip_flag, 256);
         if (rc) return rc;
         fa.err = (int *)ctx->ip_flag.ptr;
+        static const char *trace_file = getenv("OFXCV_FILL_TRACE");  // measurement hook: phase stamps of every pixel of the fill into this file
+        if (trace_file) {
+            rc = ofxcv_reserve(ctx, ctx->ip_trace, (size_t)n_holes * 64);
+            if (rc) return rc;
+            OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->ip_trace.ptr, 0, (size_t)n_holes * 64, s));
+            fa.trace = (unsigned long long *)ctx->ip_trace.ptr;
+        }
         fa.spin_limit = ctx->ip_spin_limit >= 0 ? ctx->ip_spin_limit : kSpinLimit;
         OFXCV_HIP_CHECK(ctx, hipMemsetAsync(fa.err, 0, sizeof(int), s));
         std::vector<int> &sp = m.cmp_pix, &so = m.cmp_ord, &sw = m.cmp_wg;
@@ -1108,6 +1134,15 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
         timed_out = flag != 0;
         if (timed_out) ctx->ip_fallbacks++;
+        if (fa.trace) {
+            std::vector<unsigned long long> tr((size_t)n_holes * 8);
+            OFXCV_HIP_CHECK(ctx, hipMemcpy(tr.data(), fa.trace, tr.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(trace_file, "wb")) {
+                fwrite(tr.data(), 8, tr.size(), f);
+                fclose(f);
+            }
+            fa.trace = nullptr;
+        }
     } else {
         const double ta = trace ? now() : 0;
         m.pix.reserve(n_holes);
