@@ -389,6 +389,16 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
     // wavefronts of this workgroup that need it poll the slot -- an LDS round trip where the store -> L2 -> poll path costs
     // microseconds per link of the dependency chain.  Only pixels of this workgroup's tile are ever looked up here.
     __shared__ uint32_t s_slot[LDSWIN ? kFillSlots : 1];
+    // Telea's distance factor of a tap, 1 / (|r|^2 |r|), only depends on the integer |r|^2 <= range^2: computed once per workgroup by
+    // the same double-precision operations instead of a double square root and a double division per tap and pixel
+    __shared__ float s_dst[LDSWIN && !NS ? RMAX * RMAX + 1 : 1];
+    if (LDSWIN && !NS) {
+        for (int e = threadIdx.x; e <= RMAX * RMAX; e += 64 * NWAVES) {
+            const float vl = (float)e;
+            s_dst[e] = e ? (float)(1. / (vl * sqrt((double)vl))) : 0.f;
+        }
+        __syncthreads();
+    }
     const int ts = LDSWIN ? a.ts : 0;
     if (ts) {
         for (int e = threadIdx.x; e < kFillSlots; e += 64 * NWAVES) s_slot[e] = 0;
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     if (!NS) {
                         const float ry = (float)(i - k), rx = (float)(j - l);
                         const float vl = rx * rx + ry * ry;
-                        const float dst = (float)(1. / (vl * sqrt((double)vl)));
+                        const float dst = LDSWIN ? s_dst[(int)vl] : (float)(1. / (vl * sqrt((double)vl)));
                         const float lev = (float)(1. / (1 + fabsf(TT(k, l) - Tij)));
                         float dir = rx * gTx + ry * gTy;
                         if (fabs(dir) <= 0.01) dir = 0.000001f;
