@@ -418,6 +418,10 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
         return (q != 0 && q < o) ? cur : orig;
     };
 
+    // n / d for the indices of a window (n < 2^16, d <= 255): (n + 0.5) / d is at least 0.5 / d away from an integer, far more than
+    // the rounding of a float product -- an integer division by a run-time divisor is ~25 vector instructions, and a pixel had ten of them
+    const float inv_ws = 1.0f / (float)ws, inv_side = 1.0f / (float)side;
+    auto div_small = [](int n, float inv_d) __attribute__((always_inline)) { return (int)(((float)n + 0.5f) * inv_d); };
     // one pixel (padded index p, fill-order number o) by one wavefront
     auto fill_pixel = [&](const int p, const int o) {
             {
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     TapSetup ts_;
                     ts_.bits = 0;
                     ts_.wgt = 0.f;
-                    const int k = i - range + tap / side, l = j - range + tap % side;
+                    const int tq = div_small(tap, inv_side);
+                    const int k = i - range + tq, l = j - range + (tap - tq * side);
                     const bool circ = tap < ntap && (l - j) * (l - j) + (k - i) * (k - i) <= range * range;
                     const unsigned long long cm = __builtin_amdgcn_ballot_w64(circ);
                     const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     uint32_t rgb[kEl];
                     const uint32_t *wait_on[kEl];  // entries the sequential algorithm fills before pixel o: polled through the L2 ...
                     int wait_slot[kEl];            // ... or, inside this workgroup's tile, in their LDS slot
-                    const int ti = ts ? i / ts : 0, tj = ts ? j / ts : 0;
+                    const int ti0 = ts ? (i / ts) * ts : 0, tj0 = ts ? (j / ts) * ts : 0;  // this pixel's tile (= this workgroup's): [ti0, ti0 + ts) x [tj0, tj0 + ts)
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         const int e = lane + 64 * u;
@@ -501,7 +506,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                         wait_on[u] = nullptr;
                         wait_slot[u] = -1;
                         if (e < ws * ws) {
-                            const int r = wi0 + e / ws, c = wj0 + e % ws;
+                            const int eq = div_small(e, inv_ws);
+                            const int r = wi0 + eq, c = wj0 + (e - eq * ws);
                             if (r >= 0 && c >= 0 && r < er && c < ec) {
                                 q[u] = a.ord[r * ec + c];
                                 tv[u] = a.t[r * ec + c];
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                                     const size_t at = (size_t)(r - 1) * a.w + (c - 1);
                                     if (q[u] != 0 && q[u] < o) {
                                         if (ts && q[u] <= a.k0) rgb[u] = a.out[at];  // filled by an earlier launch: final in memory
-                                        else if (ts && r / ts == ti && c / ts == tj) wait_slot[u] = q[u] - a.k0 - 1;  // by this workgroup: its slot
+                                        else if (ts && (unsigned)(r - ti0) < (unsigned)ts && (unsigned)(c - tj0) < (unsigned)ts) wait_slot[u] = q[u] - a.k0 - 1;  // by this workgroup: its slot
                                         else wait_on[u] = a.out + at;               // by another workgroup of this launch
                                     } else {
                                         rgb[u] = a.src[at];
@@ -591,7 +597,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     for (int q = 0; q < kAcc; q++) term[q] = 0.f;
                     if (tp.bits & 1u) {
                         const int tap = t0 + lane;
-                        const int k = i - range + tap / side, l = j - range + tap % side;
+                        const int tq = div_small(tap, inv_side);
+                        const int k = i - range + tq, l = j - range + (tap - tq * side);
                         const int km = k - 1 + (k == 1), kp = k - 1 - (k == er - 2);
                         const int lm = l - 1 + (l == 1), lp = l - 1 - (l == ec - 2);
                         const float ry = (float)(i - k), rx = (float)(j - l);
