@@ -579,6 +579,9 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                         }
                     }
                     stamp(2);
+                    // From here to the pixel's store a wavefront is on the pixel -> pixel chain; the other wavefronts of its SIMD are mostly
+                    // staging maps and computing weights for pixels whose turn has not come: the chain goes first in the issue arbitration.
+                    __builtin_amdgcn_s_setprio(3);
 #pragma unroll
                     for (int u = 0; u < kEl; u++) {
                         const int e = lane + 64 * u;
@@ -723,6 +726,7 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
                     if (ts) __hip_atomic_store(&s_slot[o - a.k0 - 1], px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // first: it is on the chain
                     __hip_atomic_store(a.out + at, px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (LDSWIN) __builtin_amdgcn_s_setprio(0);
                 stamp(6);
                 }
             }
