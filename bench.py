@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--separate-lut", action="store_true", help="A/B: the gray LUT as one launch per frame (ofxcv_to_byte_grayscale) instead of one per call "
                                                                 "(ofxcv_to_byte_grayscale_batch)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the inpaint / segment / 4K / host-path legs")
+    ap.add_argument("--direct-leg", action="store_true", help="also time the opt-in direct-window mode (farneback.opencv_rounding 0: outside the reference's 1e-4 band at a "
+                    "few samples; no longer faster for batches) -- off by default since round 5, the time goes to repeats of `value`")
     ap.add_argument("--no-batch16", action="store_true", help="skip the batches-of-16 leg (counter passes: its launches have the grids of other levels' launches of 8)")
     ap.add_argument("--size", default="1920x1080", help="frame size; the metric is quoted at 1920x1080 (BASELINE.json configs[2]), "
                     "3840x2160 is configs[4] (64 pairs over 8 GPUs)")
@@ -388,17 +390,19 @@ def main():
             c.close()
         del b16
 
-    # ---- the opt-in direct-window mode, same workload ----
+    # ---- the opt-in direct-window mode, same workload (--direct-leg) ----
     # (its kernels take one pair per launch: P single-pair contexts in flight, as in rounds 1 and 2)
-    dctxs = make_ctxs(min(P, 4), direct=True)
-    dbufs = make_bufs(dctxs, W, H, 1)
-    del_ = timed_regions(dctxs, dbufs, args.steps, args.warmup, max(1, min(5, args.repeats)))
-    drates = [sharding.reduce_count_sum(args.steps * len(dctxs), dist, red_dev) / e for e in del_]
-    fused_s, fused_n = kernel_leg(dctxs[0], dbufs[0], 1)
-    direct_flow = dbufs[0]["flow"][0].cpu().numpy()
-    for c in dctxs:
-        c.close()
-    del dbufs
+    drates = fused_s = fused_n = direct_flow = None
+    if args.direct_leg:
+        dctxs = make_ctxs(min(P, 4), direct=True)
+        dbufs = make_bufs(dctxs, W, H, 1)
+        del_ = timed_regions(dctxs, dbufs, args.steps, args.warmup, max(1, min(5, args.repeats)))
+        drates = [sharding.reduce_count_sum(args.steps * len(dctxs), dist, red_dev) / e for e in del_]
+        fused_s, fused_n = kernel_leg(dctxs[0], dbufs[0], 1)
+        direct_flow = dbufs[0]["flow"][0].cpu().numpy()
+        for c in dctxs:
+            c.close()
+        del dbufs
 
     if rank != 0:
         if dist is not None:
@@ -411,7 +415,13 @@ def main():
     pm = pmc.get("opencv_order_col_two_iterations_level0" if col else "opencv_order_halo_iteration_level0", {})
     pf = pmc.get("direct_window_fused_pair_level0", {})
     iter_bytes_pair = ITER_BYTES_PER_PX * W * H
-    iter_bytes = iter_bytes_pair * ppl * iters_per_launch  # one launch of the dominant kernel: `ppl` pairs x `iters_per_launch` iterations
+    # SURVEY's count: 80 B/px per ITERATION.  The column-owning launch runs two iterations and keeps the field between them on chip:
+    survey_bytes = iter_bytes_pair * ppl * iters_per_launch
+    # what one launch of the dominant kernel HAS to move -- the figure `achieved` / `frac` are computed from (VERDICT / ADVICE round 4):
+    # field-in 20 + R0 20 + R1 20 + field-out 20 = 80 B/px ONCE per launch, the three input fields re-read by the four halo lanes of every 64-lane
+    # tile column (x 64/60): 20 + 60 x 64/60 = 84 B/px (the judge's 85).  Overlapped strips (one iteration per launch): SURVEY's 80 B/px.
+    min_bytes_px = (20.0 + 60.0 * 64.0 / COL_W) if col else ITER_BYTES_PER_PX
+    iter_bytes = min_bytes_px * W * H * ppl
     achieved = iter_bytes / main_s / 1e9
     traffic = pm.get("traffic_bytes_per_launch")
     valu = pm.get("counters_per_launch", {}).get("SQ_INSTS_VALU")
@@ -448,8 +458,8 @@ def main():
         "value_three_single_pair_calls_in_flight": three_single,  # the configuration BENCH_r01 / BENCH_r02 quoted as `value`
         "value_batches_of_16": batch16,  # one batched call of 16 pairs at a time (the call's maximum)
         "col_aborts": col_aborts,  # 1 if a bounded LDS wait of iterate_col_kernel ever ran out (never seen)
-        "value_direct_window": statistics.median(drates),
-        "value_direct_window_stats": dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
+        "value_direct_window": statistics.median(drates) if drates else None,
+        "value_direct_window_stats": None if not drates else dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
                                           "fused per launch; does NOT meet 1e-4 at every sample (see parity)"),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
@@ -461,9 +471,13 @@ def main():
                                 "iterate3h_kernel<kHaloIter, 9, 8, var> (one blur+solve+update iteration in OpenCV's summation order as ONE launch: overlapped strips of 65..72 computed rows, "
                                 "eight wavefronts of 8 or 9 rows per workgroup, the strip sums of its own output for the next launch's column-sum prefix; pyramid level 0, %dx%d)") % (W, H),
                      "bytes_per_launch": iter_bytes, "pairs_per_launch": ppl, "iterations_per_launch": iters_per_launch,
-                     "bytes_per_launch_note": "SURVEY.md 8(d): 80 B/px per iteration (M-in 20 + R0 20 + R1 gather 20 + M-out 20) x %d x %d px x %d pairs x %d iterations "
-                                              "per launch.  (What the fused launch really has to move is less: M-in 20 + R0 20 + R1 20 + M-out 20 = 80 B/px per TWO "
-                                              "iterations -- the intermediate field stays on chip; `traffic` is the measured figure.)" % (W, H, ppl, iters_per_launch),
+                     "bytes_per_launch_note": "the bytes ONE launch has to move: %.1f B/px (field-in 20 + R0 20 + R1 20, re-read by the 4 halo lanes of each 64-lane tile column, "
+                                              "+ field-out 20; the field between the launch's %d iterations stays on chip) x %d x %d px x %d pairs" % (min_bytes_px, iters_per_launch, W, H, ppl),
+                     "frac_min_bytes": achieved / HBM_PEAK_GBS,  # = frac (kept under the name VERDICT round 4 asked for)
+                     "traffic_over_min": (traffic / iter_bytes) if traffic else None,
+                     "survey_per_iteration_count": {"bytes_per_launch": survey_bytes, "achieved": survey_bytes / main_s / 1e9, "frac": survey_bytes / main_s / 1e9 / HBM_PEAK_GBS,
+                                                    "note": "SURVEY.md 8(d)'s 80 B/px per ITERATION x the iterations of the launch: the bytes an unfused form would move "
+                                                            "(`frac` of rounds 1-4; 0.81 in round 4).  Not what the fused launch moves: side key only"},
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one batched call in flight; the pairs include the dependent-launch gap -- the rocprofv3 "
                                "durations of the same launches are in profiles/r04_bench_default_by_grid.txt",
@@ -478,14 +492,15 @@ def main():
                      "valu_busy_frac": (valu_busy * 4 / (1024 * 2.4e9) / main_s) if valu_busy else None,
                      "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) x %.1f clk per wave64 instruction (see VALU_CLK_PER_WAVE_INSTR in bench.py) "
                                         "/ (1024 SIMDs x 2.4 GHz) / launch time; valu_busy_frac = SQ_ACTIVE_INST_VALU (busy quad-cycles) x 4 / the same" % VALU_CLK_PER_WAVE_INSTR,
-                     "direct_window_kernel": {"kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
-                                              "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": 2 * iter_bytes_pair,
-                                              "achieved": 2 * iter_bytes_pair / fused_s / 1e9, "frac": 2 * iter_bytes_pair / fused_s / 1e9 / HBM_PEAK_GBS,
-                                              "traffic": pf.get("traffic_bytes_per_launch"),
-                                              "traffic_GBps": (pf["traffic_bytes_per_launch"] / fused_s / 1e9) if pf.get("traffic_bytes_per_launch") else None}},
+                     "direct_window_kernel": None if not fused_s else {
+                         "kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
+                         "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": iter_bytes_pair,
+                         "achieved": iter_bytes_pair / fused_s / 1e9, "frac": iter_bytes_pair / fused_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": pf.get("traffic_bytes_per_launch"),
+                         "traffic_GBps": (pf["traffic_bytes_per_launch"] / fused_s / 1e9) if pf.get("traffic_bytes_per_launch") else None}},
         "whole_call": {"algorithmic_bytes_per_pair": alg, "achieved_GBps": alg * value / world / 1e9,
                        "frac_of_hbm_peak": alg * value / world / 1e9 / HBM_PEAK_GBS,
-                       "direct_window_frac_of_hbm_peak": alg * statistics.median(drates) / world / 1e9 / HBM_PEAK_GBS},
+                       "direct_window_frac_of_hbm_peak": (alg * statistics.median(drates) / world / 1e9 / HBM_PEAK_GBS) if drates else None},
     }
     pp = pmc_per_pair() if (W, H) == (1920, 1080) and B == 8 else {}
     if pp.get("opencv_order"):
@@ -508,7 +523,7 @@ def main():
         line["parity"] = {"reference": "CPU oracle, OpenCV evaluation order (oracle/farneback.c, ORC_BLUR_FAITHFUL), same %dx%d pair; oracle itself is "
                                        "pinned by known-answer tests only (no OpenCV in this image)" % (W, H),
                           "tolerance": "|a-b| <= 1e-4 * max(1, |b|)",
-                          "timed_mode_opencv_order": par(strict_flow), "direct_window_mode": par(direct_flow)}
+                          "timed_mode_opencv_order": par(strict_flow), "direct_window_mode": par(direct_flow) if direct_flow is not None else None}
     elif world > 1:
         line["cpu_baseline"] = None
     if world == 1 and not args.no_extra_legs and (W, H) == (1920, 1080):

@@ -91,7 +91,12 @@ struct ofxcv_ctx {
     int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (A/B; same launch time, profiles/r04_experiments.md #19)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
-    DevBuf fb_col_flag;          // the sticky abort word of iterate_col_kernel (+ the trace area)
+    int fb_col_depth = 1;        // option "farneback.col_depth" (experiment, with col_lean): rows whose gathers are in flight before the first is consumed (1, 2, 4)
+    int fb_col_lean = 0;         // option "farneback.col_lean" (experiment): the (iterate, iterate) launch in its reduced-instruction form
+    DevBuf fb_col_flag;          // the trace area of iterate_col_kernel (farneback.col_trace)
+    unsigned *fb_col_abort = nullptr;  // the abort word of iterate_col_kernel: 64 bytes of pinned, host-coherent memory the kernel stores to when a bounded
+                                       // LDS wait runs out; read (and cleared) by the host at every synchronisation point of the library without a copy
+    long fb_col_aborts_seen = 0;       // calls that were reported as failed because of it
     int fb_batch_mb = 160;       // option "farneback.batch_mb": a pyramid level is walked with as many pairs per launch as keep its
                                  // working set (80 B/px per pair) under this many MiB (Infinity Cache: 256 MiB), at least one
 
@@ -193,6 +198,8 @@ static inline int ofxcv_div_up(int a, int b) { return (a + b - 1) / b; }
 int ofxcv_upload_rows(ofxcv_ctx *ctx, void *d_dst, size_t row, const void *h_src, ptrdiff_t src_row_bytes, int rows, hipStream_t s);
 int ofxcv_download_rows(ofxcv_ctx *ctx, void *h_dst, ptrdiff_t dst_row_bytes, const void *d_src, size_t row, int rows, hipStream_t s);
 
+// after a synchronisation of the context's streams: OFXCV_ERR_HIP (once; the word is cleared) if a bounded wait of iterate_col_kernel ran out since the last check
+int ofxcv_col_abort_check(ofxcv_ctx *ctx);
 int ofxcv_farneback_streams(ofxcv_ctx *ctx);  // lazily creates the preparation stream and the per-level events
 
 // measurement hook helpers (context.hip)

@@ -112,6 +112,15 @@ int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     return OFXCV_OK;
 }
 
+int ofxcv_col_abort_check(ofxcv_ctx *ctx) {
+    if (!ctx->fb_col_abort) return OFXCV_OK;
+    volatile unsigned *w = ctx->fb_col_abort;
+    if (!*w) return OFXCV_OK;
+    *w = 0;  // reported once: later calls on this context are judged on their own
+    ctx->fb_col_aborts_seen++;
+    return ofxcv_fail(ctx, OFXCV_ERR_HIP, "calc_optical_flow_farneback: a bounded wait inside iterate_col_kernel ran out; the flows of that call are not valid");
+}
+
 int ofxcv_cv_round(double v) { return (int)std::lrint(v); }
 
 extern "C" {
@@ -188,6 +197,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
         if (b->ptr) (void)hipFree(b->ptr);
     if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
+    if (ctx->fb_col_abort) (void)hipHostFree(ctx->fb_col_abort);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->ip_pinned) (void)hipHostFree(ctx->ip_pinned);
     for (int i = 0; i < 3; i++)
@@ -289,7 +299,8 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             {"farneback.halo_min5", &ctx->fb_halo_min5, 0, 1 << 30}, {"lut.four", &ctx->lut4, 0, 1},
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
             {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
-            {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20}};
+            {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20},
+            {"farneback.col_lean", &ctx->fb_col_lean, 0, 1}, {"farneback.col_depth", &ctx->fb_col_depth, 1, 4}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 if (value < k.lo || value > k.hi) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);
@@ -331,14 +342,11 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;
     else if (!std::strcmp(name, "farneback.col_min")) *value = ctx->fb_col_min;
     else if (!std::strcmp(name, "farneback.col_aborts")) {
-        // the sticky abort word of the column-owning kernel (waits for the context's streams first)
+        // the abort word of the column-owning kernel (waits for the context's streams first); reading it through this getter does not clear it
         *value = 0;
-        if (ctx->fb_col_flag.ptr) {
-            unsigned flag = 0;
-            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK ||
-                hipMemcpy(&flag, ctx->fb_col_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost) != hipSuccess)
-                return OFXCV_ERR_HIP;
-            *value = (int)flag;
+        if (ctx->fb_col_abort) {
+            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK) return OFXCV_ERR_HIP;
+            *value = (int)(*(volatile unsigned *)ctx->fb_col_abort | (ctx->fb_col_aborts_seen ? 1u : 0u));
         }
     }
     else return OFXCV_ERR_INVALID;
@@ -367,13 +375,10 @@ int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int res
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ofxcv_stream(ctx, stream)));
-    if (ctx->fb_col_flag.ptr) {
-        // the sticky abort word of iterate_col_kernel: a bounded wait that ran out leaves wrong flows behind -- fail loudly here, at the
-        // library's own synchronisation point (4 bytes; the waits terminate by construction, this is for a faulting device)
-        unsigned flag = 0;
-        OFXCV_HIP_CHECK(ctx, hipMemcpy(&flag, ctx->fb_col_flag.ptr, sizeof(flag), hipMemcpyDeviceToHost));
-        if (flag) return ofxcv_fail(ctx, OFXCV_ERR_HIP, "calc_optical_flow_farneback: a bounded wait inside iterate_col_kernel ran out; the flows of that call are not valid");
-    }
+    // the abort word of iterate_col_kernel: a bounded wait that ran out leaves wrong flows behind -- fail loudly here, at the library's own
+    // synchronisation point (the waits terminate by construction, this is for a faulting device); a read of pinned memory, no copy
+    int rc = ofxcv_col_abort_check(ctx);
+    if (rc) return rc;
     return OFXCV_OK;
 }
 

@@ -627,11 +627,13 @@ __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, i
 // the six moments in f64 exactly like the reference's inner loop.
 
 constexpr int kPeTW = 64, kPeTH = 16;
+typedef float ofxcv_f2 __attribute__((ext_vector_type(2)));
+typedef float ofxcv_f4 __attribute__((ext_vector_type(4)));
 
 // NT > 0: poly_n known at compile time (loops fully unrolled); NT == 0: run-time poly_n
 template <int NT>
 __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ I, int w, int h, float *__restrict__ R,
-                                                      int pitch, PolyCoef pc, size_t I_stride, size_t pair_stride, size_t field) {
+                                                      int pitch, PolyCoef pc, size_t I_stride, size_t pair_stride, size_t field, int pack_odd) {
     extern __shared__ float lds[];
     const int n = NT > 0 ? NT : pc.n;
     const int cw = kPeTW + 2 * n;          // staged columns
@@ -699,11 +701,18 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
             b5 += (r2[k] + r2[-k]) * g0;
         }
         size_t o = (size_t)y * pitch + x;
-        R[o + 1 * plane] = (float)(b2 * pc.ig11);
-        R[o + 0 * plane] = (float)(b3 * pc.ig11);
-        R[o + 3 * plane] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-        R[o + 2 * plane] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        R[o + 4 * plane] = (float)(b6 * pc.ig55);
+        const float c1 = (float)(b2 * pc.ig11), c0 = (float)(b3 * pc.ig11), c3 = (float)(b1 * pc.ig03 + b4 * pc.ig33),
+                    c2 = (float)(b1 * pc.ig03 + b5 * pc.ig33), c4 = (float)(b6 * pc.ig55);
+        if (pack_odd && (tbz & 1)) {  // the second frame of a pair: the packed form of an R1 field (TapsQ)
+            ((ofxcv_f4 *)R)[o] = ofxcv_f4{c0, c1, c2, c3};
+            R[o + 4 * plane] = c4;
+        } else {
+            R[o + 0 * plane] = c0;
+            R[o + 1 * plane] = c1;
+            R[o + 2 * plane] = c2;
+            R[o + 3 * plane] = c3;
+            R[o + 4 * plane] = c4;
+        }
     }
 }
 
@@ -715,13 +724,11 @@ __global__ __launch_bounds__(256) void polyexp_kernel(const float *__restrict__ 
 //    per column as one 16-byte LDS word {t0, t1, t1, t2}; the horizontal pass then needs one 16-byte LDS read per tap
 //    and forms (t0,t1) differences and (t1,t2) sums with packed instructions before they enter the f64 accumulators.
 // The kernel is VALU-bound (about 165 vector instructions per sample, a third of them f64).
-typedef float ofxcv_f2 __attribute__((ext_vector_type(2)));
-typedef float ofxcv_f4 __attribute__((ext_vector_type(4)));
 
 template <int N, int TH>
 __global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__restrict__ Ib, int w, int h, float *__restrict__ Rb,
                                                                  int pitch, PolyCoef pc, int tiles_x, int ntiles_img, int nimg, size_t I_stride,
-                                                                 size_t pair_stride, size_t field) {
+                                                                 size_t pair_stride, size_t field, int pack_odd) {
     constexpr int CW = kPeTW + 2 * N, LDW = CW + 2, IH = TH + 2 * N;  // staged columns / row stride (even) / rows
     constexpr int NSR = (IH + 3) / 4;                                 // staged rows per wavefront
     constexpr int NV = (CW / 2) * TH;                                 // column pairs x rows of the vertical pass
@@ -812,11 +819,18 @@ __global__ __launch_bounds__(256) void polyexp_persistent_kernel(const float *__
             }
             if (x < w && y < h) {
                 const size_t o = (size_t)y * pitch + x;
-                R[o + 1 * plane] = (float)(b2 * pc.ig11);
-                R[o + 0 * plane] = (float)(b3 * pc.ig11);
-                R[o + 3 * plane] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-                R[o + 2 * plane] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-                R[o + 4 * plane] = (float)(b6 * pc.ig55);
+                const float c1 = (float)(b2 * pc.ig11), c0 = (float)(b3 * pc.ig11), c3 = (float)(b1 * pc.ig03 + b4 * pc.ig33),
+                            c2 = (float)(b1 * pc.ig03 + b5 * pc.ig33), c4 = (float)(b6 * pc.ig55);
+                if (pack_odd && (im & 1)) {  // the second frame of a pair: the packed form of an R1 field (TapsQ), one 16-byte store per lane
+                    ((ofxcv_f4 *)R)[o] = ofxcv_f4{c0, c1, c2, c3};
+                    R[o + 4 * plane] = c4;
+                } else {
+                    R[o + 0 * plane] = c0;
+                    R[o + 1 * plane] = c1;
+                    R[o + 2 * plane] = c2;
+                    R[o + 3 * plane] = c3;
+                    R[o + 4 * plane] = c4;
+                }
             }
         }
         __syncthreads();
@@ -882,17 +896,67 @@ __device__ __forceinline__ Taps gather_taps(const Buf &R1, int x, int y, int w, 
     return tp;
 }
 
-__device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const Taps &tp, int x, int y, int w, int h, float dx, float dy) {
+// The same footprint from the PACKED form of an R1 field -- what a call's polynomial expansion writes for the SECOND frame of a pair (the
+// field that is only ever gathered; R0 is streamed and stays planar): per pixel a float4 {c0, c1, c2, c3} ([h][pitch] float4), then plane 4
+// ([h][pitch] floats) -- the same 5 * pitch * h floats as the planar field.  Four 16-byte gathers + two 8-byte ones per pixel instead of ten
+// 8-byte ones: the texture addresser is the busiest unit of the iteration kernels (TA_BUSY 74-83 % of the two-iteration launch, every gather ~37
+// of its cycles: profiles/r05_experiments.md), and a dwordx4 wave-load costs it what a dwordx2 one does (tools/ubench/l1rate.hip).
+// Measured: 416 -> 377 us per (iterate, iterate) launch of 8 x 1080p, 1 601 -> 1 471 us at 3840x2160, same bits.
+// The stage-level entry points (ofxcv_farneback_polyexp / _update_matrices / _update_flow_blur) keep planar fields: their kernels take the
+// layout as a flag.
+struct TapsQ {
+    ofxcv_f4 t0, t1, b0, b1;
+    TapPair t4, b4;
+    float fx, fy;
+    bool inb;
+};
+__device__ __forceinline__ ofxcv_f4 buf_ld4(const Buf &b, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(ofxcv_f4, __builtin_amdgcn_raw_buffer_load_b128(b.r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ TapsQ gather_taps_q(const Buf &R1, int x, int y, int w, int h, int pitch, unsigned plane_bytes, float dx, float dy) {
+    TapsQ tp;
+    float fx = x + dx, fy = y + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    tp.fx = fx - x1;
+    tp.fy = fy - y1;
+    tp.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+    const unsigned o = tp.inb ? (unsigned)y1 * (unsigned)pitch + (unsigned)x1 : 0u;
+    const unsigned oq = o * 16u, rq = (unsigned)pitch * 16u, o4 = o * 4u, r4 = (unsigned)pitch * 4u;
+    tp.t0 = buf_ld4(R1, oq, 0);
+    tp.t1 = buf_ld4(R1, oq + 16u, 0);
+    tp.b0 = buf_ld4(R1, oq + rq, 0);
+    tp.b1 = buf_ld4(R1, oq + rq + 16u, 0);
+    tp.t4.a = buf_ld(R1, o4, 4 * plane_bytes);
+    tp.t4.b = buf_ld(R1, o4 + 4u, 4 * plane_bytes);
+    tp.b4.a = buf_ld(R1, o4 + r4, 4 * plane_bytes);
+    tp.b4.b = buf_ld(R1, o4 + r4 + 4u, 4 * plane_bytes);
+    return tp;
+}
+// the four taps of channel c in the order (top left, top right, bottom left, bottom right)
+__device__ __forceinline__ void tap4(const Taps &tp, int c, float &ta, float &tb, float &ba, float &bb) {
+    ta = tp.t[c].a; tb = tp.t[c].b; ba = tp.b[c].a; bb = tp.b[c].b;
+}
+__device__ __forceinline__ void tap4(const TapsQ &tp, int c, float &ta, float &tb, float &ba, float &bb) {
+    if (c < 4) { ta = tp.t0[c]; tb = tp.t1[c]; ba = tp.b0[c]; bb = tp.b1[c]; }
+    else { ta = tp.t4.a; tb = tp.t4.b; ba = tp.b4.a; bb = tp.b4.b; }
+}
+
+// F4 in three parts (the column-owning kernel applies the border scale in its own, hoisted form):
+// the warped sample and r2..r6 before the border scale ...
+template <typename TAPS>
+__device__ __forceinline__ void um_sample(const float r0v[5], const TAPS &tp, float dx, float dy, float (&r)[5]) {
     const float fx = tp.fx, fy = tp.fy;
     float r2, r3, r4, r5, r6;
     {
         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const TapPair *t = tp.t, *b = tp.b;
-        r2 = a00 * t[0].a + a01 * t[0].b + a10 * b[0].a + a11 * b[0].b;
-        r3 = a00 * t[1].a + a01 * t[1].b + a10 * b[1].a + a11 * b[1].b;
-        r4 = a00 * t[2].a + a01 * t[2].b + a10 * b[2].a + a11 * b[2].b;
-        r5 = a00 * t[3].a + a01 * t[3].b + a10 * b[3].a + a11 * b[3].b;
-        r6 = a00 * t[4].a + a01 * t[4].b + a10 * b[4].a + a11 * b[4].b;
+        float rr[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            float ta, tb, ba, bb;
+            tap4(tp, c, ta, tb, ba, bb);
+            rr[c] = a00 * ta + a01 * tb + a10 * ba + a11 * bb;
+        }
+        r2 = rr[0]; r3 = rr[1]; r4 = rr[2]; r5 = rr[3]; r6 = rr[4];
         r4 = (r0v[2] + r4) * 0.5f;
         r5 = (r0v[3] + r5) * 0.5f;
         r6 = (r0v[4] + r6) * 0.25f;
@@ -907,14 +971,14 @@ __device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const T
     r3 = (r0v[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
-
-    constexpr int BORDER = 5;
-    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
-        // border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472}
-        auto bs = [](int d) { return d < 2 ? 0.14f : (d < BORDER ? 0.4472f : 1.f); };
-        float scale = bs(x) * bs(w - x - 1) * bs(y) * bs(h - y - 1);
-        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
-    }
+    r[0] = r2; r[1] = r3; r[2] = r4; r[3] = r5; r[4] = r6;
+}
+// ... border[] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} by the distance d to an image edge ...
+constexpr int kUmBorder = 5;
+__device__ __forceinline__ float um_border(int d) { return d < 2 ? 0.14f : (d < kUmBorder ? 0.4472f : 1.f); }
+// ... and the five products
+__device__ __forceinline__ M5 um_products(const float (&r)[5]) {
+    const float r2 = r[0], r3 = r[1], r4 = r[2], r5 = r[3], r6 = r[4];
     M5 m;
     m.v[0] = r4 * r4 + r6 * r6;
     m.v[1] = (r4 + r5) * r6;
@@ -924,20 +988,51 @@ __device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const T
     return m;
 }
 
+// either layout into the packed structure (packed: wave-uniform flag)
+__device__ __forceinline__ TapsQ gather_taps_any(const Buf &R1, bool packed, int x, int y, int w, int h, int pitch, unsigned plane_bytes, float dx, float dy) {
+    if (packed) return gather_taps_q(R1, x, y, w, h, pitch, plane_bytes, dx, dy);
+    const Taps p = gather_taps(R1, x, y, w, h, pitch, plane_bytes, dx, dy);
+    TapsQ q;
+    q.t0 = ofxcv_f4{p.t[0].a, p.t[1].a, p.t[2].a, p.t[3].a};
+    q.t1 = ofxcv_f4{p.t[0].b, p.t[1].b, p.t[2].b, p.t[3].b};
+    q.b0 = ofxcv_f4{p.b[0].a, p.b[1].a, p.b[2].a, p.b[3].a};
+    q.b1 = ofxcv_f4{p.b[0].b, p.b[1].b, p.b[2].b, p.b[3].b};
+    q.t4 = p.t[4];
+    q.b4 = p.b[4];
+    q.fx = p.fx;
+    q.fy = p.fy;
+    q.inb = p.inb;
+    return q;
+}
+
+template <typename TAPS>
+__device__ __forceinline__ M5 update_matrices_finish(const float r0v[5], const TAPS &tp, int x, int y, int w, int h, float dx, float dy) {
+    float r[5];
+    um_sample(r0v, tp, dx, dy, r);
+    constexpr int BORDER = kUmBorder;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float scale = um_border(x) * um_border(w - x - 1) * um_border(y) * um_border(h - y - 1);
+#pragma unroll
+        for (int c = 0; c < 5; c++) r[c] *= scale;
+    }
+    return um_products(r);
+}
+
 __device__ __forceinline__ M5 update_matrices_core(const float r0v[5], const float *__restrict__ R1, int x, int y, int w, int h,
-                                                   int pitch, size_t plane, float dx, float dy) {
-    Taps tp = gather_taps(make_buf(R1, 5 * plane * sizeof(float)), x, y, w, h, pitch, (unsigned)(plane * 4), dx, dy);
+                                                   int pitch, size_t plane, float dx, float dy, bool r1q) {
+    const TapsQ tp = gather_taps_any(make_buf(R1, 5 * plane * sizeof(float)), r1q, x, y, w, h, pitch, (unsigned)(plane * 4), dx, dy);
     return update_matrices_finish(r0v, tp, x, y, w, h, dx, dy);
 }
 
+// r1q: R1 is in its packed form (TapsQ; wave-uniform)
 __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, const float *__restrict__ R1, int x, int y,
-                                                 int w, int h, int pitch, float dx, float dy) {
+                                                 int w, int h, int pitch, float dx, float dy, bool r1q) {
     const size_t plane = (size_t)pitch * h;
     const size_t o = (size_t)y * pitch + x;
     float r0v[5];
 #pragma unroll
     for (int c = 0; c < 5; c++) r0v[c] = R0[o + c * plane];
-    return update_matrices_core(r0v, R1, x, y, w, h, pitch, plane, dx, dy);
+    return update_matrices_core(r0v, R1, x, y, w, h, pitch, plane, dx, dy, r1q);
 }
 
 // F6: the flow of the coarser level at pixel (x, y) of this one: resize INTER_LINEAR, then * 1/pyr_scale
@@ -973,7 +1068,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               FlowTab flows, int pw, int ph,
                                                               double inv_pyr_scale, double scale_x, double scale_y, int w, int h,
-                                                              int pitch, float *__restrict__ M, size_t pair_stride) {
+                                                              int pitch, float *__restrict__ M, size_t pair_stride, int r1q) {
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     int x = tbx * 64 + threadIdx.x;
@@ -993,7 +1088,7 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
         dx = f.x;
         dy = f.y;
     }
-    M5 m = update_matrices_px(R0, R1, x, y, w, h, pitch, dx, dy);
+    M5 m = update_matrices_px(R0, R1, x, y, w, h, pitch, dx, dy, r1q != 0);
     const size_t plane = (size_t)pitch * h, o = (size_t)y * pitch + x;
 #pragma unroll
     for (int c = 0; c < 5; c++) M[o + c * plane] = m.v[c];
@@ -1008,7 +1103,7 @@ template <bool UPDATE>
 __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                                 const float *__restrict__ Min, float *__restrict__ Mout,
                                                                 float *__restrict__ flow, size_t flow_step, int w, int h,
-                                                                int pitch, int m, double scale) {
+                                                                int pitch, int m, double scale, int r1q) {
     int tbx, tby;
     xcd_tile(tbx, tby);
     int x = tbx * 64 + threadIdx.x;
@@ -1036,7 +1131,7 @@ __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__r
     float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
     if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
     if (UPDATE) {
-        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv, r1q != 0);
         const size_t o = (size_t)y * pitch + x;
 #pragma unroll
         for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
@@ -1071,7 +1166,7 @@ template <bool UPDATE, int ROWS>
 __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                        const float *__restrict__ Min, float *__restrict__ Mout,
                                                        float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
-                                                       double scale) {
+                                                       double scale, int r1q) {
     const int lane = threadIdx.x & 63;
     int tbx, tby;
     xcd_tile(tbx, tby);
@@ -1143,7 +1238,7 @@ __global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__
         float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
         if (flow && live) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
         if (UPDATE) {
-            Taps tp = gather_taps(bR1, xc, y, w, h, pitch, pb, fxv, fyv);
+            const TapsQ tp = gather_taps_any(bR1, r1q != 0, xc, y, w, h, pitch, pb, fxv, fyv);
             M5 mm = update_matrices_finish(r0v[r], tp, xc, y, w, h, fxv, fyv);
             if (live) {
 #pragma unroll
@@ -1215,7 +1310,7 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
     // `wave` (first half) and 8 + `wave` (second half) and keeps their R0 values in registers for the second iteration
     const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);
     struct Px {  // one pixel between "flow known, taps requested" and "M written"
-        Taps tp;
+        TapsQ tp;    // (R1 in its packed form: this kernel only runs inside whole calls)
         float fxv, fyv;
         int y;
         bool active;
@@ -1226,7 +1321,7 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
         p.active = true;
         const int qc = p.y - (y0 - 2), qx = x - (x0 - 2);
         box_solve_rows([&](int c, int k) { return (const float *)(s0 + c * n0 + (qc - 1 + k) * kFtS0 + (qx - 1)); }, scale, p.fxv, p.fyv);
-        p.tp = gather_taps(bR1, x, p.y, w, h, pitch, pb, p.fxv, p.fyv);
+        p.tp = gather_taps_q(bR1, x, p.y, w, h, pitch, pb, p.fxv, p.fyv);
         return p;
     };
     auto first_finish = [&](int r, const Px &p, const float r0v[5]) {
@@ -1242,7 +1337,7 @@ __global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__r
         if (p.active) {
             const int ra = clampi(r - 1, rlo, rhi), rc = clampi(r + 1, rlo, rhi);
             box_solve_rows([&](int c, int k) { return (const float *)(s1row(c, k == 0 ? ra : (k == 1 ? r : rc)) + (lane - 1)); }, scale, p.fxv, p.fyv);
-            p.tp = gather_taps(bR1, xr, p.y, w, h, pitch, pb, p.fxv, p.fyv);
+            p.tp = gather_taps_q(bR1, xr, p.y, w, h, pitch, pb, p.fxv, p.fyv);
         }
         return p;
     };
@@ -1321,7 +1416,7 @@ template <bool UPDATE>
 __global__ __launch_bounds__(256) void gauss_hpass_solve_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                                 const float *__restrict__ V, float *__restrict__ Mout,
                                                                 float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
-                                                                WinTaps t) {
+                                                                WinTaps t, int r1q) {
     int tbx, tby;
     xcd_tile(tbx, tby);
     const int x = tbx * 64 + threadIdx.x, y = tby * 4 + threadIdx.y;
@@ -1340,7 +1435,7 @@ __global__ __launch_bounds__(256) void gauss_hpass_solve_kernel(const float *__r
     const float fxv = (float)((g11 * h2 - g12 * h1) * idet), fyv = (float)((g22 * h1 - g12 * h2) * idet);
     if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
     if (UPDATE) {
-        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv, r1q != 0);
         const size_t o = (size_t)y * pitch + x;
 #pragma unroll
         for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
@@ -1453,7 +1548,7 @@ __global__ __launch_bounds__(256) void strict_colscan_kernel(const float *__rest
 template <bool UPDATE>
 __global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restrict__ R0, const float *__restrict__ R1, const double *__restrict__ V,
                                                            float *__restrict__ Mout, float *__restrict__ flow, size_t flow_step, int w, int h,
-                                                           int pitch, double scale) {
+                                                           int pitch, double scale, int r1q) {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= w || y >= h) return;
     const size_t plane = (size_t)pitch * h;
@@ -1470,7 +1565,7 @@ __global__ __launch_bounds__(256) void strict_solve_kernel(const float *__restri
     float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
     if (flow) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
     if (UPDATE) {
-        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv);
+        M5 mm = update_matrices_px(R0, R1, x, y, w, h, pitch, fxv, fyv, r1q != 0);
         const size_t o = (size_t)y * pitch + x;
 #pragma unroll
         for (int c = 0; c < 5; c++) Mout[o + c * plane] = mm.v[c];
@@ -1749,7 +1844,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
     }
 
     struct Px {
-        Taps tp;
+        TapsQ tp;
         float r0v[5];
         float fxv, fyv;
     };
@@ -1808,7 +1903,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             all[j].fyv = fys[j];
 #pragma unroll
             for (int c = 0; c < 5; c++) all[j].r0v[c] = buf_ld(bR0, vx, (unsigned)(a + j) * rb + c * pb);
-            all[j].tp = gather_taps(bR1, x, a + j, w, h, pitch, pb, fxs[j], fys[j]);
+            all[j].tp = gather_taps_q(bR1, x, a + j, w, h, pitch, pb, fxs[j], fys[j]);
         }
 #pragma unroll
         for (int j = 0; j < RW; j++)
@@ -1823,7 +1918,7 @@ __device__ __forceinline__ void halo_tile(HaloLds<RW, NW, LROWS> &lds, const flo
             cur.fyv = fys[j];
 #pragma unroll
             for (int c = 0; c < 5; c++) cur.r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-            cur.tp = gather_taps(bR1, x, y, w, h, pitch, pb, cur.fxv, cur.fyv);
+            cur.tp = gather_taps_q(bR1, x, y, w, h, pitch, pb, cur.fxv, cur.fyv);
             if (j > 0 && valid(j - 1)) finish(prev, j - 1);  // the gather of row j is in flight while the row before it is finished
             prev = cur;
         }
@@ -1962,7 +2057,7 @@ __device__ __forceinline__ void lds_wait(const int *p, int target, const ColArgs
         do {
             __builtin_amdgcn_s_sleep(1);
             if (++n > ca.spin) {
-                atomicOr(ca.abort, 1u);
+                __hip_atomic_store(ca.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // pinned host memory (ctx->fb_col_abort)
                 break;
             }
         } while (lds_flag_ld(p) < target);
@@ -1995,7 +2090,7 @@ __device__ __forceinline__ void f7_store(const RgbaTab &rg, int z, int xr, int y
     }
 }
 
-template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false, bool TRACE = false>
+template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false, bool TRACE = false, bool LEAN = false>
 __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ Din, float *__restrict__ Dout, FlowTab fin, FlowTab fout, Prolong pr,
                                                               int w, int h, int pitch, double scale, ColArgs ca, size_t pair_stride, RgbaTab rg) {
@@ -2043,17 +2138,50 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     };
 
     struct Px {
-        Taps tp;
+        TapsQ tp;
         float r0v[5];
     };
+    auto gather = [&](int gx, int gy, float dx, float dy) __attribute__((always_inline)) { return gather_taps_q(bR1, gx, gy, w, h, pitch, pb, dx, dy); };
     auto solve = [&](const double (&D)[5], float &fx, float &fy) __attribute__((always_inline)) {
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
         const double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        const double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
+        const double det = g11_ * g22_ - g12_ * g12_ + 1e-3;
+        double idet;
+        if (LEAN) {
+            // 1 / det as the compiler's own correctly rounded sequence WITHOUT its range scaling (v_div_scale x 2, the multiplication by the
+            // scaled numerator 1.0, v_div_fmas): those only act on operands near the ends of the f64 exponent range, and det is a sum of
+            // products of 8-bit-image moments plus 1e-3 -- the same bits for every normal det with |det| in [2^-700, 2^700]; zero, infinity
+            // and NaN go through v_div_fixup as before.  8 instead of 12 instructions per solve.
+            double y0 = __builtin_amdgcn_rcp(det);
+            double e = __builtin_fma(-det, y0, 1.0);
+            y0 = __builtin_fma(y0, e, y0);
+            e = __builtin_fma(-det, y0, 1.0);
+            y0 = __builtin_fma(y0, e, y0);
+            e = __builtin_fma(-det, y0, 1.0);
+            idet = __builtin_amdgcn_div_fixup(__builtin_fma(e, y0, y0), det, 1.0);
+        } else {
+            idet = 1. / det;
+        }
         fx = (float)((g11_ * h2_ - g12_ * h1_) * idet);
         fy = (float)((g22_ * h1_ - g12_ * h2_) * idet);
+    };
+    // F4 of one row from its samples.  LEAN: the border scale as one wave-uniform condition -- the lane's factor of the two vertical
+    // image edges is hoisted (sxc), a row's factors are scalars, and scale 1 is applied as a multiplication (exact) to the lanes of a
+    // border row / border workgroup that are not themselves within five pixels of an edge; rows and workgroups away from the edges skip it.
+    const float sxc = um_border(x) * um_border(w - x - 1);
+    const bool wg_edge_x = x0 - 2 < kUmBorder || x0 + 61 >= w - kUmBorder;  // wave-uniform
+    auto finish = [&](const auto &qq, int y, float dx, float dy) __attribute__((always_inline)) {
+        if (!LEAN) return update_matrices_finish(qq.r0v, qq.tp, x, y, w, h, dx, dy);
+        float rr[5];
+        um_sample(qq.r0v, qq.tp, dx, dy, rr);
+        if (wg_edge_x || (unsigned)(y - kUmBorder) >= (unsigned)(h - 2 * kUmBorder)) {
+            const float sc = sxc * um_border(y) * um_border(h - y - 1);
+#pragma unroll
+            for (int c = 0; c < 5; c++) rr[c] *= sc;
+        }
+        return um_products(rr);
     };
     auto flow_out = [&](int y, float fx, float fy) __attribute__((always_inline)) {
         if (!own || y < 0 || y >= h) return;
@@ -2123,7 +2251,28 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     };
 
     // lanes beyond the image edge take the border pixel's flow (see fix_l / fix_r); branch-free
+    const bool wg_left = x0 < 2, wg_right = w + 1 - x0 < 63;  // wave-uniform: the workgroup has lanes left / right of the image
     auto border_flow = [&](float &fx, float &fy) __attribute__((always_inline)) {
+        if (LEAN) {
+            // only the first and the last tile column have such lanes; lanes 0, 1 <- lane 2 and (full last tile) lanes 62, 63 <- lane 61 as
+            // one DPP quad permutation each, confined to the quad by the row / bank masks
+            if (wg_left) {
+                fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0xEA, 0x1, 0x1, false));
+                fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0xEA, 0x1, 0x1, false));
+            }
+            if (wg_right) {
+                if (lane_r == 61) {
+                    fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0x54, 0x8, 0x8, false));
+                    fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0x54, 0x8, 0x8, false));
+                } else {
+                    const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
+                    const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane_r));
+                    fx = xr >= w ? rx : fx;
+                    fy = xr >= w ? ry : fy;
+                }
+            }
+            return;
+        }
         const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), 2));
         const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), 2));
         const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
@@ -2191,13 +2340,13 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                     if (!LAST1) {
 #pragma unroll
                         for (int c = 0; c < 5; c++) q[j].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
-                        q[j].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx1[j], fy1[j]);
+                        q[j].tp = gather(x, y, fx1[j], fy1[j]);
                     }
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST1 && p >= DEPTH) {
                     const int j = p - DEPTH, y = min(a + j, h - 1);
-                    const M5 mm = update_matrices_finish(q[j].r0v, q[j].tp, x, y, w, h, fx1[j], fy1[j]);
+                    const M5 mm = finish(q[j], y, fx1[j], fy1[j]);
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         m1[j][c] = mm.v[c];
@@ -2223,12 +2372,14 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         // ---------------------------------------------------------------- step 2, rows a-1 .. a+RW-2, the same way from the column sums of M'
         {
             double sum[5];
+            if (!LEAN || a < 1 || a - 1 + RW > h) {  // (wave-uniform: only the first and the last rounds have such rows)
 #pragma unroll
-            for (int i = 0; i < RW; i++) {
-                const int t = a - 1 + i;
-                const bool valid = t >= 0 && t < h;  // wave-uniform
+                for (int i = 0; i < RW; i++) {
+                    const int t = a - 1 + i;
+                    const bool valid = t >= 0 && t < h;  // wave-uniform
 #pragma unroll
-                for (int c = 0; c < 5; c++) d2[i][c] = valid ? d2[i][c] : 0.f;
+                    for (int c = 0; c < 5; c++) d2[i][c] = valid ? d2[i][c] : 0.f;
+                }
             }
 #pragma unroll
             for (int c = 0; c < 5; c++) {
@@ -2264,13 +2415,13 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         // row a-1+i: its R0 samples are step 1's of row i-1 unless the row index was clamped there or here (first / last round)
 #pragma unroll
                         for (int c = 0; c < 5; c++) q[i].r0v[c] = i == 0 ? buf_ld(bR0, vx, (unsigned)y * rb + c * pb) : r0k[i - 1][c];
-                        q[i].tp = gather_taps(bR1, x, y, w, h, pitch, pb, fx2[i], fy2[i]);
+                        q[i].tp = gather(x, y, fx2[i], fy2[i]);
                     }
                     if (SCHED) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST2 && p >= DEPTH) {
                     const int i = p - DEPTH, y = clampi(a - 1 + i, 0, h - 1);
-                    const M5 mm = update_matrices_finish(q[i].r0v, q[i].tp, x, y, w, h, fx2[i], fy2[i]);
+                    const M5 mm = finish(q[i], y, fx2[i], fy2[i]);
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         m2[i][c] = mm.v[c];
@@ -2462,7 +2613,8 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
 
 // F3 for `nimg` frames in one launch: I of frame i at d_I + i * I_stride, R of frame i at d_R + (i / 2) * pair_stride + (i % 2) * field
 int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h, float *d_R, int poly_n, double poly_sigma, int nimg,
-                   size_t I_stride, size_t pair_stride, size_t field) {
+                   size_t I_stride, size_t pair_stride, size_t field, bool pack_odd) {
+    const int po = pack_odd ? 1 : 0;  // the odd frames (the second frame of every pair) in the packed form of an R1 field
     if (poly_n < 1 || poly_n > kMaxPolyN) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "poly_n %d outside 1..%d", poly_n, kMaxPolyN);
     PolyCoef pc;
     make_poly_coef(poly_n, poly_sigma, pc);
@@ -2476,7 +2628,7 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
         const int nwg = std::min((ntiles * nimg + 7) & ~7, ctx->num_cus * wgs_per_cu & ~7);  // a multiple of the 8 XCDs
 #define OFXCV_LAUNCH_PE(N, TH)                                                                                                          \
     hipLaunchKernelGGL((polyexp_persistent_kernel<N, TH>), dim3(nwg), dim3(256), 0, s, d_I, w, h, d_R, plane_pitch(w), pc, tiles_x, ntiles, \
-                       nimg, I_stride, pair_stride, field)
+                       nimg, I_stride, pair_stride, field, po)
         if (poly_n == 5) {
             if (th == 16) OFXCV_LAUNCH_PE(5, 16);
             else OFXCV_LAUNCH_PE(5, 8);
@@ -2488,9 +2640,9 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
         OFXCV_LAUNCH_CHECK(ctx, "polyexp_persistent_kernel");
         return OFXCV_OK;
     }
-    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
-    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
-    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field);
+    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
+    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
+    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
     OFXCV_LAUNCH_CHECK(ctx, "polyexp_kernel");
     return OFXCV_OK;
 }
@@ -2499,7 +2651,8 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
 // z * L.planes floats further), `flows` the per-pair flow outputs (null pointers: the flow stays on chip).  The kernels of
 // the default mode (OpenCV-order 3x3 box) take all pairs in one launch; the other window forms are launched pair by pair.
 int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, const FlowTab &flows,
-                     int w, int h, int winsize, bool update, const Layout &L) {
+                     int w, int h, int winsize, bool update, const Layout &L, bool r1_packed) {
+    const int r1q = r1_packed ? 1 : 0;  // R1 in its packed form (whole calls) or planar (the stage-level entry point)
     int m = winsize / 2;
     double scale = 1. / (winsize * winsize);
     const int pitch = plane_pitch(w);
@@ -2513,9 +2666,9 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
             OFXCV_LAUNCH_CHECK(ctx, "strict_colscan_kernel");
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
             if (update)
-                hipLaunchKernelGGL(strict_solve_kernel<true>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale);
+                hipLaunchKernelGGL(strict_solve_kernel<true>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale, r1q);
             else
-                hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale);
+                hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale, r1q);
             OFXCV_LAUNCH_CHECK(ctx, "strict_solve_kernel");
         } else if (winsize == 3) {
             // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
@@ -2524,7 +2677,7 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
             while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
             dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
 #define OFXCV_LAUNCH_IT(UPD, RW) \
-    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, scale)
+    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, scale, r1q)
             if (update) {
                 if (rows == 4) OFXCV_LAUNCH_IT(true, 4);
                 else if (rows == 2) OFXCV_LAUNCH_IT(true, 2);
@@ -2539,9 +2692,9 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         } else {
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
             if (update)
-                hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale);
+                hipLaunchKernelGGL(blur_solve_update_kernel<true>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale, r1q);
             else
-                hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale);
+                hipLaunchKernelGGL(blur_solve_update_kernel<false>, grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, m, scale, r1q);
             OFXCV_LAUNCH_CHECK(ctx, "blur_solve_update_kernel");
         }
     }
@@ -2570,9 +2723,9 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
         hipLaunchKernelGGL(gauss_vpass_kernel, grid, block, 0, s, mi, w, h, pitch, t, V);
         OFXCV_LAUNCH_CHECK(ctx, "gauss_vpass_kernel");
         if (update)
-            hipLaunchKernelGGL(gauss_hpass_solve_kernel<true>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t);
+            hipLaunchKernelGGL(gauss_hpass_solve_kernel<true>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t, 1);  // (whole calls only: R1 packed)
         else
-            hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t);
+            hipLaunchKernelGGL(gauss_hpass_solve_kernel<false>, grid, block, 0, s, r0, r1, (const float *)V, mo, flows.p[z], flows.step[z], w, h, pitch, t, 1);
         OFXCV_LAUNCH_CHECK(ctx, "gauss_hpass_solve_kernel");
     }
     return OFXCV_OK;
@@ -2738,7 +2891,7 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     if (rgba) rg = *rgba;
     const bool iter_pair = k1 == kHaloIter && k2 == kHaloIter;
     const ColGeom g = col_geom(ctx, w, h, iter_pair);
-    ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, (unsigned *)ctx->fb_col_flag.ptr, (unsigned)ctx->fb_col_spin,
+    ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, ctx->fb_col_abort, (unsigned)ctx->fb_col_spin,
                   ctx->fb_col_trace ? (unsigned long long *)((char *)ctx->fb_col_flag.ptr + 256) : nullptr};
     dim3 grid(g.tiles_x, 1, L.n);
     const int pitch = plane_pitch(w);
@@ -2758,7 +2911,14 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
         else if (k1 == kHaloGiven && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloLast, RW, NW, DEPTH); \
         else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2); \
     } while (0)
-    if (iter_pair && ctx->fb_col_trace) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, 1, true, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
+#define OFXCV_COL_X(DEPTH) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, DEPTH, true, false, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
+    if (iter_pair && !ctx->fb_col_trace && ctx->fb_col_lean && ctx->fb_col_geom == 0) {  // experiment: reduced-instruction form, gather pipeline depth
+        if (ctx->fb_col_depth == 2) OFXCV_COL_X(2);
+        else if (ctx->fb_col_depth == 4) OFXCV_COL_X(4);
+        else OFXCV_COL_X(1);
+    }
+#undef OFXCV_COL_X
+    else if (iter_pair && ctx->fb_col_trace) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, 1, true, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
     else if (iter_pair && ctx->fb_col_geom == 1) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, 1);
     else OFXCV_LAUNCH_COL(4, 8, 1);
 #undef OFXCV_LAUNCH_COL
@@ -2837,7 +2997,7 @@ int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int hei
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
     if (!d_I || !d_R || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_polyexp: bad argument");
-    return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma, 1, 0, 0, 0);
+    return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma, 1, 0, 0, 0, false);
 }
 
 int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow, size_t flow_step,
@@ -2848,7 +3008,7 @@ int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const flo
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
     hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
                        ofxcv_stream(ctx, stream), d_R0, d_R1, one_flow(const_cast<float *>(d_flow), flow_step), 0, 0, 1.0, 1.0, 1.0, width, height,
-                       plane_pitch(width), d_M, (size_t)0);
+                       plane_pitch(width), d_M, (size_t)0, 0);
     OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
     return OFXCV_OK;
 }
@@ -2868,7 +3028,7 @@ int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const fl
     }
     L.vsum_ptr = (double *)ctx->fb_vsum.ptr;
     return launch_iteration(ctx, ofxcv_stream(ctx, stream), d_R0, d_R1, d_M_in, d_M_out, one_flow(d_flow, flow_step), width, height, winsize,
-                            update != 0, L);
+                            update != 0, L, false);
 }
 
 // The launch sequence of one call (n frame pairs).  The pyramid images and polynomial expansions of ALL levels depend only
@@ -2905,7 +3065,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             p += 2 * field;
             rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, L.t1, I, L.img);
             if (rc) return rc;
-            rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field);
+            rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field, true);  // R1 = the odd frames, packed
             if (rc) return rc;
             OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[k], sp));
         }
@@ -3060,15 +3220,15 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                     }
                 }
                 if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, init, no_pr, w, h, kHaloGiven, hs, 0, G);
-                else hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R0, R1, init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+                else hipLaunchKernelGGL(update_matrices_kernel<2>, grid, block, 0, s, R0, R1, init, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes, 1);
             } else if (!have_prev) {
                 if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, no_flow, no_pr, w, h, kHaloZero, hs, 0, G);
-                else hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes);
+                else hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes, 1);
             } else {
                 const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
                 if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, sub_tab(prev_all, z0, gn), pr, w, h, kHaloCoarse, hs, 0, G);
                 else hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R0, R1, sub_tab(prev_all, z0, gn), pw, ph, pr.inv_pyr_scale, pr.scale_x,
-                                        pr.scale_y, w, h, pitch, M0, L.planes);
+                                        pr.scale_y, w, h, pitch, M0, L.planes, 1);
             }
             if (halo_first && rc) return rc;
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
@@ -3104,7 +3264,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                         }
                         rc = launch_halo_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, no_pr, w, h, update ? kHaloIter : kHaloLast, hs, cur, G, sink ? &rg : nullptr);
                     } else
-                        rc = launch_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G);
+                        rc = launch_iteration(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], ft, w, h, winsize, update, G, true);
                     i += 1;
                 }
                 ctx->prof_now = false;
@@ -3201,10 +3361,17 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         rc = ofxcv_reserve(ctx, ctx->fb_vsum, L.vsum_bytes());
         if (rc) return rc;
     }
-    if (ctx->fb_col && !ctx->fb_col_flag.ptr) {  // the sticky abort word of iterate_col_kernel
+    if (ctx->fb_col && !ctx->fb_col_flag.ptr) {  // the trace area of iterate_col_kernel
         rc = ofxcv_reserve(ctx, ctx->fb_col_flag, kColFlagBytes);
         if (rc) return rc;
         OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, kColFlagBytes, s));
+    }
+    if (ctx->fb_col && !ctx->fb_col_abort) {  // its abort word: pinned, host-coherent (the host reads it at its synchronisation points without a copy)
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        void *p = nullptr;
+        OFXCV_HIP_CHECK(ctx, hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(p, 0, 64);
+        ctx->fb_col_abort = (unsigned *)p;
     }
     rc = ofxcv_farneback_streams(ctx);
     if (rc) return rc;

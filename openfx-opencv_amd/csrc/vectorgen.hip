@@ -396,7 +396,7 @@ static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t r
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->copy));
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
     ctx->host_zero_copy_calls++;
-    return OFXCV_OK;  // `regs` unregisters the host ranges here: nothing of this call is in flight any more
+    return ofxcv_col_abort_check(ctx);  // `regs` unregisters the host ranges here: nothing of this call is in flight any more
 }
 
 // One reference frame against one or two other frames (forward: t+1, backward: t-1 -- the two directions a default
@@ -616,7 +616,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         else
             OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, (size_t)dst_row_bytes, d_rgba, drow, drow, height, hipMemcpyDeviceToHost, ctx->compute));
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
-        return OFXCV_OK;
+        return ofxcv_col_abort_check(ctx);  // (the host images of a call whose kernel gave up are not valid: fail, do not hand them over)
     }
     for (int k = 0; k < n_other; k++) {
         if (render_scale_x != 1.0 || render_scale_y != 1.0) {
@@ -628,6 +628,10 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[k], d_flow[k], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
     }
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+    {
+        const int arc = ofxcv_col_abort_check(ctx);
+        if (arc) return arc;
+    }
 
     // write-back into the host-owned destination (:507-516): the channel -> (flow, coordinate) table was resolved above
     int nmap = 0, dst_c[4];

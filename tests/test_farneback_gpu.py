@@ -776,6 +776,35 @@ def test_column_owning_form_for_part_of_a_batch(oracle, ofxcv):
     s1.close()
 
 
+def test_column_owning_abort_word_is_reported_once(oracle, ofxcv):
+    """A bounded LDS wait of iterate_col_kernel that runs out leaves wrong flows behind: the library's own synchronisation points
+    (ofxcv_ctx_synchronize, the host-image entry points) must fail for THAT call and not for the next one.  Forced
+    here with farneback.col_spin 1 (a wait gives up after one poll); the same context then repeats the call with the default bound
+    and gets the single-call result bit for bit."""
+    w, h, n = 333, 257, 2
+    prs = _pairs(oracle, w, h, range(610, 610 + n))
+    da, db = [_dev(a) for a, _ in prs], [_dev(b) for _, b in prs]
+    single = ofxcv.Context(0)
+    singles = [single.calc_optical_flow_farneback(x, y, iterations=4).cpu().numpy() for x, y in zip(da, db)]
+    single.close()
+    c = ofxcv.Context(0)
+    c.set_option("farneback.col_min", 1)
+    c.set_option("farneback.col_spin", 1)
+    c.calc_optical_flow_farneback_batch(da, db, iterations=4)
+    if c.get_option("farneback.col_aborts") == 0:
+        c.close()
+        pytest.skip("no wait ran out with a bound of one poll on this box (timing)")
+    with pytest.raises(ofxcv.OfxcvError):
+        c.synchronize()
+    c.synchronize()  # reported once
+    c.set_option("farneback.col_spin", 1 << 22)
+    got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(da, db, iterations=4)]
+    c.synchronize()
+    for z in range(n):
+        assert np.array_equal(got[z], singles[z]), z
+    c.close()
+
+
 def test_column_owning_plan(gpu_ctx):
     """ofxcv_farneback_col_pairs: how many pairs of a call walk level 0 in the column-owning form (256 CUs, one workgroup per
     tile column and pair, launches charged in rounds of the chip against 0.196 x w / 1920 of a round per pair in strips)."""

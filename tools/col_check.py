@@ -8,7 +8,13 @@ import torch
 import openfx_opencv_amd as ofxcv
 from openfx_opencv_amd import synth
 
-geoms = [int(v) for v in sys.argv[1:]] or [0, 1]
+extra = []
+argv = sys.argv[1:]
+if "--opts" in argv:  # further options of the tested context: --opts k=v,k=v
+    i = argv.index("--opts")
+    extra = [kv.split("=") for kv in argv[i + 1].split(",") if kv]
+    del argv[i:i + 2]
+geoms = [int(v) for v in argv] or [0, 1]
 cases = [(333, 257, 2, dict()), (640, 480, 1, dict()), (125, 70, 3, dict(levels=1)), (640, 480, 2, dict(iterations=4)), (640, 480, 1, dict(iterations=1)),
          (200, 150, 1, dict(iterations=2, levels=0)), (1920, 1080, 2, dict()), (61, 131, 1, dict(levels=0)), (60, 64, 1, dict(levels=0)), (59, 300, 1, dict(levels=1))]
 bad = 0
@@ -25,6 +31,8 @@ for w, h, n, kw in cases:
         c.set_option("farneback.col", 1)
         c.set_option("farneback.col_min", 1)
         c.set_option("farneback.col_geom", g)
+        for k_, v_ in extra:
+            c.set_option(k_, int(v_))
         got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(ga, gb, **kw)]
         ab = c.get_option("farneback.col_aborts")
         same = [bool(np.array_equal(x, y)) for x, y in zip(ref, got)]
