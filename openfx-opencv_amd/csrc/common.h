@@ -88,11 +88,10 @@ struct ofxcv_ctx {
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
     int fb_col_min = 128;        // option "farneback.col_min": workgroups (tile columns x pairs) below which no launch takes that form; from there on a cost model decides per level how many pairs do (col_pairs in farneback.hip); values below the default force the form (tests)
     int fb_col_split = 1;        // option "farneback.col_split": the pairs of a call that do not fill a round of the chip in that form keep the overlapped strips (1); 0 = all pairs or none
-    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (A/B; same launch time, profiles/r04_experiments.md #19)
+    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (the second geometry the tests walk; no ring)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
-    int fb_col_depth = 1;        // option "farneback.col_depth" (experiment, with col_lean): rows whose gathers are in flight before the first is consumed (1, 2, 4)
-    int fb_col_lean = 0;         // option "farneback.col_lean" (experiment): the (iterate, iterate) launch in its reduced-instruction form
+    int fb_col_ring = 1;         // option "farneback.col_ring": the step pairs of the column-owning form that open with an iteration gather R1 from a ring of rows in LDS filled by LDS-DMA (1, default); 0 = every gather from memory (cross-check, A/B)
     DevBuf fb_col_flag;          // the trace area of iterate_col_kernel (farneback.col_trace)
     unsigned *fb_col_abort = nullptr;  // the abort word of iterate_col_kernel: 64 bytes of pinned, host-coherent memory the kernel stores to when a bounded
                                        // LDS wait runs out; read (and cleared) by the host at every synchronisation point of the library without a copy

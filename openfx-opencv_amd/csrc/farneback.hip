@@ -2043,8 +2043,13 @@ struct ColArgs {
 template <int NW>
 struct ColLds {
     float b[2][NW][3][5][64];
-    double p[2][5][64];
-    int seq[2];
+    // the token of step s: the running column sums of five channels per lane as {P0, P1} {P2, P3} {P4} and, written LAST and read FIRST, the ticket
+    // they are for.  LDS executes a wavefront's accesses in issue order, so a reader that finds the tag finds the sums behind it: no fence, no
+    // separate flag, one LDS round trip per link.
+    struct alignas(16) Token {
+        double a[64][2], b[64][2], c[64];
+        int tag[64];
+    } tok[2];
     int wr[2][NW], rd[2][NW];
 };
 
@@ -2090,7 +2095,33 @@ __device__ __forceinline__ void f7_store(const RgbaTab &rg, int z, int xr, int y
     }
 }
 
-template <int K1, int K2, int RW, int NW, int DEPTH, bool SCHED = false, bool TRACE = false, bool LEAN = false>
+// R1 WINDOW IN LDS (RING; round 5).  Counters (profiles/r05_pmc_attr_iterate_col_baseline.txt): the texture addresser is the busiest unit of this
+// kernel -- TA_BUSY 74-83 % of the launch, ~37 of its cycles per gather -- while the vector ALU is 45 % busy and the LDS pipe 3 %.  So the
+// workgroup keeps the R1 rows its two steps can reach in an LDS ring and gathers from there:
+//   * ring: kRingRows = 64 image rows x kRingCols = 64 + 2 D columns (the tile column's lanes +- D), packed like the field itself (float4 of four
+//     channels per pixel + plane 4): 90 KB beside the 65 KB of hand-off rows -- one workgroup per CU either way;
+//   * fill: LDS-DMA (buffer_load ... lds: no registers, no ds_write), in groups of four rows.  The wavefront with ticket t (rows 4t .. 4t+3) issues
+//     the fill of group t + L (rows 4(t+L) ..) right after it has taken the step-1 token, L = 6 groups = three quarters of a round ahead of the first
+//     wavefront that needs it (ticket t + 5); it publishes `filled[wave] = round + 1` once its loads have landed (s_waitcnt vmcnt(0) at the end
+//     of its step 1, where nothing else is in flight);
+//   * why a 64-row ring is enough and never overwritten too early: the eight active tickets span at most 8 x 4 rows, a ticket reads rows
+//     [4t - 1 - D, 4t + 3 + D], the newest group in flight is t_fastest + L: 33 + 4 L + D = 61 rows.  Group g overwrites group g - 16, last read by
+//     ticket g - 14; the filler (ticket g - 6) holds the step-1 token, which it can only have got after ticket g - 7 -- the next round of ticket g - 15's
+//     wavefront -- started, and it is itself the next round of ticket g - 14: every reader of the old rows is done;
+//   * a gather whose 64 lanes all sample within +- D of their own pixel (wave-uniform test, one ballot) reads the ring (four ds_read_b128 + two
+//     ds_read2_b32 per pixel); otherwise the whole wavefront-row takes the global gather as before -- same values either way.
+constexpr int kRingD = 4, kRingRows = 64, kRingCols = 64 + 2 * kRingD, kRingLead = 6;
+struct ColRing {
+    ofxcv_f4 q[kRingRows * kRingCols];
+    float c[kRingRows * kRingCols];
+    int filled[16];
+};
+typedef unsigned ofxcv_u4 __attribute__((ext_vector_type(4)));
+// The fill's loads are LDS-DMA (buffer_load ... offen lds: 64 lanes x 4 or 16 bytes from a buffer into LDS at M0 + lane * size), issued from inline
+// assembly: M0 is compiler-reserved, so it is saved and restored inside the statement, and the loads are invisible to the compiler's wait-count
+// bookkeeping on purpose (a load it tracked would make it wait for the fill in front of every ring read): completion is the filler's own
+// `s_waitcnt vmcnt(0)` before it publishes the group.
+template <int K1, int K2, int RW, int NW, bool RING = false, bool TRACE = false>
 __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
                                                               const float *__restrict__ Din, float *__restrict__ Dout, FlowTab fin, FlowTab fout, Prolong pr,
                                                               int w, int h, int pitch, double scale, ColArgs ca, size_t pair_stride, RgbaTab rg) {
@@ -2098,8 +2129,11 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     constexpr bool OUT = !LAST1 && !LAST2;  // the launch leaves a field
     static_assert(K2 == kColNone || K2 == kHaloIter || K2 == kHaloLast, "step 2 iterates or ends the level");
     static_assert(LAST1 != TWO, "nothing follows the last step; every other step has a partner");
-    static_assert(RW >= 3 && DEPTH >= 1 && DEPTH <= RW, "the three boundary rows");
+    static_assert(RW >= 3, "the three boundary rows");
+    constexpr int DEPTH = 1;  // rows whose samples are in flight before the first is consumed (2 and 4 measured the same: r05_experiments.md)
     __shared__ ColLds<NW> lds;
+    static_assert(!RING || (K1 == kHaloIter && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
+    __shared__ typename std::conditional<RING, ColRing, int>::type ring;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     R0 += (size_t)tbz * pair_stride;
@@ -2112,12 +2146,14 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     float *__restrict__ oflow = fout.p[tbz];       // last: the level's flow
     const size_t oflow_step = fout.step[tbz];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (threadIdx.x < 2) lds.seq[threadIdx.x] = 0;
+    if (threadIdx.x < 128) lds.tok[threadIdx.x >> 6].tag[threadIdx.x & 63] = 0;
     if (threadIdx.x < 2 * NW) {
         (&lds.wr[0][0])[threadIdx.x] = 0;
         (&lds.rd[0][0])[threadIdx.x] = 0;
     }
-    __syncthreads();
+    if constexpr (RING) {
+        if (threadIdx.x < 16) ring.filled[threadIdx.x] = 0;
+    }
     const int x0 = tbx * kColW;
     const int xr = x0 - 2 + lane, x = clampi(xr, 0, w - 1);  // clamped = the replicated border columns of the reference
     const bool own = lane >= 2 && lane < 2 + kColW && xr < w;
@@ -2129,6 +2165,79 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     // lanes beyond the image edge repeat the border column: after step 1 they must hold the BORDER pixel's flow (their own box
     // window is not the border pixel's), so that their M' is the replicated border column step 2 sums over
     const int lane_r = __builtin_amdgcn_readfirstlane(min(w + 1 - x0, 63));
+    // ---- the R1 ring (RING): this lane's part of a fill group and the group fill itself
+    const int xw0 = x0 - 2 - kRingD;  // image column of ring column 0
+    [[maybe_unused]] unsigned ring_q_addr = 0, ring_c_addr = 0;
+    [[maybe_unused]] int frow[5];
+    [[maybe_unused]] unsigned fvo[5];  // this lane's element of each of a group's five loads: (row in the group) * pitch + image column (clamped to the field's rows)
+    [[maybe_unused]] ofxcv_u4 r1rsrc = {0, 0, 0, 0};
+    if constexpr (RING) {
+        ring_q_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)ring.q);
+        ring_c_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)ring.c);
+        const unsigned long long ba = (unsigned long long)(size_t)R1;
+        r1rsrc = ofxcv_u4{(unsigned)ba, (unsigned)(ba >> 32) & 0xffffu, (unsigned)(5 * plane * sizeof(float)), 0x00020000u};
+#pragma unroll
+        for (int i = 0; i < 5; i++) {  // element e = i * 64 + lane of a group of 4 rows x kRingCols columns (the fifth load: 32 lanes)
+            const int e = i * 64 + lane;
+            frow[i] = e / kRingCols;
+            fvo[i] = (unsigned)(frow[i] * pitch + clampi(xw0 + e - frow[i] * kRingCols, 0, pitch - 1));
+        }
+    }
+    // group g = image rows 4g .. 4g+3 -> ring rows (4g .. 4g+3) & 63, ten LDS-DMA loads (five of 16 bytes per lane, five of 4) in ONE statement: M0 is
+    // saved once, stepped from load to load and restored.  Columns outside the field's rows are clamped (never sampled: such a tap is out of
+    // bounds); rows below the image repeat row h-1; a group entirely below the image is not filled at all (the late tickets' clamped rows still read
+    // the rows just above the image's last row, which such a fill would overwrite).
+    auto ring_fill = [&](int g) __attribute__((always_inline)) {
+        if constexpr (RING) {
+            if (4 * g >= h) return;
+            const unsigned qa = ring_q_addr + (unsigned)((4 * g) & (kRingRows - 1)) * (kRingCols * 16u);
+            const unsigned ca4 = ring_c_addr + (unsigned)((4 * g) & (kRingRows - 1)) * (kRingCols * 4u);
+            unsigned vo[5];
+            unsigned sq, sc;
+            if (4 * g + 3 < h) {  // (wave-uniform) every row of the group inside the image: the lane's constant part + the group's rows as scalar offsets
+#pragma unroll
+                for (int i = 0; i < 5; i++) vo[i] = fvo[i];
+                sq = (unsigned)(4 * g) * (unsigned)pitch * 16u;
+                sc = (unsigned)(4 * g) * (unsigned)pitch * 4u + 4u * pb;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 5; i++) vo[i] = fvo[i] - (unsigned)(frow[i] * pitch) + (unsigned)(min(4 * g + frow[i], h - 1) * pitch);
+                sq = 0u;
+                sc = 4u * pb;
+            }
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %[k], m0\n\t"
+                "s_mov_b32 m0, %[qa]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[q0], %[rs], %[sq] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[q1], %[rs], %[sq] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[q2], %[rs], %[sq] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %[q3], %[rs], %[sq] offen lds\n\t"
+                "s_mov_b32 m0, %[ca]\n\ts_nop 0\n\tbuffer_load_dword %[c0], %[rs], %[sc] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tbuffer_load_dword %[c1], %[rs], %[sc] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tbuffer_load_dword %[c2], %[rs], %[sc] offen lds\n\t"
+                "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tbuffer_load_dword %[c3], %[rs], %[sc] offen lds\n\t"
+                "s_mov_b32 m0, %[k]"
+                : [k] "=&s"(keep)
+                : [qa] "s"(qa), [ca] "s"(ca4), [rs] "s"(r1rsrc), [sq] "s"(sq), [sc] "s"(sc), [q0] "v"(vo[0] * 16u), [q1] "v"(vo[1] * 16u), [q2] "v"(vo[2] * 16u),
+                  [q3] "v"(vo[3] * 16u), [c0] "v"(vo[0] * 4u), [c1] "v"(vo[1] * 4u), [c2] "v"(vo[2] * 4u), [c3] "v"(vo[3] * 4u)
+                : "memory", "scc");
+            if (lane < 4 * kRingCols - 256) {  // the last 32 elements of the group
+                asm volatile(
+                    "s_mov_b32 %[k], m0\n\t"
+                    "s_mov_b32 m0, %[qa]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[q4], %[rs], %[sq] offen lds\n\t"
+                    "s_mov_b32 m0, %[ca]\n\ts_nop 0\n\tbuffer_load_dword %[c4], %[rs], %[sc] offen lds\n\t"
+                    "s_mov_b32 m0, %[k]"
+                    : [k] "=&s"(keep)
+                    : [qa] "s"(qa + 4096u), [ca] "s"(ca4 + 1024u), [rs] "s"(r1rsrc), [sq] "s"(sq), [sc] "s"(sc), [q4] "v"(vo[4] * 16u), [c4] "v"(vo[4] * 4u)
+                    : "memory");
+            }
+        }
+    };
+    if constexpr (RING) {
+        if (wave < kRingLead) ring_fill(wave);  // groups 0 .. L-1: what the first tickets need before any of them has filled anything
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
     const int off = wave * RW;
     const int pw = wave == 0 ? NW - 1 : wave - 1;  // whose boundary rows this wavefront takes
     // TRACE (option farneback.col_trace): one workgroup writes the shader clock at the phase boundaries of every round
@@ -2141,43 +2250,101 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         TapsQ tp;
         float r0v[5];
     };
-    auto gather = [&](int gx, int gy, float dx, float dy) __attribute__((always_inline)) { return gather_taps_q(bR1, gx, gy, w, h, pitch, pb, dx, dy); };
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto gather = [&](int gx, int gy, float dx, float dy) __attribute__((always_inline)) {
+        if constexpr (!RING) {
+            return gather_taps_q(bR1, gx, gy, w, h, pitch, pb, dx, dy);
+        } else {
+            TapsQ tp;
+            const float fx = gx + dx, fy = gy + dy;
+            const int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+            tp.fx = fx - x1;
+            tp.fy = fy - y1;
+            tp.inb = (unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1);
+            // every lane's sample within +- D of its own pixel: the ring holds the footprint (wave-uniform decision)
+            const bool inw = (unsigned)(x1 - gx + kRingD) < 2u * kRingD && (unsigned)(y1 - gy + kRingD) < 2u * kRingD;
+            if (__builtin_amdgcn_ballot_w64(!inw) == 0) {
+                const int cx = x1 - xw0;
+                const int e0 = (y1 & (kRingRows - 1)) * kRingCols + cx, e1 = ((y1 + 1) & (kRingRows - 1)) * kRingCols + cx;
+                tp.t0 = ring.q[e0];
+                tp.t1 = ring.q[e0 + 1];
+                tp.b0 = ring.q[e1];
+                tp.b1 = ring.q[e1 + 1];
+                tp.t4.a = ring.c[e0];
+                tp.t4.b = ring.c[e0 + 1];
+                tp.b4.a = ring.c[e1];
+                tp.b4.b = ring.c[e1 + 1];
+            } else {
+                const unsigned o = tp.inb ? (unsigned)y1 * (unsigned)pitch + (unsigned)x1 : 0u;
+                const unsigned oq = o * 16u, rq = (unsigned)pitch * 16u, o4 = o * 4u, r4 = (unsigned)pitch * 4u;
+                tp.t0 = buf_ld4(bR1, oq, 0);
+                tp.t1 = buf_ld4(bR1, oq + 16u, 0);
+                tp.b0 = buf_ld4(bR1, oq + rq, 0);
+                tp.b1 = buf_ld4(bR1, oq + rq + 16u, 0);
+                tp.t4.a = buf_ld(bR1, o4, 4 * pb);
+                tp.t4.b = buf_ld(bR1, o4 + 4u, 4 * pb);
+                tp.b4.a = buf_ld(bR1, o4 + r4, 4 * pb);
+                tp.b4.b = buf_ld(bR1, o4 + r4 + 4u, 4 * pb);
+            }
+            return tp;
+        }
+    };
+    // RING: before a ticket's first gather, the groups its rows can reach (<= (4t + 3 + D) / 4) must have landed: the fills of the tickets up to
+    // T = that group - L.  Wavefront j has then published at least (T - j) / 8 + 1 fills: lanes 0 .. 7 each check one wavefront's counter.
+    auto ring_wait = [&](int ticket) __attribute__((always_inline)) {
+        if constexpr (RING) {
+            const int T = (4 * ticket + 3 + kRingD) / 4 - kRingLead;
+            const int l = fresh_lane();
+            const int need = (l < NW && T >= l) ? (T - l) / 8 + 1 : 0;
+            unsigned n = 0;
+            while (__builtin_amdgcn_ballot_w64(lds_flag_ld(&ring.filled[l & 15]) < need) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++n > ca.spin) {
+                    __hip_atomic_store(ca.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    };
     auto solve = [&](const double (&D)[5], float &fx, float &fy) __attribute__((always_inline)) {
         double acc[5];
 #pragma unroll
         for (int c = 0; c < 5; c++) acc[c] = (dpp64_from_left(D[c]) + D[c]) + dpp64_from_right(D[c]);
         const double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
         const double det = g11_ * g22_ - g12_ * g12_ + 1e-3;
-        double idet;
-        if (LEAN) {
-            // 1 / det as the compiler's own correctly rounded sequence WITHOUT its range scaling (v_div_scale x 2, the multiplication by the
-            // scaled numerator 1.0, v_div_fmas): those only act on operands near the ends of the f64 exponent range, and det is a sum of
-            // products of 8-bit-image moments plus 1e-3 -- the same bits for every normal det with |det| in [2^-700, 2^700]; zero, infinity
-            // and NaN go through v_div_fixup as before.  8 instead of 12 instructions per solve.
-            double y0 = __builtin_amdgcn_rcp(det);
-            double e = __builtin_fma(-det, y0, 1.0);
-            y0 = __builtin_fma(y0, e, y0);
-            e = __builtin_fma(-det, y0, 1.0);
-            y0 = __builtin_fma(y0, e, y0);
-            e = __builtin_fma(-det, y0, 1.0);
-            idet = __builtin_amdgcn_div_fixup(__builtin_fma(e, y0, y0), det, 1.0);
-        } else {
-            idet = 1. / det;
-        }
+        // 1 / det as the compiler's own correctly rounded sequence WITHOUT its range scaling (v_div_scale x 2, the multiplication by the
+        // scaled numerator 1.0, v_div_fmas): those only act on operands near the ends of the f64 exponent range, and det is a sum of
+        // products of 8-bit-image moments plus 1e-3 -- the same bits for every normal det with |det| in [2^-700, 2^700]; zero, infinity
+        // and NaN go through v_div_fixup as before.  8 instead of 12 instructions per solve.
+        double y0 = __builtin_amdgcn_rcp(det);
+        double e = __builtin_fma(-det, y0, 1.0);
+        y0 = __builtin_fma(y0, e, y0);
+        e = __builtin_fma(-det, y0, 1.0);
+        y0 = __builtin_fma(y0, e, y0);
+        e = __builtin_fma(-det, y0, 1.0);
+        const double idet = __builtin_amdgcn_div_fixup(__builtin_fma(e, y0, y0), det, 1.0);
         fx = (float)((g11_ * h2_ - g12_ * h1_) * idet);
         fy = (float)((g22_ * h1_ - g12_ * h2_) * idet);
     };
-    // F4 of one row from its samples.  LEAN: the border scale as one wave-uniform condition -- the lane's factor of the two vertical
-    // image edges is hoisted (sxc), a row's factors are scalars, and scale 1 is applied as a multiplication (exact) to the lanes of a
-    // border row / border workgroup that are not themselves within five pixels of an edge; rows and workgroups away from the edges skip it.
-    const float sxc = um_border(x) * um_border(w - x - 1);
-    const bool wg_edge_x = x0 - 2 < kUmBorder || x0 + 61 >= w - kUmBorder;  // wave-uniform
+    // F4 of one row from its samples: the border scale as one wave-uniform condition -- the lane's factor of the two vertical image edges is
+    // hoisted, a row's factors are scalars, and scale 1 is applied as a multiplication (exact) to the lanes of a border row / border workgroup
+    // that are not themselves within five pixels of an edge; rows and workgroups away from the edges skip it.  The reference's test
+    // `(unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)` is kept to the letter: below ten columns its
+    // first half wraps and only holds at x == 4, so a lane's column factors count in a border ROW always, elsewhere only where that half holds.
+    const bool cx_in = (unsigned)(x - kUmBorder) >= (unsigned)(w - 2 * kUmBorder);
+    const float sxc = um_border(x) * um_border(w - x - 1), sx_only = cx_in ? sxc : 1.f;
+    const bool wg_edge_x = x0 - 2 < kUmBorder || x0 + 61 >= w - kUmBorder || w < 2 * kUmBorder;  // wave-uniform: some lane's cx_in may hold
     auto finish = [&](const auto &qq, int y, float dx, float dy) __attribute__((always_inline)) {
-        if (!LEAN) return update_matrices_finish(qq.r0v, qq.tp, x, y, w, h, dx, dy);
         float rr[5];
         um_sample(qq.r0v, qq.tp, dx, dy, rr);
-        if (wg_edge_x || (unsigned)(y - kUmBorder) >= (unsigned)(h - 2 * kUmBorder)) {
-            const float sc = sxc * um_border(y) * um_border(h - y - 1);
+        const bool cy = (unsigned)(y - kUmBorder) >= (unsigned)(h - 2 * kUmBorder);  // wave-uniform
+        if (wg_edge_x || cy) {
+            const float sc = (cy ? sxc : sx_only) * um_border(y) * um_border(h - y - 1);
 #pragma unroll
             for (int c = 0; c < 5; c++) rr[c] *= sc;
         }
@@ -2192,24 +2359,37 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     // the lane index, recomputed where a hand-off needs it: an LDS address kept in a register across a round is what the
     // register allocator spills first, and a reload from scratch inside the token's critical section costs every wavefront
     // behind this one a memory round trip (measured: two reloads = 5 000 cycles per link, the whole launch chain-bound)
-    auto fresh_lane = [&]() __attribute__((always_inline)) {
-        int l;
-        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-        return l;
-    };
     auto chain = [&](int s, int ticket, const double (&sum)[5], double (&P)[5]) __attribute__((always_inline)) {
         // the sums must be complete BEFORE the token is taken: whatever they wait for (the rows of the difference field still in
         // flight, the last rows of M') would otherwise be waited for while every wavefront behind this one waits for the token
         asm volatile("" ::"v"(sum[0]), "v"(sum[1]), "v"(sum[2]), "v"(sum[3]), "v"(sum[4]) : "memory");
-        if (ticket != 0) lds_wait(&lds.seq[s], ticket, ca);
+        typedef double tok_d2 __attribute__((ext_vector_type(2)));
         const int l = fresh_lane();
+        const unsigned ta = (unsigned)(size_t)(__attribute__((address_space(3))) void *)&lds.tok[s];  // a[], b[] at 16 bytes per lane, c[] at 8, tag[] at 4
+        const unsigned a16 = ta + 16u * (unsigned)l, a8 = ta + 2048u + 8u * (unsigned)l, a4 = ta + 2560u + 4u * (unsigned)l;
         if (ticket != 0) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) P[c] = lds.p[s][c][l];
+            tok_d2 A, B;
+            double C;
+            int tag;
+            unsigned n = 0;
+            do {  // (a busy poll: the token is what every wavefront behind this one waits for)
+                asm volatile("ds_read_b32 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %5 offset:1024\n\tds_read_b64 %3, %6\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(tag), "=&v"(A), "=&v"(B), "=&v"(C) : "v"(a4), "v"(a16), "v"(a8) : "memory");
+                if (__builtin_amdgcn_readfirstlane(tag) == ticket) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++n > ca.spin) {
+                    __hip_atomic_store(ca.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            } while (true);
+            P[0] = A.x; P[1] = A.y; P[2] = B.x; P[3] = B.y; P[4] = C;
         }
-#pragma unroll
-        for (int c = 0; c < 5; c++) lds.p[s][c][l] = P[c] + sum[c];
-        lds_post(&lds.seq[s], ticket + 1, l);
+        {
+            const tok_d2 A = {P[0] + sum[0], P[1] + sum[1]}, B = {P[2] + sum[2], P[3] + sum[3]};
+            const double C = P[4] + sum[4];
+            asm volatile("ds_write_b128 %0, %3\n\tds_write_b128 %0, %4 offset:1024\n\tds_write_b64 %1, %5\n\tds_write_b32 %2, %6"
+                         :: "v"(a16), "v"(a8), "v"(a4), "v"(A), "v"(B), "v"(C), "v"(ticket + 1) : "memory");
+        }
     };
     // the last three rows of this wavefront's step-s field for the wavefront below
     auto put_boundary = [&](int s, int r, const float (&m)[RW][5]) __attribute__((always_inline)) {
@@ -2250,35 +2430,40 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
 
+    // The R0 samples of a round -- rows a-1 .. a+RW-1: step 2 starts one row above step 1 -- are requested a round ahead as well (after the
+    // step 1 before; R0 does not depend on the flow).  With the R1 taps coming from LDS, a row then waits for nothing that is further away than LDS.
+    [[maybe_unused]] float r0n[RW + 1][5];
+    auto load_r0 = [&](int r) __attribute__((always_inline)) {
+        const int a = r * ca.S + off;
+#pragma unroll
+        for (int i = 0; i <= RW; i++) {
+            const unsigned so = (unsigned)clampi(a - 1 + i, 0, h - 1) * rb;
+#pragma unroll
+            for (int c = 0; c < 5; c++) r0n[i][c] = buf_ld(bR0, vx, so + c * pb);
+        }
+    };
+    if (!LAST1) load_r0(0);
+
     // lanes beyond the image edge take the border pixel's flow (see fix_l / fix_r); branch-free
     const bool wg_left = x0 < 2, wg_right = w + 1 - x0 < 63;  // wave-uniform: the workgroup has lanes left / right of the image
     auto border_flow = [&](float &fx, float &fy) __attribute__((always_inline)) {
-        if (LEAN) {
-            // only the first and the last tile column have such lanes; lanes 0, 1 <- lane 2 and (full last tile) lanes 62, 63 <- lane 61 as
-            // one DPP quad permutation each, confined to the quad by the row / bank masks
-            if (wg_left) {
-                fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0xEA, 0x1, 0x1, false));
-                fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0xEA, 0x1, 0x1, false));
-            }
-            if (wg_right) {
-                if (lane_r == 61) {
-                    fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0x54, 0x8, 0x8, false));
-                    fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0x54, 0x8, 0x8, false));
-                } else {
-                    const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
-                    const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane_r));
-                    fx = xr >= w ? rx : fx;
-                    fy = xr >= w ? ry : fy;
-                }
-            }
-            return;
+        // only the first and the last tile column have such lanes; lanes 0, 1 <- lane 2 and (full last tile) lanes 62, 63 <- lane 61 as
+        // one DPP quad permutation each, confined to the quad by the row / bank masks
+        if (wg_left) {
+            fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0xEA, 0x1, 0x1, false));
+            fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0xEA, 0x1, 0x1, false));
         }
-        const float lx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), 2));
-        const float ly = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), 2));
-        const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
-        const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane_r));
-        fx = xr < 0 ? lx : (xr >= w ? rx : fx);
-        fy = xr < 0 ? ly : (xr >= w ? ry : fy);
+        if (wg_right) {
+            if (lane_r == 61) {
+                fx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fx), __builtin_bit_cast(int, fx), 0x54, 0x8, 0x8, false));
+                fy = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fy), __builtin_bit_cast(int, fy), 0x54, 0x8, 0x8, false));
+            } else {
+                const float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane_r));
+                const float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane_r));
+                fx = xr >= w ? rx : fx;
+                fy = xr >= w ? ry : fy;
+            }
+        }
     };
     for (int r = 0; r < ca.rounds; r++) {
         const int a = r * ca.S + off;  // first step-1 row of this wavefront in this round
@@ -2308,12 +2493,21 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             stamp(r, 1);   // rows of the difference field requested
             chain(0, ticket, sum, P);
             stamp(r, 2);   // chain of step 1 passed
+            ring_fill(ticket + kRingLead);  // (holding the token: every reader of the rows this overwrites is done)
+            ring_wait(ticket);
+            stamp(r, 3);   // fill issued, the rows this ticket reads have landed
         }
         // Rows below the image repeat the last row (zero differences -> the same column sums -> the same flow -> the same M'):
         // exactly what d'_{h-1} = M'[h-1] - M'[h-3] wants of the row below the image.
+        [[maybe_unused]] float r0c[RW + 1][5];
+        if (!LAST1) {
+#pragma unroll
+            for (int i = 0; i <= RW; i++)
+#pragma unroll
+                for (int c = 0; c < 5; c++) r0c[i][c] = r0n[i][c];
+        }
         float m1[RW][5];
         float d2[RW][5];  // d'_t, t = a - 1 + i: rows a+i and a+i-3 of M'
-        float r0k[RW][5];  // the R0 samples of this wavefront's step-1 rows: step 2 visits the same rows one later (its first row is the row above)
         {
             Px q[RW];
             float fx1[RW], fy1[RW];
@@ -2339,10 +2533,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                     }
                     if (!LAST1) {
 #pragma unroll
-                        for (int c = 0; c < 5; c++) q[j].r0v[c] = buf_ld(bR0, vx, (unsigned)y * rb + c * pb);
+                        for (int c = 0; c < 5; c++) q[j].r0v[c] = r0c[j + 1][c];
                         q[j].tp = gather(x, y, fx1[j], fy1[j]);
                     }
-                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST1 && p >= DEPTH) {
                     const int j = p - DEPTH, y = min(a + j, h - 1);
@@ -2350,14 +2544,21 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #pragma unroll
                     for (int c = 0; c < 5; c++) {
                         m1[j][c] = mm.v[c];
-                        r0k[j][c] = q[j].r0v[c];
                         if (j >= 3) d2[j][c] = mm.v[c] - m1[j - 3][c];
                     }
-                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
+        if constexpr (RING) {
+            // this wavefront's fill is published here, a whole step after its issue.  (Where the memory system is busy -- the launch moves its 1.45 GB
+            // at 4.5 TB/s -- the loads take thousands of cycles to land; publishing two rows into step 2 instead only moved the wait: r05_experiments.md.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int l = fresh_lane();
+            lds_post(&ring.filled[wave], r + 1, l);
+        }
         if (SOLVE1 && r + 1 < ca.rounds) load_d(r + 1);  // this round's rows are used up: the next round's arrive during step 2
+        if (!LAST1 && r + 1 < ca.rounds) load_r0(r + 1);
         if (LAST1) continue;
         stamp(r, 4);   // M' complete
         put_boundary(0, r, m1);  // rows RW-3 .. RW-1 for the wavefront below
@@ -2372,7 +2573,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         // ---------------------------------------------------------------- step 2, rows a-1 .. a+RW-2, the same way from the column sums of M'
         {
             double sum[5];
-            if (!LEAN || a < 1 || a - 1 + RW > h) {  // (wave-uniform: only the first and the last rounds have such rows)
+            if (a < 1 || a - 1 + RW > h) {  // (wave-uniform: only the first and the last rounds have such rows)
 #pragma unroll
                 for (int i = 0; i < RW; i++) {
                     const int t = a - 1 + i;
@@ -2414,10 +2615,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                     } else {
                         // row a-1+i: its R0 samples are step 1's of row i-1 unless the row index was clamped there or here (first / last round)
 #pragma unroll
-                        for (int c = 0; c < 5; c++) q[i].r0v[c] = i == 0 ? buf_ld(bR0, vx, (unsigned)y * rb + c * pb) : r0k[i - 1][c];
+                        for (int c = 0; c < 5; c++) q[i].r0v[c] = r0c[i][c];
                         q[i].tp = gather(x, y, fx2[i], fy2[i]);
                     }
-                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST2 && p >= DEPTH) {
                     const int i = p - DEPTH, y = clampi(a - 1 + i, 0, h - 1);
@@ -2428,7 +2629,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         if (i == 1 && topw) m2[0][c] = mm.v[c];  // the row above row 0 is row 0
                         if (i >= 3) st_d3(mm.v[c] - m2[i - 3][c], i, c);
                     }
-                    if (SCHED) __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -2896,32 +3097,27 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     dim3 grid(g.tiles_x, 1, L.n);
     const int pitch = plane_pitch(w);
     const double scale = 1. / 9.;
-#define OFXCV_LAUNCH_COL_K(K1, K2, RW, NW, DEPTH) \
-    hipLaunchKernelGGL((iterate_col_kernel<K1, K2, RW, NW, DEPTH, true>), grid, dim3(64 * NW), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
-#define OFXCV_LAUNCH_COL(RW, NW, DEPTH)                                                                     \
-    do {                                                                                                \
-        if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, RW, NW, DEPTH);       \
-        else if (k1 == kHaloIter && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, RW, NW, DEPTH);  \
-        else if (k1 == kHaloLast && k2 == kColNone) OFXCV_LAUNCH_COL_K(kHaloLast, kColNone, RW, NW, DEPTH);    \
-        else if (k1 == kHaloZero && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloIter, RW, NW, DEPTH);  \
-        else if (k1 == kHaloZero && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloLast, RW, NW, DEPTH);  \
-        else if (k1 == kHaloCoarse && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloIter, RW, NW, DEPTH); \
-        else if (k1 == kHaloCoarse && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloLast, RW, NW, DEPTH); \
-        else if (k1 == kHaloGiven && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloIter, RW, NW, DEPTH); \
-        else if (k1 == kHaloGiven && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloLast, RW, NW, DEPTH); \
-        else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2); \
-    } while (0)
-#define OFXCV_COL_X(DEPTH) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, DEPTH, true, false, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
-    if (iter_pair && !ctx->fb_col_trace && ctx->fb_col_lean && ctx->fb_col_geom == 0) {  // experiment: reduced-instruction form, gather pipeline depth
-        if (ctx->fb_col_depth == 2) OFXCV_COL_X(2);
-        else if (ctx->fb_col_depth == 4) OFXCV_COL_X(4);
-        else OFXCV_COL_X(1);
-    }
-#undef OFXCV_COL_X
-    else if (iter_pair && ctx->fb_col_trace) hipLaunchKernelGGL((iterate_col_kernel<kHaloIter, kHaloIter, 4, 8, 1, true, true>), grid, dim3(512), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg);
-    else if (iter_pair && ctx->fb_col_geom == 1) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, 1);
-    else OFXCV_LAUNCH_COL(4, 8, 1);
-#undef OFXCV_LAUNCH_COL
+#define OFXCV_LAUNCH_COL_K(K1, K2, RW, NW, RING, TRACE) \
+    hipLaunchKernelGGL((iterate_col_kernel<K1, K2, RW, NW, RING, TRACE>), grid, dim3(64 * NW), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
+    // the R1 ring in LDS (option farneback.col_ring, default on): the steps pairs that open with an iteration -- the ring's fill schedule rides on the
+    // step-1 token -- in the eight-by-four geometry; everything else gathers from memory
+    const bool ring = ctx->fb_col_ring && g.nw == 8 && g.rw == 4;
+    if (iter_pair && ctx->fb_col_trace) {
+        if (ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
+        else OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, true);
+    } else if (iter_pair && g.nw == 12) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, false, false);
+    else if (k1 == kHaloIter && k2 == kHaloIter && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, false);
+    else if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, false);
+    else if (k1 == kHaloIter && k2 == kHaloLast && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, 4, 8, true, false);
+    else if (k1 == kHaloIter && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, 4, 8, false, false);
+    else if (k1 == kHaloLast && k2 == kColNone) OFXCV_LAUNCH_COL_K(kHaloLast, kColNone, 4, 8, false, false);
+    else if (k1 == kHaloZero && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloIter, 4, 8, false, false);
+    else if (k1 == kHaloZero && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloLast, 4, 8, false, false);
+    else if (k1 == kHaloCoarse && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloIter, 4, 8, false, false);
+    else if (k1 == kHaloCoarse && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloLast, 4, 8, false, false);
+    else if (k1 == kHaloGiven && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloIter, 4, 8, false, false);
+    else if (k1 == kHaloGiven && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloLast, 4, 8, false, false);
+    else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2);
 #undef OFXCV_LAUNCH_COL_K
     OFXCV_LAUNCH_CHECK(ctx, "iterate_col_kernel");
     return OFXCV_OK;

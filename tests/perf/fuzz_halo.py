@@ -5,7 +5,8 @@ running column sums the library has -- the serial column scan (farneback.opencv_
 the same flows bit for bit -- and so must the library's defaults (its own plan of which pairs of a call take which form) -- and no bounded wait may run out.  (All are within 1e-4 of the faithful oracle at every sample:
 tests/test_farneback_gpu.py, tests/perf/fuzz_sizes.py.)
 usage: python tests/perf/fuzz_halo.py [seed] [cases]"""
-import os, sys
+import faulthandler, os, sys
+faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import openfx_opencv_amd as ofxcv
@@ -32,12 +33,13 @@ for case in range(ncases):
         halo["farneback.halo_strip"] = int(rng.choice([33, 35, 36, 65, 68, 71, 72]))
     if rng.random() < 0.2:
         halo["farneback.batch_mb"] = int(rng.choice([1, 8, 40]))
-    col = {"farneback.col_min": 1, "farneback.col_geom": int(rng.integers(0, 2))}
+    col = {"farneback.col_min": 1, "farneback.col_geom": int(rng.integers(0, 2)), "farneback.col_ring": int(rng.integers(0, 2))}
     base = rng.integers(0, 256, size=(h + 24, w + 24), dtype=np.uint8)
     blur = (base[:-2, :-2].astype(np.int32) + base[1:-1, 1:-1] + base[2:, 2:]) // 3
     pa = [torch.from_numpy(np.ascontiguousarray(blur[i:i + h, i:i + w]).astype(np.uint8)).cuda() for i in range(n)]
     pb = [torch.from_numpy(np.ascontiguousarray(blur[i + 1:i + 1 + h, i + 2:i + 2 + w]).astype(np.uint8)).cuda() for i in range(n)]
     inits = [rng.normal(0, 2, size=(h, w, 2)).astype(np.float32) for _ in range(n)]
+    print("case %d: %dx%d n=%d %s %s %s" % (case, w, h, n, kw, halo, col), flush=True)
     outs, aborts = [], 0
     for opts in ({"farneback.opencv_rounding": 2}, halo, col, {}):
         c = ofxcv.Context(0)

@@ -314,7 +314,7 @@ def test_opencv_order_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx
 
 # the three evaluations of OpenCV's running sums the library has: mode 2 (serial column scan, the independent cross-check), the
 # overlapped-strip form and the column-owning form (farneback.col_min 1 forces it on every level of any frame)
-_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_geom=1))
+_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0), dict(col_min=1, col_geom=1))
 # strip / wavefront geometries of the overlapped-strip form the library otherwise picks by level size
 _HALO_GEOMS = (dict(halo_geom=1), dict(halo_geom=2), dict(halo_geom=3), dict(halo_geom=2, halo_strip=33), dict(halo_geom=2, halo_strip=35),
                dict(halo_geom=3, halo_strip=65), dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=70), dict(halo_geom=3, halo_strip=72),
@@ -456,6 +456,68 @@ def test_opencv_order_mode_wide_dynamic_range(oracle, strict_ctx):
     bad = err > REL_TOL * np.maximum(1, np.abs(ref))
     print("wide dynamic range: max err %.3g, outside %d, bit-identical %.6f" % (err.max(), bad.sum(), (ref == got).mean()))
     assert not bad.any(), "max err %g, %d samples outside" % (err.max(), bad.sum())
+
+
+def test_column_ring_window_and_fallback(ofxcv):
+    """The R1 ring of the column-owning form holds the rows and columns within +- 4 pixels of a pixel; a wavefront-row with a sample beyond that takes
+    the global gather.  Small motion (every gather from the ring), a 9 x 7 pixel shift (every gather from memory), a shift at the window's
+    edge (rows of both kinds) and a caller's noisy initial flow: ring on / off / overlapped strips agree bit for bit."""
+    import torch
+    rng = np.random.default_rng(7)
+    w, h = 700, 330
+    base = rng.integers(0, 256, size=(h + 40, w + 40), dtype=np.uint8)
+    blur = ((base[:-2, :-2].astype(np.int32) + base[1:-1, 1:-1] + base[2:, 2:]) // 3).astype(np.uint8)
+    crop = lambda dy, dx: _dev(np.ascontiguousarray(blur[20 + dy:20 + dy + h, 20 + dx:20 + dx + w]))
+    for name, (dy, dx), kw in (("small", (1, 1), dict()), ("large", (7, -9), dict()), ("edge", (4, -4), dict(iterations=5)),
+                               ("initial flow", (2, 1), dict(iterations=3, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW))):
+        pa, pb = [crop(0, 0), crop(1, 0)], [crop(dy, dx), crop(dy + 1, dx)]
+        init = [rng.normal(0, 3, size=(h, w, 2)).astype(np.float32) for _ in range(2)]
+        outs = []
+        for opts in (dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0)):
+            c = ofxcv.Context(0)
+            for k, v in opts.items():
+                c.set_option("farneback." + k, v)
+            fl = [torch.from_numpy(i0.copy()).cuda() for i0 in init] if "flags" in kw else None
+            outs.append([f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(pa, pb, fl, **kw)])
+            assert c.get_option("farneback.col_aborts") == 0
+            c.close()
+        for o in outs[1:]:
+            for z in range(2):
+                assert np.array_equal(outs[0][z], o[z]), (name, z)
+
+
+def test_column_forms_on_flat_bands_above_texture(oracle, ofxcv):
+    """the column-owning form hands `P + (d0 + d1 + d2 + d3)` to the next wavefront where OpenCV adds row by row; the two are the
+    same doubles only while no f64 addition rounds.  Frames with exactly flat and one-gray-level BANDS above full-contrast texture put values
+    many orders of magnitude apart into ONE column sum, where the additions do round: every form (serial scan, overlapped strips, column-owning
+    with the R1 ring and without, both row geometries) must still be within 1e-4 of the sequential oracle at EVERY sample; how many samples stay
+    bit-identical to the serial scan is printed (the forms re-associate f64 additions, nothing else)."""
+    from openfx_opencv_amd import synth
+    w, h = 333, 257
+    a, b = synth.flow_pair(w, h, seed=33)
+    ga, gb = oracle.to_byte_grayscale(a).astype(np.int32), oracle.to_byte_grayscale(b).astype(np.int32)
+    for g in (ga, gb):
+        g[: h // 4, :] = 128                                        # flat band
+        g[h // 4 : h // 2, :] = 128 + (g[h // 4 : h // 2, :] >> 7)  # one gray level of texture
+        g[h // 2 : h // 2 + 8, :] = 0                               # a black bar: zero matrices in the middle of every column
+    ga, gb = ga.astype(np.uint8), gb.astype(np.uint8)
+    ref = oracle.calc_optical_flow_farneback(ga, gb, iterations=6, blur_mode=oracle.BLUR_FAITHFUL)
+    da, db = _dev(ga), _dev(gb)
+    scan = None
+    for opts in _FORMS:
+        c = ofxcv.Context(0)
+        for k, v in opts.items():
+            c.set_option("farneback." + k, v)
+        got = c.calc_optical_flow_farneback_batch([da, da], [db, db], iterations=6)[1].cpu().numpy()
+        assert c.get_option("farneback.col_aborts") == 0
+        c.close()
+        err = np.abs(ref - got)
+        bad = err > REL_TOL * np.maximum(1, np.abs(ref))
+        if scan is None:
+            scan = got
+        print("flat bands, %-40s max err %.3g, outside %d, bit-identical to the oracle %.6f, to the serial scan %.6f"
+              % (opts, err.max(), bad.sum(), (ref == got).mean(), (scan == got).mean()))
+        assert not bad.any(), (opts, err.max(), bad.sum())
 
 
 def test_opencv_order_mode_other_parameters(oracle, strict_ctx):
@@ -618,7 +680,7 @@ def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
     w, h = 333, 257
     (a, b), (_, c) = _pairs(oracle, w, h, (5, 6))
     da, db, dc = _dev(a), _dev(b), _dev(c)
-    cases = [dict(opts=dict(opencv_rounding=1)), dict(opts=dict(opencv_rounding=1, col_min=1)), dict(opts=dict(opencv_rounding=1, col_min=1, col_geom=1)),
+    cases = [dict(opts=dict(opencv_rounding=1)), dict(opts=dict(opencv_rounding=1, col_min=1)), dict(opts=dict(opencv_rounding=1, col_min=1, col_ring=0)), dict(opts=dict(opencv_rounding=1, col_min=1, col_geom=1)),
              dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
              dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
              dict(opts=dict(opencv_rounding=1, halo_geom=2)), dict(opts=dict(opencv_rounding=1, halo_small=5))]
@@ -651,7 +713,7 @@ def test_batch_launch_groups(oracle, ofxcv, mb):
     ctx.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(col_min=1), dict(opencv_rounding=0), dict(col_min=1, col_geom=1), dict(opencv_rounding=2)])
+@pytest.mark.parametrize("opts", [dict(), dict(col_min=1), dict(col_min=1, col_ring=0), dict(opencv_rounding=0), dict(col_min=1, col_geom=1), dict(opencv_rounding=2)])
 def test_flow_to_rgba_fused_into_the_call(oracle, ofxcv, opts):
     """ofxcv_calc_optical_flow_farneback_batch_rgba: F7 rides on the launch that produces the final flow (overlapped strips: the default for these
     small batches; column-owning form: col_min 1) or is appended by the library (other window modes) -- the RGBA images equal ofxcv_flow_to_rgba applied to the returned flows bit for bit: all

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Which unit is busy while the vector ALU idles: PMC passes over one batched Farneback call (tools/ab_iter.py), counters picked from
 # what `rocprofv3 -L` lists on this box (names that do not exist are dropped instead of failing the pass), small sets per pass.
-# usage: pmc_attr.sh [--size WxH] [--batch N] [--opts "k=v,..."] [--tag T]      summary -> gpurun_out/pmc_attr/<tag>.txt
-SIZE=1920x1080; BATCH=8; OPTS=""; TAG=default
+# usage: pmc_attr.sh [--size WxH] [--batch N] [--opts "k=v,..."] [--tag T] [--sets "1 2 6"  (line numbers of the set list; default all)]      summary -> gpurun_out/pmc_attr/<tag>.txt
+SIZE=1920x1080; BATCH=8; OPTS=""; TAG=default; SETS=""
 while [ -n "$1" ]; do
-  case "$1" in --size) SIZE=$2; shift 2;; --batch) BATCH=$2; shift 2;; --opts) OPTS=$2; shift 2;; --tag) TAG=$2; shift 2;; *) break;; esac
+  case "$1" in --size) SIZE=$2; shift 2;; --batch) BATCH=$2; shift 2;; --opts) OPTS=$2; shift 2;; --tag) TAG=$2; shift 2;; --sets) SETS=$2; shift 2;; *) break;; esac
 done
 cd /tmp && export TMPDIR=/tmp
 RAW=/tmp/pmc_attr_$TAG; rm -rf $RAW; mkdir -p $RAW
@@ -41,6 +41,7 @@ cat $RAW/sets.txt > $OUT/${TAG}_sets.txt
 i=0
 while read -r set; do
   i=$((i+1))
+  if [ -n "$SETS" ] && ! echo " $SETS " | grep -q " $i "; then continue; fi
   timeout 240 rocprofv3 --pmc $set --output-format csv -d $RAW/p$i -o p -- python $GRAFT_REPO_ROOT/tools/ab_iter.py --size $SIZE --batch $BATCH --calls 1 "$OPTS" > $RAW/p$i.log 2>&1 || { echo "pass $i ($set) failed/timeout"; tail -3 $RAW/p$i.log; }
 done < $RAW/sets.txt
 python - "$RAW" "$OUT/${TAG}.txt" <<'PY'
