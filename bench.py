@@ -40,7 +40,7 @@ VALU_CLK_PER_WAVE_INSTR = 4.0
 VALU_ISSUE_PER_S = 1024 * 2.4e9 / VALU_CLK_PER_WAVE_INSTR
 # one iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
 ITER_BYTES_PER_PX = 80.0
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
 COL_W = 60  # columns a workgroup of iterate_col_kernel stores (csrc/farneback.hip: kColW)
 
 
@@ -528,7 +528,7 @@ def main():
         line["cpu_baseline"] = None
     if world == 1 and not args.no_extra_legs and (W, H) == (1920, 1080):
         try:
-            line.update(extra_legs(ofxcv, synth, torch, np, local_rank, not args.no_cpu_baseline))
+            line.update(extra_legs(ofxcv, synth, torch, np, local_rank, not args.no_cpu_baseline, args.direct_leg))
         except Exception as e:  # the headline must still be reported
             line["extra_legs_error"] = "%s: %s" % (type(e).__name__, e)
     print(json.dumps(line), flush=True)
@@ -536,7 +536,7 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
+def extra_legs(ofxcv, synth, torch, np, dev, with_cpu, direct_leg=False):
     """One leg per remaining BASELINE config, rank 0 at N = 1 only; every figure is a median of a few runs."""
     out = {}
     med = statistics.median
@@ -668,7 +668,7 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu):
         grays.append((c0.to_byte_grayscale(torch.from_numpy(a4).cuda()), c0.to_byte_grayscale(torch.from_numpy(b4).cuda())))
     torch.cuda.synchronize()
     del a4, b4
-    for direct, key in ((False, "value"), (True, "value_direct_window")):
+    for direct, key in ((False, "value"), (True, "value_direct_window")) if direct_leg else ((False, "value"),):
         ns, nb = (4, 1) if direct else (1, 8)
         cs = [ofxcv.Context(dev) for _ in range(ns)]
         bufs = []
