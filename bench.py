@@ -360,11 +360,18 @@ def main():
     strict_flow = bufs[0]["flow"][0].cpu().numpy()
     g_a, g_b = bufs[0]["ga"][0].cpu().numpy(), bufs[0]["gb"][0].cpu().numpy()
     col_aborts = ctxs[0].get_option("farneback.col_aborts")
-    one_in_flight = one_batch_in_flight = three_single = batch16 = None
+    one_in_flight = one_batch_in_flight = three_single = batch16 = lock_hold_us = lock_call_us = None
     if world == 1:
         n1 = max(10, args.steps // 2)
+        lh0 = ctxs[0].lock_hold()
         e1 = timed_regions(ctxs[:1], bufs[:1], n1, 3, 3)
+        lh1 = ctxs[0].lock_hold()
         one_batch_in_flight = n1 * B / statistics.median(e1)
+        # time inside the process-wide runtime lock (hipGraphLaunch of the call's captured launch sequence) per batched call: with G devices driven
+        # from ONE host process the lock is busy hold x G / call time of the time
+        lock_calls = 3 + 3 * n1  # warm-up + three regions
+        lock_hold_us = (lh1[0] - lh0[0]) / 1e3 / max(1, lock_calls)
+        lock_call_us = statistics.median(e1) / n1 * 1e6
         one = [{k: v[:1] for k, v in bufs[0].items()}]  # a single pair per call on one stream: what one unbatched caller gets
         e1 = timed_regions(ctxs[:1], one, n1, 3, 3)
         one_in_flight = n1 / statistics.median(e1)
@@ -457,6 +464,11 @@ def main():
         "value_one_batch_in_flight": one_batch_in_flight,  # one batched call of `pairs_per_batched_call` pairs at a time
         "value_three_single_pair_calls_in_flight": three_single,  # the configuration BENCH_r01 / BENCH_r02 quoted as `value`
         "value_batches_of_16": batch16,  # one batched call of 16 pairs at a time (the call's maximum)
+        "host_lock_hold_us_per_call": lock_hold_us,  # inside the process-wide runtime lock per batched call (its hipGraphLaunch)
+        "host_lock": None if lock_hold_us is None else {
+            "hold_us_per_batched_call": lock_hold_us, "call_us": lock_call_us, "utilisation_at_8_gpus_in_one_process": 8 * lock_hold_us / lock_call_us,
+            "note": "ofxcv_lock_hold: time a batched call of %d pairs spends inside the runtime lock (one hipGraphLaunch) / the call's GPU time; x 8 = how busy "
+                    "the ONE lock of a host process would be with eight devices (one process per GPU, as this benchmark's --gpus N, never meets it)" % B},
         "col_aborts": col_aborts,  # 1 if a bounded LDS wait of iterate_col_kernel ever ran out (never seen)
         "value_direct_window": statistics.median(drates) if drates else None,
         "value_direct_window_stats": None if not drates else dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "

@@ -34,12 +34,20 @@ typedef struct ofxcv_ctx ofxcv_ctx;
  * One context = one device + its scratch (pyramid / polynomial-expansion planes, LUT, pinned
  * staging, two streams).  A context serves one call at a time; concurrent render() threads
  * (VectorGenerator is eRenderFullySafe, VectorGenerator.cpp:108) each take their own. */
+/* Devices a host process can spread its render threads over (GenericOpenCVPlugin.cpp:350-357 / VectorGenerator.cpp:108: the reference is
+ * eRenderFullySafe, i.e. the host calls render() from many threads).  Environment OFXCV_VIRTUAL_DEVICES=N presents N logical devices over
+ * the physical ones (logical d -> physical d % count): the per-device state of a multi-GPU host process -- render threads' device choice,
+ * per-device runtime lock, per-device caches of named frames -- then runs on a one-GPU box (tests, soak tools). */
 int ofxcv_device_count(void);
 int ofxcv_ctx_create(int device, ofxcv_ctx **out);
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx);
 const char *ofxcv_last_error(const ofxcv_ctx *ctx);
 const char *ofxcv_status_string(int status);
 int ofxcv_ctx_device(const ofxcv_ctx *ctx);
+/* measurement: nanoseconds this context's Farneback calls have held the process-wide (or per-device) runtime lock exclusively -- stream capture
+ * + graph instantiation, hipGraphLaunch -- and the number of such holds.  hold x devices / call time = what the lock allows an in-process multi-GPU
+ * host */
+int ofxcv_lock_hold(const ofxcv_ctx *ctx, long *ns, long *holds);
 /* the context's compute stream (hipStream_t), used whenever a `stream` argument is NULL */
 void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
 /* hipStreamSynchronize on the context's compute stream (or on `stream` if non-NULL); OFXCV_ERR_HIP if a bounded wait of the

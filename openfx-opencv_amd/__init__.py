@@ -58,7 +58,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
-    "ofxcv_ctx_device", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_to_byte_grayscale_batch", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
+    "ofxcv_ctx_device", "ofxcv_lock_hold", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_to_byte_grayscale_batch", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
     "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_col_pairs", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
@@ -103,7 +103,7 @@ class Context:
             raise OfxcvError(rc, lib().ofxcv_status_string(rc).decode())
         self.device = device
         import torch
-        self.stream = torch.cuda.ExternalStream(lib().ofxcv_ctx_stream(self._h), device=device)
+        self.stream = torch.cuda.ExternalStream(lib().ofxcv_ctx_stream(self._h), device=device % max(1, torch.cuda.device_count()))  # (logical -> physical: OFXCV_VIRTUAL_DEVICES)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -122,6 +122,12 @@ class Context:
 
     def synchronize(self):
         self._check(lib().ofxcv_ctx_synchronize(self._h, None))
+
+    def lock_hold(self):
+        """(nanoseconds, holds): time this context's Farneback calls have held the runtime lock exclusively"""
+        ns, n = C.c_long(), C.c_long()
+        self._check(lib().ofxcv_lock_hold(self._h, C.byref(ns), C.byref(n)))
+        return ns.value, n.value
 
     def set_option(self, name, value):
         self._check(lib().ofxcv_ctx_set_option(self._h, name.encode(), C.c_int(int(value))))

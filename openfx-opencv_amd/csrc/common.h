@@ -41,7 +41,9 @@ struct FbGraph {
 };
 
 struct ofxcv_ctx {
-    int device = 0;
+    int device = 0;      // LOGICAL device: index of the runtime lock (OFXCV_LOCK_PER_DEVICE) and of the per-device caches
+    int hip_device = 0;  // the HIP device behind it (OFXCV_VIRTUAL_DEVICES=N maps N logical devices onto the physical ones: device % physical count)
+    long lock_hold_ns = 0, lock_holds = 0;  // time this context's Farneback calls spent holding the runtime lock exclusively (graph capture / launch)
     hipStream_t compute = nullptr;  // default stream for kernels when the caller passes NULL
     hipStream_t copy = nullptr;     // H2D / D2H staging stream of the host-buffer entry points
     hipEvent_t ev_h2d[3] = {nullptr, nullptr, nullptr};

@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <new>
 
+#include <algorithm>
 #include "common.h"
 
 int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
@@ -125,10 +126,20 @@ int ofxcv_cv_round(double v) { return (int)std::lrint(v); }
 
 extern "C" {
 
-int ofxcv_device_count(void) {
+// OFXCV_VIRTUAL_DEVICES=N (> 0): N LOGICAL devices over the physical ones (logical d -> physical d % count).  Everything that is per device in
+// a host process -- the render threads' device choice, the per-device runtime lock (OFXCV_LOCK_PER_DEVICE=1), the per-device caches of named
+// frames -- then runs as on an N-GPU node on a box with one GPU (tests, tools/bench_host_threads.py --devices N).
+static int ofxcv_physical_devices() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+int ofxcv_device_count(void) {
+    const int n = ofxcv_physical_devices();
+    if (n <= 0) return 0;
+    const char *e = std::getenv("OFXCV_VIRTUAL_DEVICES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? std::min(v, 64) : n;
 }
 
 const char *ofxcv_status_string(int status) {
@@ -146,11 +157,12 @@ const char *ofxcv_status_string(int status) {
 int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     if (!out) return OFXCV_ERR_INVALID;
     *out = nullptr;
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OFXCV_ERR_NO_DEVICE;
+    const int n = ofxcv_physical_devices();
+    if (n <= 0 || device < 0 || device >= ofxcv_device_count()) return OFXCV_ERR_NO_DEVICE;
     ofxcv_ctx *ctx = new (std::nothrow) ofxcv_ctx();
     if (!ctx) return OFXCV_ERR_MEMORY;
     ctx->device = device;
+    ctx->hip_device = device % n;
     if (const char *e = getenv("OFXCV_FARNEBACK_WINDOW")) {  // lets a plugin user pick the window evaluation without a new parameter
         if (!std::strcmp(e, "direct")) ctx->fb_opencv_rounding = 0;
         else if (!std::strcmp(e, "opencv")) ctx->fb_opencv_rounding = 1;
@@ -160,8 +172,8 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     auto init = [&]() -> int {
         // stream creation changes the runtime's stream list, which another thread's hipGraphLaunch walks: under the runtime lock
         std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(device));
-        OFXCV_HIP_CHECK(ctx, hipSetDevice(device));
-        OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device));
+        OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
+        OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, ctx->hip_device));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
         for (int i = 0; i < 3; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
@@ -180,7 +192,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
 
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    (void)hipSetDevice(ctx->hip_device);
     std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
     (void)ofxcv_ctx_quiesce(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
@@ -217,6 +229,14 @@ long ofxcv_inpaint_fallback_count(const ofxcv_ctx *ctx) { return ctx ? ctx->ip_f
 const char *ofxcv_last_error(const ofxcv_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
 int ofxcv_ctx_device(const ofxcv_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+// measurement: nanoseconds this context's Farneback calls have held the runtime lock exclusively, and how many times
+int ofxcv_lock_hold(const ofxcv_ctx *ctx, long *ns, long *holds) {
+    if (!ctx || !ns || !holds) return OFXCV_ERR_INVALID;
+    *ns = ctx->lock_hold_ns;
+    *holds = ctx->lock_holds;
+    return OFXCV_OK;
+}
 
 void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute : nullptr; }
 
@@ -345,7 +365,7 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
         // the abort word of the column-owning kernel (waits for the context's streams first); reading it through this getter does not clear it
         *value = 0;
         if (ctx->fb_col_abort) {
-            if (hipSetDevice(ctx->device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK) return OFXCV_ERR_HIP;
+            if (hipSetDevice(ctx->hip_device) != hipSuccess || ofxcv_ctx_quiesce(const_cast<ofxcv_ctx *>(ctx)) != OFXCV_OK) return OFXCV_ERR_HIP;
             *value = (int)(*(volatile unsigned *)ctx->fb_col_abort | (ctx->fb_col_aborts_seen ? 1u : 0u));
         }
     }

@@ -20,6 +20,7 @@
 // The one deliberate difference: OpenCV's box window keeps running sums (and rounds each row
 // difference to f32 before accumulating it); here each pixel sums its own 3x3 window in f64.
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <type_traits>
@@ -3156,7 +3157,7 @@ int ofxcv_farneback_plane_pitch(int width) { return plane_pitch(width); }
 // launch left (option "farneback.col_trace" 1); n 64-bit words
 int ofxcv_debug_col_trace(ofxcv_ctx *ctx, unsigned long long *out, int n) {
     if (!ctx || !out || !ctx->fb_col_flag.ptr || (size_t)n * 8 + 256 > ctx->fb_col_flag.bytes) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     int rc = ofxcv_ctx_quiesce(ctx);
     if (rc) return rc;
     OFXCV_HIP_CHECK(ctx, hipMemcpy(out, (char *)ctx->fb_col_flag.ptr + 256, (size_t)n * 8, hipMemcpyDeviceToHost));
@@ -3176,7 +3177,7 @@ int ofxcv_farneback_level_geom(int width, int height, double pyr_scale, int k, i
 int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step, int width, int height, int lw, int lh,
                               double sigma, int ksize, float *d_I, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_img || !d_I || width <= 0 || height <= 0 || lw <= 0 || lh <= 0 || ksize < 1 || !(ksize & 1) || step < (size_t)width)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_pyr_image: bad argument");
     int rc = ofxcv_reserve(ctx, ctx->fb_tmp, sizeof(float) * ((size_t)(2 * lw + 2) * height));
@@ -3191,7 +3192,7 @@ int ofxcv_farneback_pyr_image(ofxcv_ctx *ctx, const uint8_t *d_img, size_t step,
 int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int height, float *d_R, int poly_n, double poly_sigma,
                             void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_I || !d_R || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_polyexp: bad argument");
     return launch_polyexp(ctx, ofxcv_stream(ctx, stream), d_I, width, height, d_R, poly_n, poly_sigma, 1, 0, 0, 0, false);
 }
@@ -3199,7 +3200,7 @@ int ofxcv_farneback_polyexp(ofxcv_ctx *ctx, const float *d_I, int width, int hei
 int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_flow, size_t flow_step,
                                     int width, int height, float *d_M, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_R0 || !d_R1 || !d_flow || !d_M || width <= 0 || height <= 0 || (flow_step & 7))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_matrices: bad argument");
     hipLaunchKernelGGL(update_matrices_kernel<2>, dim3(ofxcv_div_up(width, 64), ofxcv_div_up(height, 4)), dim3(64, 4), 0,
@@ -3212,7 +3213,7 @@ int ofxcv_farneback_update_matrices(ofxcv_ctx *ctx, const float *d_R0, const flo
 int ofxcv_farneback_update_flow_blur(ofxcv_ctx *ctx, const float *d_R0, const float *d_R1, const float *d_M_in, float *d_M_out,
                                      float *d_flow, size_t flow_step, int width, int height, int winsize, int update, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_M_in || width <= 0 || height <= 0 || winsize < 1 || !(winsize & 1) || (d_flow && (flow_step & 7)) ||
         (update && (!d_R0 || !d_R1 || !d_M_out || d_M_out == d_M_in)) || (!update && !d_flow))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback_update_flow_blur: bad argument");
@@ -3499,7 +3500,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
                                                  const ptrdiff_t *rgba_row_bytes, const unsigned *chan_u_mask, const unsigned *chan_v_mask,
                                                  double render_scale_x, double render_scale_y, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (n < 1 || n > kMaxBatch) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: batch of %d pairs outside 1..%d", n, kMaxBatch);
     if (!d_prev || !prev_step || !d_next || !next_step || !d_flow || !flow_step || width <= 0 || height <= 0)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "calc_optical_flow_farneback: bad argument");
@@ -3615,6 +3616,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         // during it (ofxcv_capture_mutex): either was seen to invalidate a capture on ROCm 7.2.  Launches, copies
         // and graph replays of other threads stay concurrent.
         std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex(ctx->device));
+        const auto hold0 = std::chrono::steady_clock::now();
         if (slot->exec) {  // evicted entry: destroyed under the exclusive lock (see common.h)
             (void)hipGraphExecDestroy(slot->exec);
             slot->exec = nullptr;
@@ -3626,6 +3628,8 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
             if (ok) ok = hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
         }
+        ctx->lock_hold_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hold0).count();
+        ctx->lock_holds++;
         capture_lock.unlock();
         if (!ok) {
             // plain launches from here on, all on the caller's stream (the preparation stream may have been left in
@@ -3645,7 +3649,11 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         // hip::Graph::UpdateStreams on ROCm 7.2 -- about 1 in 30 runs of four concurrent render threads, backtrace under
         // rocgdb with every other locked operation parked on this lock
         std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex(ctx->device));
-        OFXCV_HIP_CHECK(ctx, hipGraphLaunch(g->exec, s));
+        const auto hold0 = std::chrono::steady_clock::now();
+        const hipError_t le = hipGraphLaunch(g->exec, s);
+        ctx->lock_hold_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hold0).count();
+        ctx->lock_holds++;
+        OFXCV_HIP_CHECK(ctx, le);
     }
     return OFXCV_OK;
 }

@@ -864,7 +864,7 @@ extern "C" {
 int ofxcv_inpaint_mask(ofxcv_ctx *ctx, const uint8_t *d_rgba, ptrdiff_t row_bytes, int width, int height, int dilate_iters,
                        uint8_t *d_mask, ptrdiff_t mask_step, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_rgba || !d_mask || width <= 0 || height <= 0 || dilate_iters < 0 || mask_step < width || (((uintptr_t)d_rgba | (uintptr_t)row_bytes) & 3))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_mask: bad argument");
     int rc = ofxcv_reserve(ctx, ctx->ip_tmp, (size_t)width * height);
@@ -884,7 +884,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
                   ptrdiff_t mask_step, int width, int height, double radius, int method, uint8_t *d_dst, ptrdiff_t dst_step,
                   float *d_t_map, int *d_order_map, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_src || !d_mask || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4) || d_src == d_dst)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint: bad argument");
     if (method != OFXCV_INPAINT_NS && method != OFXCV_INPAINT_TELEA)
@@ -1212,7 +1212,7 @@ int ofxcv_inpaint_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
                               double dilation, uint8_t *h_dst, ptrdiff_t dst_row_bytes, uint8_t *h_mask_out) {
     if (!ctx) return OFXCV_ERR_INVALID;
     if (!h_src || !h_dst || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint_render_host: bad argument");
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     hipStream_t s = ctx->compute;
     const int w = width, h = height;
     const size_t row = (size_t)w * 4, img = align_up(row * h, 256), msk = align_up((size_t)w * h, 256);

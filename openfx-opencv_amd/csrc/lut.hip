@@ -172,7 +172,7 @@ extern "C" {
 int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_row_bytes, int ncomp, int width,
                             int height, uint8_t *d_dst, ptrdiff_t dst_row_bytes, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_src || !d_dst || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "to_byte_grayscale: bad argument");
     if (ncomp != 3 && ncomp != 4) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "to_byte_grayscale: RGB or RGBA only");
     hipStream_t s = ofxcv_stream(ctx, stream);
@@ -206,7 +206,7 @@ int ofxcv_to_byte_grayscale_batch(ofxcv_ctx *ctx, int n, const float *const *d_s
         }
         return OFXCV_OK;
     }
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     hipStream_t s = ofxcv_stream(ctx, stream);
     int rc = ensure_lut(ctx, s);
     if (rc) return rc;
@@ -226,7 +226,7 @@ int ofxcv_flow_to_rgba(ofxcv_ctx *ctx, const float *d_flow, size_t flow_step, in
                        ptrdiff_t dst_row_bytes, unsigned chan_u_mask, unsigned chan_v_mask, double render_scale_x,
                        double render_scale_y, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_flow || !d_dst || width <= 0 || height <= 0 || (flow_step & 7) || render_scale_x == 0 || render_scale_y == 0)
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "flow_to_rgba: bad argument");
     return ofxcv_launch_flow_to_rgba(ctx, ofxcv_stream(ctx, stream), d_flow, flow_step, width, height, d_dst, dst_row_bytes, chan_u_mask, chan_v_mask,

@@ -218,7 +218,7 @@ int ofxcv_pyr_mean_shift_filtering(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff
                                    double sp, double sr, int max_level, int max_iter, double eps, uint8_t *d_dst, ptrdiff_t dst_step,
                                    void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // a thread may hold contexts on several devices
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));  // a thread may hold contexts on several devices
     if (!d_src || !d_dst || width <= 0 || height <= 0 || (channels != 3 && channels != 4))
         return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "pyr_mean_shift_filtering: bad argument");
     if (max_level < 0 || max_level > 8) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "pyr_mean_shift_filtering: max_level outside 0..8");
@@ -287,7 +287,7 @@ int ofxcv_segment_render_host(ofxcv_ctx *ctx, const uint8_t *h_src, ptrdiff_t sr
                               int max_level, uint8_t *h_dst, ptrdiff_t dst_row_bytes) {
     if (!ctx) return OFXCV_ERR_INVALID;
     if (!h_src || !h_dst || width <= 0 || height <= 0) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "segment_render_host: bad argument");
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     hipStream_t s = ctx->compute;
     const size_t row = (size_t)width * 4, img = align_up(row * height, 256);
     int rc = ofxcv_reserve(ctx, ctx->ip_img, 2 * img);

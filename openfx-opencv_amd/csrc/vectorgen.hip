@@ -417,7 +417,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
                       const ptrdiff_t other_row_bytes[2], int ncomp, int width, int height, float *h_dst, ptrdiff_t dst_row_bytes,
                       const unsigned chan_u_mask[2], const unsigned chan_v_mask[2], double render_scale_x, double render_scale_y,
                       int levels, int iterations, int poly_n, double poly_sigma, const char *const keys[3] = nullptr) {
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
     if (ctx->host_register == 2) {  // opt-in: the host's buffers registered for the call, the kernel stores into the host image
@@ -740,7 +740,7 @@ extern "C" int ofxcv_host_cache_stats(ofxcv_ctx *ctx, size_t *bytes, int *frames
 }
 extern "C" int ofxcv_host_cache_clear(ofxcv_ctx *ctx) {
     if (!ctx) return OFXCV_ERR_INVALID;
-    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     GrayCache::of(ctx->device).clear(ctx);
     return OFXCV_OK;
 }

@@ -3,6 +3,8 @@
 // (opencv2fx.cpp:60-94) and a per-thread lease of libofxcv_hip contexts.
 #pragma once
 #include <atomic>
+#include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -165,23 +167,46 @@ struct ImageGuard {
     ImageGuard &operator=(const ImageGuard &) = delete;
 };
 
-// One libofxcv_hip context per calling host thread (render may be called concurrently: VectorGenerator is
-// eRenderFullySafe).  Threads are spread round-robin over the visible devices; the context lives as long as
+// One libofxcv_hip context per calling host thread AND device (render may be called concurrently: VectorGenerator is
+// eRenderFullySafe, VectorGenerator.cpp:108).  Which device: threads are spread round-robin over the visible devices -- unless the
+// caller asks for one (get(device)): frames that travel with names (kOfxImagePropUniqueIdentifier) stay on the device they were
+// uploaded to, so VectorGenerator sends BLOCKS of consecutive frame times to the same device whatever thread renders them
+// (device_for_time) and a sequence's frames are found again on an 8-GPU node as they are on one GPU.  The contexts live as long as
 // the thread.  A HIP failure maps to kOfxStatFailed / kOfxStatErrMemory.
 class ThreadContext {
   public:
-    static ofxcv_ctx *get() {
+    static constexpr int kMaxDevices = 64;
+    // the device of a named frame time: blocks of OFXCV_FRAMES_PER_DEVICE (default 16) consecutive frames per device, round-robin
+    static int device_for_time(double time) {
+        const int n = ofxcv_device_count();
+        if (n <= 1) return 0;
+        static const int per = [] {
+            const char *e = std::getenv("OFXCV_FRAMES_PER_DEVICE");
+            const int v = e ? std::atoi(e) : 0;
+            return v > 0 ? v : 16;
+        }();
+        const long blk = (long)std::floor(time / per);
+        return (int)(((blk % n) + n) % n);
+    }
+    static ofxcv_ctx *get(int device = -1) {
         thread_local Holder h;
         std::lock_guard<std::mutex> lock(h.mu);  // uncontended except against release_all()
-        if (!h.ctx) {
-            static std::atomic<int> next{0};
-            int n = ofxcv_device_count();
-            if (n <= 0) throw SuiteError(kOfxStatFailed);
-            int rc = ofxcv_ctx_create(next.fetch_add(1) % n, &h.ctx);
+        const int n = ofxcv_device_count();
+        if (n <= 0) throw SuiteError(kOfxStatFailed);
+        if (device < 0) {
+            if (h.home < 0) {
+                static std::atomic<int> next{0};
+                h.home = next.fetch_add(1);
+            }
+            device = h.home % n;
+        }
+        device = (device % n) % kMaxDevices;
+        if (!h.ctx[device]) {
+            int rc = ofxcv_ctx_create(device, &h.ctx[device]);
             if (rc == OFXCV_ERR_MEMORY) throw std::bad_alloc();
             if (rc != OFXCV_OK) throw SuiteError(kOfxStatFailed);
         }
-        return h.ctx;
+        return h.ctx[device];
     }
     // OfxActionUnload: the host guarantees no render is in flight; every context this plugin binary created on any
     // thread is destroyed (streams, scratch, pinned staging, registrations), threads that render again re-create theirs
@@ -189,17 +214,19 @@ class ThreadContext {
         std::lock_guard<std::mutex> lock(registry_mu());
         for (Holder *h : registry()) {
             std::lock_guard<std::mutex> hl(h->mu);
-            if (h->ctx) {
-                (void)ofxcv_host_cache_clear(h->ctx);  // the named frames kept on its device (no call is using any: nothing is in flight)
-                ofxcv_ctx_destroy(h->ctx);
-            }
-            h->ctx = nullptr;
+            for (ofxcv_ctx *&c : h->ctx)
+                if (c) {
+                    (void)ofxcv_host_cache_clear(c);  // the named frames kept on its device (no call is using any: nothing is in flight)
+                    ofxcv_ctx_destroy(c);
+                    c = nullptr;
+                }
         }
     }
 
   private:
     struct Holder {
-        ofxcv_ctx *ctx = nullptr;
+        ofxcv_ctx *ctx[kMaxDevices] = {};
+        int home = -1;  // this thread's place in the round-robin over the devices
         std::mutex mu;
         Holder() {
             std::lock_guard<std::mutex> lock(registry_mu());
@@ -215,7 +242,8 @@ class ThreadContext {
                         break;
                     }
             }
-            if (ctx) ofxcv_ctx_destroy(ctx);
+            for (ofxcv_ctx *c : ctx)
+                if (c) ofxcv_ctx_destroy(c);
         }
     };
     static std::mutex &registry_mu() { static std::mutex m; return m; }

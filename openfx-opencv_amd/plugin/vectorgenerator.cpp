@@ -221,7 +221,7 @@ void fail_with_message(OfxImageEffectHandle effect, const char *text) {  // setP
 }
 
 // one direction of calcOpticalFlow (:353-520): `mu`/`mv` = RGBA channels receiving flow.x / flow.y
-void calc_optical_flow(OfxImageEffectHandle effect, const Image &ref, const Image &other, const Image &dst, const OfxRectI &rw,
+void calc_optical_flow(OfxImageEffectHandle effect, double time, const Image &ref, const Image &other, const Image &dst, const OfxRectI &rw,
                        double rsx, double rsy, unsigned mu, unsigned mv, int levels, int iterations, int poly_n, double poly_sigma) {
     if (ref.depth != kOfxBitDepthFloat || other.depth != kOfxBitDepthFloat || dst.depth != kOfxBitDepthFloat) throw SuiteError(kOfxStatErrImageFormat);
     int ncomp = ref.components == kOfxImageComponentRGBA ? 4 : (ref.components == kOfxImageComponentRGB ? 3 : 0);
@@ -235,7 +235,8 @@ void calc_optical_flow(OfxImageEffectHandle effect, const Image &ref, const Imag
     const int x1 = std::max(std::max(rw.x1, ref.bounds.x1), dst.bounds.x1), x2 = std::min(std::min(rw.x2, ref.bounds.x2), dst.bounds.x2);
     const int y1 = std::max(std::max(rw.y1, ref.bounds.y1), dst.bounds.y1), y2 = std::min(std::min(rw.y2, ref.bounds.y2), dst.bounds.y2);
     if (x1 >= x2 || y1 >= y2) return;
-    ofxcv_ctx *ctx = ThreadContext::get();
+    // named frames: the device of this frame time's block (they are found again there whatever thread renders the neighbouring frames)
+    ofxcv_ctx *ctx = ThreadContext::get(ref.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
     if (x1 == ref.bounds.x1 && y1 == ref.bounds.y1 && x2 == ref.bounds.x2 && y2 == ref.bounds.y2) {
         float *d0 = (float *)((char *)dst.data + (ptrdiff_t)(y1 - dst.bounds.y1) * dst.row_bytes) + (size_t)(x1 - dst.bounds.x1) * 4;
         // (the frames with the names the host gives their pixels, as in the two-direction call of render())
@@ -308,7 +309,7 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
                 if (ch[i] == 3) bu |= 1u << i;
                 if (ch[i] == 4) bv |= 1u << i;
             }
-            ofxcv_ctx *ctx = ThreadContext::get();
+            ofxcv_ctx *ctx = ThreadContext::get(r.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
             float *d0 = (float *)((char *)o.data + (ptrdiff_t)(r.bounds.y1 - o.bounds.y1) * o.row_bytes) + (size_t)(r.bounds.x1 - o.bounds.x1) * 4;
             // The frames travel with the names the host gives their pixels (kOfxImagePropUniqueIdentifier; "" = none): rendering
             // frame t+1 after frame t finds two of its three source frames on the device already.  A name covers the whole image:
@@ -329,7 +330,7 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
             if (ch[i] == 1) mu |= 1u << i;
             if (ch[i] == 2) mv |= 1u << i;
         }
-        calc_optical_flow(effect, ref.img, other.img, dst.img, rw, rs[0], rs[1], mu, mv, levels, iterations, poly_n, poly_sigma);
+        calc_optical_flow(effect, time, ref.img, other.img, dst.img, rw, rs[0], rs[1], mu, mv, levels, iterations, poly_n, poly_sigma);
     }
     if (backward) {
         ImageGuard other(g, d->srcClip, time - 1);
@@ -339,7 +340,7 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
             if (ch[i] == 3) mu |= 1u << i;
             if (ch[i] == 4) mv |= 1u << i;
         }
-        calc_optical_flow(effect, ref.img, other.img, dst.img, rw, rs[0], rs[1], mu, mv, levels, iterations, poly_n, poly_sigma);
+        calc_optical_flow(effect, time, ref.img, other.img, dst.img, rw, rs[0], rs[1], mu, mv, levels, iterations, poly_n, poly_sigma);
     }
     return kOfxStatOK;
 }

@@ -354,6 +354,41 @@ def test_vectorgenerator_render_through_ofx(host, oracle):
 
 
 @pytest.mark.gpu
+def test_vectorgenerator_named_frames_follow_their_block_across_devices(host, monkeypatch):
+    """with several devices the plugin sends BLOCKS of 16 consecutive frame times to one device when the host names its
+    images (a named frame stays on the device it was uploaded to), instead of whatever device the calling thread happens to own.  Two logical
+    devices over the one GPU (OFXCV_VIRTUAL_DEVICES): output frame 16 (block 1 -> device 1) leaves frames 15, 16, 17 on device 1; frame 16's pixels
+    then change under the SAME name; output frame 15 (block 0 -> device 0) has never seen the name there and uploads the new pixels, output frame 17
+    (block 1) finds the old ones on its device -- the contract of the identifier, per device."""
+    from openfx_opencv_amd import synth
+    w, h = 288, 160
+    seq = {u: synth.flow_pair(w, h, seed=300 + u)[0].copy() for u in range(13, 20)}
+    pl = Plugin(host, "VectorGenerator")
+
+    def render(inst, t, named):
+        out = np.full((h, w, 4), -9.0, np.float32)
+        for u in (t - 1, t, t + 1):
+            pl.set_image(inst, "Source", float(u), seq[u], "OfxBitDepthFloat")
+            if named:
+                assert host.mh_set_image_id(inst, b"Source", C.c_double(float(u)), ("ofxcv-blocks-%d" % u).encode()) == 0
+        pl.set_image(inst, "Output", float(t), out, "OfxBitDepthFloat")
+        assert pl.render(inst, float(t), w, h) == STAT_OK
+        return out
+
+    monkeypatch.setenv("OFXCV_VIRTUAL_DEVICES", "2")
+    inst = pl.instance()
+    old17 = render(inst, 17, False)                      # (unnamed renders: the pixels as they are)
+    first16 = render(inst, 16, True)                     # names 15, 16, 17 now live on device 1
+    assert np.array_equal(first16, render(inst, 16, False))
+    seq[16][...] = synth.flow_pair(w, h, seed=999)[0]    # new pixels under the old name
+    new15 = render(inst, 15, False)
+    assert np.array_equal(render(inst, 15, True), new15)       # block 0 = device 0: the name is new there, the new pixels are uploaded
+    assert np.array_equal(render(inst, 17, True), old17)       # block 1 = device 1: frame 16 is found there, old pixels
+    assert not np.array_equal(render(inst, 17, False), old17)
+    pl.destroy(inst)
+
+
+@pytest.mark.gpu
 def test_vectorgenerator_sequence_with_image_identifiers(host):
     """A host that names its images' pixels (kOfxImagePropUniqueIdentifier): rendering the frames of a sequence one after the
     other through the OFX boundary gives the frames a host without identifiers gets.  That the names reach the library (whose

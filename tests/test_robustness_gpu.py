@@ -278,6 +278,44 @@ def test_host_path_split_form_gives_the_same_frame(ofxcv):
         assert np.array_equal(o, outs[(1, 0, key[2])]), key
 
 
+def test_virtual_devices_have_their_own_caches_and_locks(ofxcv, monkeypatch):
+    """OFXCV_VIRTUAL_DEVICES=N: N logical devices over the one physical GPU -- what is per device in a multi-GPU
+    host process (contexts, the cache of named frames, with OFXCV_LOCK_PER_DEVICE the runtime lock) runs here as on an N-GPU node: a frame
+    named on logical device 0 is NOT found on device 1, results are the same on every device, and the lock-hold counter of a context counts
+    its graph launches."""
+    from openfx_opencv_amd import synth
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("written for the one-GPU box")
+    monkeypatch.setenv("OFXCV_VIRTUAL_DEVICES", "3")
+    assert ofxcv.lib().ofxcv_device_count() == 3
+    w, h = 256, 144
+    seq = [synth.flow_pair(w, h, seed=70 + i)[0] for i in range(3)]
+    ctxs = [ofxcv.Context(d) for d in range(3)]
+    with pytest.raises(ofxcv.OfxcvError):
+        ofxcv.Context(3)
+    for c in ctxs:
+        c.host_cache_clear()
+    outs = []
+    for c in ctxs:
+        o = np.zeros((h, w, 4), np.float32)
+        c.vectorgen_flows_host(seq[1], seq[2], seq[0], o, 1, 2, 4, 8, keys=("vd:1", "vd:2", "vd:0"))
+        outs.append(o)
+        assert (c.host_cache_misses(), c.host_cache_hits()) == (3, 0)   # every logical device uploads for itself
+        assert c.host_cache_stats()[1] == 3
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    o = np.zeros((h, w, 4), np.float32)
+    ctxs[1].vectorgen_flows_host(seq[1], seq[2], seq[0], o, 1, 2, 4, 8, keys=("vd:1", "vd:2", "vd:0"))
+    assert ctxs[1].host_cache_hits() == 3 and np.array_equal(o, outs[0])
+    ns, holds = ctxs[1].lock_hold()
+    assert holds >= 2 and ns > 0
+    for c in ctxs:
+        c.host_cache_clear()
+        c.close()
+    monkeypatch.delenv("OFXCV_VIRTUAL_DEVICES")
+    assert ofxcv.lib().ofxcv_device_count() == 1
+
+
 def test_named_frames_stay_on_the_device(ofxcv):
     """ofxcv_vectorgen_flows_host_keyed: a frame whose name was seen before (same geometry, same device) is neither uploaded nor
     converted again -- rendering a sequence in order uploads ONE frame per output frame instead of three -- and the output is

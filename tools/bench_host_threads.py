@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """ofxcv_vectorgen_flows_host (default output frame = 2 flows, one batched call) with 1 / 2 / 4 / 8 calling threads, one
-context each, every thread rendering for --seconds.  --devices N spreads the contexts round-robin over N GPUs of the box
-(in-process multi-GPU: what an OFX host with eRenderFullySafe render threads does).
+context each, every thread rendering for --seconds.  --devices N spreads the contexts round-robin over N devices
+(in-process multi-GPU: what an OFX host with eRenderFullySafe render threads does); more devices than the box has are LOGICAL devices over
+the physical ones (OFXCV_VIRTUAL_DEVICES, set here): per-device locks (OFXCV_LOCK_PER_DEVICE=1) and per-device caches of named frames run as
+on an N-GPU node.  With --sequence the frames go to devices the way the VectorGenerator plugin sends them: blocks of --block consecutive
+frame times per device (--block 0: by calling thread, the round-4 behaviour).
 usage: python tools/bench_host_threads.py [--devices N] [--seconds S] [--threads 1,2,4,8]     (BENCH_CTX_OPTIONS=opt=val,...)"""
 import argparse, os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +16,7 @@ ap.add_argument("--devices", type=int, default=1)
 ap.add_argument("--seconds", type=float, default=1.5)
 ap.add_argument("--threads", default="1,2,4,8")
 ap.add_argument("--size", default="1920x1080")
+ap.add_argument("--block", type=int, default=16, help="frames per device block in --sequence mode (0 = device by calling thread)")
 ap.add_argument("--sequence", type=int, default=0, help="N > 0: the threads render the output frames of ONE sequence of N distinct frames in order "
                 "(thread i takes frames i, i + threads, ...), every frame named (ofxcv_vectorgen_flows_host_keyed): what an OFX host that provides "
                 "kOfxImagePropUniqueIdentifier gets during playback")
@@ -20,9 +24,13 @@ args = ap.parse_args()
 W, H = (int(v) for v in args.size.split("x"))
 ref, nxt = synth.flow_pair(W, H, seed=11)
 prev, _ = synth.flow_pair(W, H, seed=12)
-ndev = max(1, min(args.devices, torch.cuda.device_count()))
+if args.devices > torch.cuda.device_count():
+    os.environ["OFXCV_VIRTUAL_DEVICES"] = str(args.devices)
+ndev = max(1, min(args.devices, ofxcv.lib().ofxcv_device_count()))
 for nt in [int(v) for v in args.threads.split(",")]:
     ctxs = [ofxcv.Context(i % ndev) for i in range(nt)]
+    by_block = args.sequence and args.block > 0 and ndev > 1
+    per_dev = [[ofxcv.Context(d) for d in range(ndev)] for _ in range(nt)] if by_block else None  # a render thread's context per device
     for kv in filter(None, os.environ.get("BENCH_CTX_OPTIONS", "").split(",")):
         for c in ctxs:
             c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -46,7 +54,8 @@ for nt in [int(v) for v in args.threads.split(",")]:
                 a, b, p = t % n, (t + 1) % n, (t - 1) % n
                 # names by position in an endless sequence (the N buffers come round again under new names): every output frame
                 # has ONE frame the device has not seen, as in playback
-                c.vectorgen_flows_host(seq[a], seq[b], seq[p], f[3], 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
+                cc = per_dev[i][(t // args.block) % ndev] if by_block else c
+                cc.vectorgen_flows_host(seq[a], seq[b], seq[p], f[3], 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
                 t += nt
             else:
                 c.vectorgen_flows_host(f[0], f[1], f[2], f[3], 1, 2, 4, 8)
@@ -62,5 +71,10 @@ for nt in [int(v) for v in args.threads.split(",")]:
     print("%d devices, %d calling threads: %.1f output frames/s = %.0f pairs/s (%.2f ms per call per thread; zero-copy calls %s)" %
           (ndev, nt, n / el, 2 * n / el, el * nt / max(1, n) * 1e3, [c.host_zero_copy_calls() for c in ctxs]) +
           ("  named frames found on the device / uploaded: %d / %d" % (sum(c.host_cache_hits() for c in ctxs), sum(c.host_cache_misses() for c in ctxs)) if args.sequence else ""), flush=True)
-    for c in ctxs:
+    allc = ctxs + ([c for row in per_dev for c in row] if per_dev else [])
+    if args.sequence:
+        print("    named frames over all contexts: found %d / uploaded %d" % (sum(c.host_cache_hits() for c in allc), sum(c.host_cache_misses() for c in allc)), flush=True)
+    lh = [c.lock_hold() for c in allc]
+    print("    runtime lock: %.1f us held per Farneback call (%d holds)" % (sum(a for a, _ in lh) / 1e3 / max(1, sum(b for _, b in lh)), sum(b for _, b in lh)), flush=True)
+    for c in allc:
         c.close()
