@@ -93,6 +93,7 @@ struct ofxcv_ctx {
     int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (the second geometry the tests walk; no ring)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
+    int fb_reuse_prep = 0;       // option "farneback.reuse_prep" (measurement probe): skip the pyramid images / polynomial expansions, the scratch still holds those of the same frames
     int fb_col_ring = 1;         // option "farneback.col_ring": the step pairs of the column-owning form that open with an iteration gather R1 from a ring of rows in LDS filled by LDS-DMA (1, default); 0 = every gather from memory (cross-check, A/B)
     DevBuf fb_col_flag;          // the trace area of iterate_col_kernel (farneback.col_trace)
     unsigned *fb_col_abort = nullptr;  // the abort word of iterate_col_kernel: 64 bytes of pinned, host-coherent memory the kernel stores to when a bounded

@@ -320,7 +320,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
             {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
             {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20},
-            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}};
+            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}, {"farneback.reuse_prep", &ctx->fb_reuse_prep, 0, 1}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 if (value < k.lo || value > k.hi) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);

@@ -3260,10 +3260,14 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             R[k][0] = p;
             R[k][1] = p + field;
             p += 2 * field;
-            rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, L.t1, I, L.img);
-            if (rc) return rc;
-            rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field, true);  // R1 = the odd frames, packed
-            if (rc) return rc;
+            // (measurement probe farneback.reuse_prep: the pyramid images and expansions a previous call on the SAME frames left in the scratch are used
+            // as they are -- the upper bound of what keeping a named frame's expansions on the device could save; results are unchanged)
+            if (!ctx->fb_reuse_prep) {
+                rc = launch_pyr_image(ctx, sp, imgs, 2 * n, width, height, w, h, sigma, ksz, T1, L.t1, I, L.img);
+                if (rc) return rc;
+                rc = launch_polyexp(ctx, sp, I, w, h, R[k][0], poly_n, poly_sigma, 2 * n, L.img, L.planes, field, true);  // R1 = the odd frames, packed
+                if (rc) return rc;
+            }
             OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_level[k], sp));
         }
     }

@@ -41,7 +41,12 @@ struct FrontQueue {
     size_t ci = 0;
     int cb = -1, hi = -1;                      // current bucket, highest bucket ever used
     std::vector<uint64_t> px;                  // push number -> (i << 32 | j)
+    // Distances >= 2048 share the LAST bucket: once the front is there every push belongs to the current bucket, and a sorted insert per push
+    // would make a very large hole quadratic.  Those pushes go into a binary min-heap instead; pop() takes the smaller of
+    // the heap's top and the sorted remainder -- still the smallest queued key.
+    std::vector<uint64_t> ovf;
     void clear() {
+        ovf.clear();
         for (int b = 0; b <= hi && b < (int)later.size(); b++) later[b].clear();
         cur.clear();
         px.clear();
@@ -54,17 +59,22 @@ struct FrontQueue {
         const uint64_t key = ((uint64_t)bits << 32) | (uint32_t)px.size();
         px.push_back(((uint64_t)(uint32_t)i << 32) | (uint32_t)j);
         const float s = T * (float)kPerUnit;
-        const int b = s >= (float)(kBuckets - 1) ? kBuckets - 1 : (int)s;  // monotone in T (T >= 0 while queued)
+        // monotone in T (T >= 0 while queued); a NaN or negative T -- neither occurs on the reference's maps -- is given a bucket instead of an
+        // undefined conversion (NaN: the last one, negative: the first)
+        const int b = !(s < (float)(kBuckets - 1)) ? kBuckets - 1 : (s > 0.f ? (int)s : 0);
         if (b > cb) {
             if (later.empty()) later.resize(kBuckets);
             later[b].push_back(key);
             if (b > hi) hi = b;
+        } else if (cb == kBuckets - 1) {
+            ovf.push_back(key);
+            std::push_heap(ovf.begin(), ovf.end(), std::greater<uint64_t>());
         } else {
             cur.insert(std::lower_bound(cur.begin() + (ptrdiff_t)ci, cur.end(), key), key);
         }
     }
     bool pop(int &i, int &j) {
-        while (ci == cur.size()) {  // on to the next occupied bucket
+        while (ci == cur.size() && ovf.empty()) {  // on to the next occupied bucket
             int b = cb + 1;
             while (b <= hi && later[b].empty()) b++;
             if (b > hi) return false;
@@ -74,7 +84,15 @@ struct FrontQueue {
             ci = 0;
             cb = b;
         }
-        const uint64_t p = px[(uint32_t)cur[ci++]];
+        uint64_t key;
+        if (!ovf.empty() && (ci == cur.size() || ovf.front() < cur[ci])) {
+            std::pop_heap(ovf.begin(), ovf.end(), std::greater<uint64_t>());
+            key = ovf.back();
+            ovf.pop_back();
+        } else {
+            key = cur[ci++];
+        }
+        const uint64_t p = px[(uint32_t)key];
         i = (int)(p >> 32);
         j = (int)(uint32_t)p;
         return true;

@@ -149,7 +149,7 @@ class GrayCache {
     std::mutex mu_;
     std::condition_variable cv_;
     std::vector<GrayEntry *> entries_;
-    size_t bytes_ = 0;
+    size_t bytes_ = 0, budget_ = 0;
     unsigned long clock_ = 0;
 
     void drop(size_t i, ofxcv_ctx *ctx) {  // mu_ held; entry unpinned: nothing of it is in flight (its users synchronised before unpinning)
@@ -188,19 +188,26 @@ public:
         // failed entries nobody uses any more, then least-recently-used ones, make room
         for (size_t i = entries_.size(); i-- > 0;)
             if (entries_[i]->failed && entries_[i]->pins == 0) drop(i, ctx);
+        // The budget is the cache's, not the caller's: the value the latest caller brought (contexts of one host share an option default; a
+        // host that lowers it means it for the device).  Evictions go on until the new entry fits -- also after an evicted entry's buffer
+        // has been taken over (the take-over used to end the loop without looking at the budget again).
+        budget_ = budget;
         GrayEntry *e = nullptr;
-        while (bytes_ + bytes > budget) {
+        while (bytes_ + (e ? 0 : bytes) > budget_ - (e ? std::min(budget_, bytes) : 0)) {
             size_t lru = entries_.size();
             for (size_t i = 0; i < entries_.size(); i++)
                 if (entries_[i]->pins == 0 && (lru == entries_.size() || entries_[i]->stamp < entries_[lru]->stamp)) lru = i;
-            if (lru == entries_.size()) return nullptr;
-            if (entries_[lru]->bytes == bytes) {
+            if (lru == entries_.size()) {
+                if (e) break;  // (nothing else can go: the taken-over buffer is used all the same -- it was inside the budget a moment ago)
+                return nullptr;
+            }
+            if (!e && entries_[lru]->bytes == bytes) {
                 // the usual case (a sequence has one frame size): the evicted entry's buffer and event are taken over as they are --
                 // no hipFree (it waits for the whole device) and no hipMalloc on the path of a render call
                 e = entries_[lru];
                 entries_.erase(entries_.begin() + (ptrdiff_t)lru);
                 bytes_ -= bytes;
-                break;
+                continue;
             }
             drop(lru, ctx);
         }

@@ -54,6 +54,43 @@ static int run_case(int w, int h, unsigned seed, int blobs, int rmax, bool touch
     return par ? 0 : -1;  // -1: one piece, the serial form ran
 }
 
+// a front that lives beyond the last bucket (distances >= 2048: a hole more than 4 000 pixels across): every push then belongs to the current
+// bucket and goes through the queue's overflow heap -- same pop order as a binary heap, and no quadratic inserts (200 000 pushes here)
+static int queue_far_case(unsigned seed) {
+    std::mt19937 rng(seed);
+    FrontQueue q;
+    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> ref;
+    std::vector<std::pair<int, int>> who;
+    float last = 2040.f;
+    auto push = [&](float T) {
+        uint32_t bits;
+        std::memcpy(&bits, &T, 4);
+        ref.push(((uint64_t)bits << 32) | (uint32_t)who.size());
+        const int i = (int)(rng() % 5000), j = (int)(rng() % 5000);
+        who.push_back({i, j});
+        q.push(i, j, T);
+    };
+    for (int k = 0; k < 64; k++) push(last + (float)(rng() % 100) / 10.f);
+    for (int step = 0; step < 200000; step++) {
+        const uint64_t k = ref.top();
+        ref.pop();
+        int i = -1, j = -1;
+        if (!q.pop(i, j) || i != who[(uint32_t)k].first || j != who[(uint32_t)k].second) return 1;
+        const uint32_t bits = (uint32_t)(k >> 32);
+        std::memcpy(&last, &bits, 4);
+        push(last + 0.707f + (float)(rng() % 300) / 1000.f);
+        if (rng() % 8 == 0) push(last);  // ties with what just popped
+    }
+    while (!ref.empty()) {
+        const uint64_t k = ref.top();
+        ref.pop();
+        int i, j;
+        if (!q.pop(i, j) || i != who[(uint32_t)k].first || j != who[(uint32_t)k].second) return 1;
+    }
+    int i, j;
+    return q.pop(i, j) ? 1 : 0;
+}
+
 // the bucket queue against a binary heap on arbitrary push / pop sequences: equal distances (push order decides), pushes
 // below the distance that popped last (never produced by a front, served all the same), distances beyond the last bucket
 static int queue_case(unsigned seed) {
@@ -109,6 +146,13 @@ int main() {
         cases++;
         if (queue_case(seed)) {
             std::printf("bucket queue differs from the heap, seed %u\n", seed);
+            bad++;
+        }
+    }
+    for (unsigned seed = 1; seed <= 3; seed++) {
+        cases++;
+        if (queue_far_case(seed)) {
+            std::printf("bucket queue (front beyond the last bucket) differs from the heap, seed %u\n", seed);
             bad++;
         }
     }
