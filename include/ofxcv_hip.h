@@ -79,6 +79,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x
  *                                    (taps cast to float before they are normalised), 4 = 4.x (normalised in double, one cast):
  *                                    two taps of the 9- and 19-tap kernels differ by one ulp;
+ *   "farneback.filter_contraction" 0|1   OpenCV 4.x runs GaussianBlur's separable filters and resize's vertical lerp through universal-intrinsics
+ *                      code (AVX2 / NEON) whose taps are fused multiply-adds; 2.4 / 3.x and builds without it round product and sum separately.
+ *                      0 (default) = separate roundings, 1 = fused (pyramid images and the flow prolongation; optflowgf.cpp itself is plain C++).
  *   "farneback.resize_generation" 0|1|2   cv::resize(INTER_LINEAR) rewrites itself to INTER_AREA when the level is exactly half the
  *                                    frame in both directions; the 2x2 mean it then takes differs from the bilinear form only in the
  *                                    association of three float additions: 0 (default) ((a+b)+(c+d))/4 = bilinear = the 4.x SIMD path,

@@ -61,6 +61,7 @@ struct ofxcv_ctx {
     int fb_polyexp_variant = 5;
     int fb_pyr_bytewise = 0;     // option "farneback.pyr_bytewise": 1 = the coarse pyramid levels take the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel)
     int fb_gauss_generation = 3;    // option "farneback.gaussian_kernel_generation": getGaussianKernel of OpenCV 2.4 / 3.x (3) or 4.x (4)
+    int fb_filter_contraction = 0;  // option "farneback.filter_contraction": 1 = the separable filters of the pyramid and resize's vertical lerp as fused multiply-adds (OpenCV 4.x AVX2 / NEON paths); 0 = scalar order (2.4 / 3.x)
     int fb_resize_generation = 0;   // option "farneback.resize_generation": association of cv::resize's exact-2x INTER_AREA rewrite (farneback.hip: resize_combine)
     int num_cus = 256;
     hipStream_t last_stream = nullptr;  // last caller-supplied stream (ofxcv_stream)
@@ -84,6 +85,7 @@ struct ofxcv_ctx {
     // the five-row form takes those: batches of 2 958 -> 1 024 pairs/s, batches of 8 +0.9 %, single calls and batches of 4 unchanged)
     int fb_halo_geom = 0, fb_halo_min8 = 300, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
+    int lut_luma601 = 0;         // option "lut.luma" 709 (default) | 601: luma weights of the gray conversion (supportext's are not verifiable here)
     int lut4 = 1;                // option "lut.four": gray LUT with four pixels per lane where the images are aligned for it
     int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
     int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5

@@ -262,6 +262,16 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->fb_gauss_generation = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "lut.luma")) {
+        if (value != 709 && value != 601) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "lut.luma: 709 (Rec.709 weights, default) or 601");
+        ctx->lut_luma601 = value == 601;
+        return OFXCV_OK;
+    }
+    if (!std::strcmp(name, "farneback.filter_contraction")) {
+        if (value != 0 && value != 1) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.filter_contraction: 0 (scalar order) or 1 (fused multiply-adds, OpenCV 4.x vector paths)");
+        ctx->fb_filter_contraction = value;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "farneback.resize_generation")) {
         if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.resize_generation: 0, 1 or 2");
         ctx->fb_resize_generation = value;
@@ -352,6 +362,8 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     if (!std::strcmp(name, "farneback.opencv_rounding")) *value = ctx->fb_opencv_rounding;
     else if (!std::strcmp(name, "farneback.gaussian_kernel_generation")) *value = ctx->fb_gauss_generation;
     else if (!std::strcmp(name, "farneback.resize_generation")) *value = ctx->fb_resize_generation;
+    else if (!std::strcmp(name, "farneback.filter_contraction")) *value = ctx->fb_filter_contraction;
+    else if (!std::strcmp(name, "lut.luma")) *value = ctx->lut_luma601 ? 601 : 709;
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
     else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;

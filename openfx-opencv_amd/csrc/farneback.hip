@@ -55,6 +55,7 @@ struct FlowTab {  // 2-channel flow fields, one per pair (the caller's at level 
 
 struct GaussTaps {
     int ksize;
+    int fc;  // filter contraction (option "farneback.filter_contraction"): the taps as fused multiply-adds (madd below)
     float k[kMaxGaussTaps];
 };
 
@@ -171,6 +172,12 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// One tap of a separable filter / of resize's vertical lerp: a * b + c with two roundings (fc = 0: the scalar loops of OpenCV 2.4 / 3.x and the
+// oracle's default) or as ONE fused multiply-add (fc = 1: what OpenCV 4.x's universal-intrinsics paths compute with v_muladd -- SymmRowSmallVec_32f,
+// RowVec_32f, SymmColumnSmallVec_32f, SymmColumnVec_32f, VResizeLinearVec_32f).  Option "farneback.filter_contraction"; oracle: orc_set_filter_contraction.
+// The pyramid kernels without a GaussTaps argument carry the flag in bit 4 of their `area` argument.
+__device__ __forceinline__ float madd(float a, float b, float c, int fc) { return fc ? __builtin_fmaf(a, b, c) : a * b + c; }
+
 // imgwarp.cpp resize(INTER_LINEAR) coefficient rule for destination index d
 __device__ __forceinline__ void lerp_coef_scaled(int d, int ssize, double scale, int &s, float &a0, float &a1) {
     float f = (float)((d + 0.5) * scale - 0.5);
@@ -200,11 +207,11 @@ __device__ __forceinline__ void lerp_coef(int d, int ssize, int dsize, int &s, f
 //   1  ((t00 + t01) + t10) + t11                                                   the scalar loop (2.4.x; builds without SIMD)
 //   2  (t00 + t10) + (t01 + t11)                                                   ResizeAreaFastVec_SIMD_32f of 3.x (SSE2: rows first)
 // Option "farneback.resize_generation"; the oracle's counterpart is orc_set_resize_generation.
-__device__ __forceinline__ float resize_combine(float t00, float t01, float t10, float t11, float ax0, float ax1, float b0, float b1, int area) {
+__device__ __forceinline__ float resize_combine(float t00, float t01, float t10, float t11, float ax0, float ax1, float b0, float b1, int area, int fc) {
     if (area == 1) return (((t00 + t01) + t10) + t11) * 0.25f;
     if (area == 2) return ((t00 + t10) + (t01 + t11)) * 0.25f;
-    const float r0 = t00 * ax0 + t01 * ax1, r1 = t10 * ax0 + t11 * ax1;
-    return r0 * b0 + r1 * b1;
+    const float r0 = t00 * ax0 + t01 * ax1, r1 = t10 * ax0 + t11 * ax1;  // (HResizeLinear has no float vector path: never contracted)
+    return madd(r0, b0, r1 * b1, fc);
 }
 
 // Workgroup -> tile mapping.  The dispatcher is observed to place workgroup b on XCD b % 8 and every XCD has its own
@@ -256,13 +263,13 @@ __global__ __launch_bounds__(256) void pyr_hblur_kernel(ImgTab imgs, int first, 
     const int ksize = gk.ksize, r = ksize >> 1;
     float s;
     if (ksize == 3) {
-        s = (float)S[sx] * gk.k[1] + ((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)]) * gk.k[2];
+        s = madd((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)], gk.k[2], (float)S[sx] * gk.k[1], gk.fc);
     } else if (ksize == 5) {
-        s = (float)S[sx] * gk.k[2] + ((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)]) * gk.k[3] +
-            ((float)S[reflect101(sx - 2, W)] + (float)S[reflect101(sx + 2, W)]) * gk.k[4];
+        s = madd((float)S[reflect101(sx - 2, W)] + (float)S[reflect101(sx + 2, W)], gk.k[4],
+                 madd((float)S[reflect101(sx - 1, W)] + (float)S[reflect101(sx + 1, W)], gk.k[3], (float)S[sx] * gk.k[2], gk.fc), gk.fc);
     } else {
         s = gk.k[0] * (float)S[reflect101(sx - r, W)];
-        for (int j = 1; j < ksize; j++) s += (float)S[reflect101(sx - r + j, W)] * gk.k[j];
+        for (int j = 1; j < ksize; j++) s = madd((float)S[reflect101(sx - r + j, W)], gk.k[j], s, gk.fc);
     }
     T1[(size_t)y * ncol + c] = s;
 }
@@ -271,11 +278,10 @@ __device__ __forceinline__ float col_filter(const float *__restrict__ T1, int nc
     const int ksize = gk.ksize, r = ksize >> 1;
     const float *kc = gk.k + r;
     if (ksize == 3)
-        return (T1[(size_t)reflect101(y - 1, H) * ncol + c] + T1[(size_t)reflect101(y + 1, H) * ncol + c]) * kc[1] +
-               T1[(size_t)y * ncol + c] * kc[0];
+        return madd(T1[(size_t)reflect101(y - 1, H) * ncol + c] + T1[(size_t)reflect101(y + 1, H) * ncol + c], kc[1], T1[(size_t)y * ncol + c] * kc[0], gk.fc);
     float s = kc[0] * T1[(size_t)y * ncol + c];
     for (int k = 1; k <= r; k++)
-        s += kc[k] * (T1[(size_t)reflect101(y + k, H) * ncol + c] + T1[(size_t)reflect101(y - k, H) * ncol + c]);
+        s = madd(T1[(size_t)reflect101(y + k, H) * ncol + c] + T1[(size_t)reflect101(y - k, H) * ncol + c], kc[k], s, gk.fc);
     return s;
 }
 
@@ -299,10 +305,10 @@ __global__ __launch_bounds__(256) void pyr_vblur_resize_kernel(const float *__re
         float t00 = col_filter(T1, ncol, dx * 2, sy, H, gk), t10 = col_filter(T1, ncol, dx * 2, sy1, H, gk);
         if (sx + 1 < W) {
             float t01 = col_filter(T1, ncol, dx * 2 + 1, sy, H, gk), t11 = col_filter(T1, ncol, dx * 2 + 1, sy1, H, gk);
-            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
+            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area, gk.fc);
         } else {
             const float r0 = t00 * 1.f, r1 = t10 * 1.f;
-            out = r0 * b0 + r1 * b1;
+            out = madd(r0, b0, r1 * b1, gk.fc);
         }
     }
     I[(size_t)dy * lw + dx] = out;
@@ -370,11 +376,11 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
         if (ntap == 2) sx = min(sx + (j & 1), W - 1);
         const unsigned char *S = s_src + ry * t.cw + (sx - c_lo);  // S[i] = source column sx + i (reflected)
         float v;
-        if (ksize == 3) v = (float)S[0] * gk.k[1] + ((float)S[-1] + (float)S[1]) * gk.k[2];
-        else if (ksize == 5) v = (float)S[0] * gk.k[2] + ((float)S[-1] + (float)S[1]) * gk.k[3] + ((float)S[-2] + (float)S[2]) * gk.k[4];
+        if (ksize == 3) v = madd((float)S[-1] + (float)S[1], gk.k[2], (float)S[0] * gk.k[1], gk.fc);
+        else if (ksize == 5) v = madd((float)S[-2] + (float)S[2], gk.k[4], madd((float)S[-1] + (float)S[1], gk.k[3], (float)S[0] * gk.k[2], gk.fc), gk.fc);
         else {
             v = gk.k[0] * (float)S[-r];
-            for (int q = 1; q < ksize; q++) v += (float)S[q - r] * gk.k[q];
+            for (int q = 1; q < ksize; q++) v = madd((float)S[q - r], gk.k[q], v, gk.fc);
         }
         s_h[ry * ncolh + j] = v;
     }
@@ -382,9 +388,9 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
     const float *kc = gk.k + r;
     auto colf = [&](int j, int sy) -> float {  // column filter at source row sy, filtered column j
         const float *C = s_h + (sy - r_lo) * ncolh + j;
-        if (ksize == 3) return (C[-ncolh] + C[ncolh]) * kc[1] + C[0] * kc[0];
+        if (ksize == 3) return madd(C[-ncolh] + C[ncolh], kc[1], C[0] * kc[0], gk.fc);
         float v = kc[0] * C[0];
-        for (int q = 1; q <= r; q++) v += kc[q] * (C[q * ncolh] + C[-q * ncolh]);
+        for (int q = 1; q <= r; q++) v = madd(C[q * ncolh] + C[-q * ncolh], kc[q], v, gk.fc);
         return v;
     };
     for (int e = tid; e < t.ow * t.oh; e += 256) {
@@ -400,10 +406,10 @@ __global__ __launch_bounds__(256) void pyr_fused_kernel(ImgTab imgs, int W, int 
             float t00 = colf(2 * tx, sy), t10 = colf(2 * tx, sy1);
             if (sx + 1 < W) {
                 float t01 = colf(2 * tx + 1, sy), t11 = colf(2 * tx + 1, sy1);
-                out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
+                out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area, gk.fc);
             } else {
                 const float r0 = t00 * 1.f, r1 = t10 * 1.f;
-                out = r0 * b0 + r1 * b1;
+                out = madd(r0, b0, r1 * b1, gk.fc);
             }
         }
         I[(size_t)dy * lw + dx] = out;
@@ -471,8 +477,8 @@ __global__ __launch_bounds__(256) void pyr_fused_al_kernel(ImgTab imgs, int W, i
         float va = gk.k[0] * B(0), vb = gk.k[0] * B(1);
 #pragma unroll
         for (int q = 1; q < KS; q++) {
-            va += B(q) * gk.k[q];
-            vb += B(q + 1) * gk.k[q];
+            va = madd(B(q), gk.k[q], va, gk.fc);
+            vb = madd(B(q + 1), gk.k[q], vb, gk.fc);
         }
         *(float2 *)(s_h + (size_t)e * 2) = make_float2(va, vb);
     }
@@ -493,12 +499,12 @@ __global__ __launch_bounds__(256) void pyr_fused_al_kernel(ImgTab imgs, int W, i
         float t00 = kc[0] * c[R].x, t01 = kc[0] * c[R].y, t10 = kc[0] * c[R + 1].x, t11 = kc[0] * c[R + 1].y;
 #pragma unroll
         for (int q = 1; q <= R; q++) {
-            t00 += kc[q] * (c[R + q].x + c[R - q].x);
-            t01 += kc[q] * (c[R + q].y + c[R - q].y);
-            t10 += kc[q] * (c[R + 1 + q].x + c[R + 1 - q].x);
-            t11 += kc[q] * (c[R + 1 + q].y + c[R + 1 - q].y);
+            t00 = madd(c[R + q].x + c[R - q].x, kc[q], t00, gk.fc);
+            t01 = madd(c[R + q].y + c[R - q].y, kc[q], t01, gk.fc);
+            t10 = madd(c[R + 1 + q].x + c[R + 1 - q].x, kc[q], t10, gk.fc);
+            t11 = madd(c[R + 1 + q].y + c[R + 1 - q].y, kc[q], t11, gk.fc);
         }
-        I[(size_t)dy * lw + dx] = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, 0);
+        I[(size_t)dy * lw + dx] = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, 0, gk.fc);
     }
 }
 
@@ -507,7 +513,8 @@ __global__ __launch_bounds__(256) void pyr_fused_al_kernel(ImgTab imgs, int W, i
 // Same operations in the same order as the generic kernels.
 __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, int H, int lw, int lh,
                                                           int ntap, float k0, float k1, double scale_x, double scale_y,
-                                                          float *__restrict__ I, size_t I_stride, int area) {
+                                                          float *__restrict__ I, size_t I_stride, int area_fc) {
+    const int area = area_fc & 15, fc = area_fc >> 4;  // (bit 4: filter contraction, see madd)
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     const uint8_t *__restrict__ img = imgs.p[tbz];
@@ -524,10 +531,10 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, in
     // row filter of source row `ry` at column `cx`:  S[0]*k0 + (S[-1] + S[1])*k1
     auto rowf = [&](int ry, int cx) -> float {
         const uint8_t *S = img + (size_t)reflect101(ry, H) * step;
-        return (float)S[cx] * k0 + ((float)S[reflect101(cx - 1, W)] + (float)S[reflect101(cx + 1, W)]) * k1;
+        return madd((float)S[reflect101(cx - 1, W)] + (float)S[reflect101(cx + 1, W)], k1, (float)S[cx] * k0, fc);
     };
     // column filter at source row `cy`:  (T[-1] + T[1])*k1 + T[0]*k0
-    auto colf = [&](int cy, int cx) -> float { return (rowf(cy - 1, cx) + rowf(cy + 1, cx)) * k1 + rowf(cy, cx) * k0; };
+    auto colf = [&](int cy, int cx) -> float { return madd(rowf(cy - 1, cx) + rowf(cy + 1, cx), k1, rowf(cy, cx) * k0, fc); };
     float out;
     if (ntap == 1) {
         out = colf(sy, sx);
@@ -537,10 +544,10 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, in
         if (sx + 1 < W) {
             const int sx1 = min(sx + 1, W - 1);
             float t01 = colf(sy, sx1), t11 = colf(sy1, sx1);
-            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area);
+            out = resize_combine(t00, t01, t10, t11, ax0, ax1, b0, b1, area, fc);
         } else {
             const float r0 = t00 * 1.f, r1 = t10 * 1.f;
-            out = r0 * b0 + r1 * b1;
+            out = madd(r0, b0, r1 * b1, fc);
         }
     }
     I[(size_t)dy * lw + dx] = out;
@@ -554,7 +561,8 @@ __global__ __launch_bounds__(256) void pyr_direct3_kernel(ImgTab imgs, int W, in
 // would cross the image edge take the byte path with reflected columns.  Arithmetic and order as in the byte kernel.
 template <int NTAP>
 __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, int H, int lw, int lh,
-                                                           float k0, float k1, float *__restrict__ I, size_t I_stride, int area) {
+                                                           float k0, float k1, float *__restrict__ I, size_t I_stride, int area_fc) {
+    const int area = area_fc & 15, fc = area_fc >> 4;  // (bit 4: filter contraction, see madd)
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
     const uint8_t *__restrict__ img = imgs.p[tbz];
@@ -584,14 +592,14 @@ __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, i
             for (int i = 0; i < 6; i++) b[i] = (float)S[reflect101(min(c0 - 1 + i, W), W)];
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) rf[r][j] = b[j + 1] * k0 + (b[j] + b[j + 2]) * k1;
+        for (int j = 0; j < 4; j++) rf[r][j] = madd(b[j] + b[j + 2], k1, b[j + 1] * k0, fc);
     }
     // column filter at source row sy (+ sy+1):  (T[-1] + T[1])*k1 + T[0]*k0
     if (NTAP == 1) {
         float *out = I + (size_t)dy * lw + c0;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = (rf[0][j] + rf[2][j]) * k1 + rf[1][j] * k0;
+        for (int j = 0; j < 4; j++) v[j] = madd(rf[0][j] + rf[2][j], k1, rf[1][j] * k0, fc);
         if ((lw & 3) == 0 && (((uintptr_t)I) & 15) == 0) {  // c0 is a multiple of 4: one aligned 16-byte store
             *(float4 *)out = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -603,13 +611,13 @@ __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, i
         float t0[4], t1[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            t0[j] = (rf[0][j] + rf[2][j]) * k1 + rf[1][j] * k0;
-            t1[j] = (rf[1][j] + rf[3][j]) * k1 + rf[2][j] * k0;
+            t0[j] = madd(rf[0][j] + rf[2][j], k1, rf[1][j] * k0, fc);
+            t1[j] = madd(rf[1][j] + rf[3][j], k1, rf[2][j] * k0, fc);
         }
         float *out = I + (size_t)dy * lw + (c0 >> 1);
         float v[2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) v[q] = resize_combine(t0[2 * q], t0[2 * q + 1], t1[2 * q], t1[2 * q + 1], 0.5f, 0.5f, 0.5f, 0.5f, area);
+        for (int q = 0; q < 2; q++) v[q] = resize_combine(t0[2 * q], t0[2 * q + 1], t1[2 * q], t1[2 * q + 1], 0.5f, 0.5f, 0.5f, 0.5f, area, fc);
         if ((lw & 1) == 0 && (((uintptr_t)I) & 7) == 0) {
             *(float2 *)out = make_float2(v[0], v[1]);
         } else {
@@ -1040,6 +1048,7 @@ __device__ __forceinline__ M5 update_matrices_px(const float *__restrict__ R0, c
 struct Prolong {
     int pw, ph;                             // size of the coarser level
     double inv_pyr_scale, scale_x, scale_y;  // scale = (double)pw / w, divided once on the host
+    int fc = 0;                              // filter contraction (madd): resize's vertical lerp as a fused multiply-add
 };
 __device__ __forceinline__ void prolong_flow(const float *__restrict__ flow, size_t flow_step, const Prolong &pr, int x, int y, float &dx, float &dy) {
     int sx, sy;
@@ -1059,8 +1068,8 @@ __device__ __forceinline__ void prolong_flow(const float *__restrict__ flow, siz
         r0x = a.x * 1.f; r0y = a.y * 1.f;
         r1x = c.x * 1.f; r1y = c.y * 1.f;
     }
-    dx = (float)((double)(r0x * b0 + r1x * b1) * pr.inv_pyr_scale);
-    dy = (float)((double)(r0y * b0 + r1y * b1) * pr.inv_pyr_scale);
+    dx = (float)((double)madd(r0x, b0, r1x * b1, pr.fc) * pr.inv_pyr_scale);
+    dy = (float)((double)madd(r0y, b0, r1y * b1, pr.fc) * pr.inv_pyr_scale);
 }
 
 // F6 + first F4 of a level.  MODE 0: zero initial flow (coarsest level); MODE 1: flow prolongated from
@@ -1082,14 +1091,14 @@ __global__ __launch_bounds__(256) void update_matrices_kernel(const float *__res
     const size_t flow_step = MODE ? flows.step[tbz] : 0;
     float dx = 0.f, dy = 0.f;
     if (MODE == 1) {
-        const Prolong pr = {pw, ph, inv_pyr_scale, scale_x, scale_y};
+        const Prolong pr = {pw, ph, inv_pyr_scale, scale_x, scale_y, r1q >> 1};  // (bit 1 of the layout flag: filter contraction)
         prolong_flow(flow, flow_step, pr, x, y, dx, dy);
     } else if (MODE == 2) {
         float2 f = *(const float2 *)((const char *)flow + (size_t)y * flow_step + (size_t)x * 8);
         dx = f.x;
         dy = f.y;
     }
-    M5 m = update_matrices_px(R0, R1, x, y, w, h, pitch, dx, dy, r1q != 0);
+    M5 m = update_matrices_px(R0, R1, x, y, w, h, pitch, dx, dy, (r1q & 1) != 0);
     const size_t plane = (size_t)pitch * h, o = (size_t)y * pitch + x;
 #pragma unroll
     for (int c = 0; c < 5; c++) M[o + c * plane] = m.v[c];
@@ -2742,6 +2751,8 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
     if (ksize > kMaxGaussTaps) return ofxcv_fail(ctx, OFXCV_ERR_UNSUPPORTED, "pyramid blur of %d taps exceeds %d", ksize, kMaxGaussTaps);
     GaussTaps gk;
     make_gauss_taps(ksize, sigma, gk, ctx->fb_gauss_generation);
+    gk.fc = ctx->fb_filter_contraction;
+    const int fcb = ctx->fb_filter_contraction << 4;  // the same flag for the kernels that take the two taps as scalars (bit 4 of `area`)
     int ntap = (lw == W && lh == H) ? 1 : 2;
     const int area = (W == 2 * lw && H == 2 * lh) ? ctx->fb_resize_generation : 0;  // cv::resize's exact-2x rewrite (resize_combine)
     const bool no_fused = ctx->fb_unfused_pyr;
@@ -2750,14 +2761,14 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
     const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && aligned && (I_stride & 3) == 0;
     if (dword_ok && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
         dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4), nimg), block(64, 4);
-        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, 0);
-        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, area);
+        if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, fcb);
+        else hipLaunchKernelGGL(pyr_direct3v_kernel<2>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, area | fcb);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3v_kernel");
         return OFXCV_OK;
     }
     if (!no_fused && ksize == 3 && W >= 2 && H >= 2) {
         hipLaunchKernelGGL(pyr_direct3_kernel, dim3(ofxcv_div_up(lw, 64), ofxcv_div_up(lh, 4), nimg), dim3(64, 4), 0, s, imgs, W, H, lw, lh, ntap,
-                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride, area);
+                           gk.k[1], gk.k[2], (double)W / lw, (double)H / lh, d_I, I_stride, area | fcb);
         OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3_kernel");
         return OFXCV_OK;
     }
@@ -3377,7 +3388,7 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                 } else if (have_prev) {
                     fk = kHaloCoarse;
                     ftab = sub_tab(prev_all, z0, gn);
-                    prc = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
+                    prc = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, ctx->fb_filter_contraction};
                 }
                 // steps of the level: first M, iterations - 1 x iterate, last -- two per launch
                 const int nsteps = iterations + 1;
@@ -3426,10 +3437,10 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
                 if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, no_flow, no_pr, w, h, kHaloZero, hs, 0, G);
                 else hipLaunchKernelGGL(update_matrices_kernel<0>, grid, block, 0, s, R0, R1, no_flow, 0, 0, 1.0, 1.0, 1.0, w, h, pitch, M0, L.planes, 1);
             } else {
-                const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h};
+                const Prolong pr = {pw, ph, 1. / pyr_scale, (double)pw / w, (double)ph / h, ctx->fb_filter_contraction};
                 if (halo_first) rc = launch_halo_iteration(ctx, s, R0, R1, nullptr, M0, sub_tab(prev_all, z0, gn), pr, w, h, kHaloCoarse, hs, 0, G);
                 else hipLaunchKernelGGL(update_matrices_kernel<1>, grid, block, 0, s, R0, R1, sub_tab(prev_all, z0, gn), pw, ph, pr.inv_pyr_scale, pr.scale_x,
-                                        pr.scale_y, w, h, pitch, M0, L.planes, 1);
+                                        pr.scale_y, w, h, pitch, M0, L.planes, 1 | (pr.fc << 1));
             }
             if (halo_first && rc) return rc;
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");

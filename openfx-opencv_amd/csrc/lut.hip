@@ -18,6 +18,9 @@ namespace {
 
 // Rec.709 luma weights of the supportext grayscale conversion.
 constexpr float kLumaR = 0.2126f, kLumaG = 0.7152f, kLumaB = 0.0722f;
+// ... and Rec.601 (option "lut.luma" 601): openfx-supportext's source is not in the reference tree (empty submodule), so which set its
+// to_byte_grayscale_nodither uses cannot be verified here ("make it one named constant") -- both are a switch, like the OpenCV generations
+constexpr float kLuma601R = 0.299f, kLuma601G = 0.587f, kLuma601B = 0.114f;
 
 float srgb_encode(float v) {
     if (v < 0.0031308f) return (v < 0.0f) ? 0.0f : v * 12.92f;
@@ -61,8 +64,11 @@ int ensure_lut(ofxcv_ctx *ctx, hipStream_t s) {
     return OFXCV_OK;
 }
 
-__device__ __forceinline__ uint8_t lut_byte(const uint16_t *__restrict__ lut, float r, float g, float b) {
-    float l = kLumaR * r + kLumaG * g + kLumaB * b;
+// (the table pointer's lowest bit carries the luma choice: the table is 2-byte aligned data, bit 0 of its address is free)
+__device__ __forceinline__ uint8_t lut_byte(const uint16_t *__restrict__ lut_tagged, float r, float g, float b) {
+    const bool r601 = ((uintptr_t)lut_tagged & 1u) != 0;
+    const uint16_t *__restrict__ lut = (const uint16_t *)((uintptr_t)lut_tagged & ~(uintptr_t)1);
+    float l = r601 ? kLuma601R * r + kLuma601G * g + kLuma601B * b : kLumaR * r + kLumaG * g + kLumaB * b;
     return (uint8_t)((lut[__float_as_uint(l) >> 16] + 0x80) >> 8);
 }
 
@@ -180,14 +186,15 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
     if (rc) return rc;
     // one pixel per thread measured best (9.6 us per 1080p RGBA frame; 2 / 4 / 8 pixels per thread: 10.4 / 11.6 / 10.8 us)
     constexpr int kSeg = 1;
+    const uint16_t *lut_arg = (const uint16_t *)((uintptr_t)ctx->d_srgb_lut | (ctx->lut_luma601 ? 1u : 0u));  // (bit 0: Rec.601 luma weights, lut_byte)
     dim3 block(256), grid(ofxcv_div_up(width, 256 * kSeg), height);
     if (ncomp == 4 && ctx->lut4 && !(width & 3) && !(((uintptr_t)d_src) & 15) && !(src_row_bytes & 15) && !(((uintptr_t)d_dst) & 3) && !(dst_row_bytes & 3))
         hipLaunchKernelGGL(gray_lut4_kernel, dim3(ofxcv_div_up(width / 4, 256), height), block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes,
-                           ctx->d_srgb_lut);
+                           lut_arg);
     else if (ncomp == 4)
-        hipLaunchKernelGGL((gray_lut_kernel<4, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
+        hipLaunchKernelGGL((gray_lut_kernel<4, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, lut_arg);
     else
-        hipLaunchKernelGGL((gray_lut_kernel<3, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, ctx->d_srgb_lut);
+        hipLaunchKernelGGL((gray_lut_kernel<3, kSeg>), grid, block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes, lut_arg);
     OFXCV_LAUNCH_CHECK(ctx, "gray_lut_kernel");
     return OFXCV_OK;
 }
@@ -217,7 +224,7 @@ int ofxcv_to_byte_grayscale_batch(ofxcv_ctx *ctx, int n, const float *const *d_s
         t.src_rb[i] = src_row_bytes[i];
         t.dst_rb[i] = dst_row_bytes[i];
     }
-    hipLaunchKernelGGL(gray_lut4_batch_kernel, dim3(ofxcv_div_up(width / 4, 256), height, n), dim3(256), 0, s, t, width, height, ctx->d_srgb_lut);
+    hipLaunchKernelGGL(gray_lut4_batch_kernel, dim3(ofxcv_div_up(width / 4, 256), height, n), dim3(256), 0, s, t, width, height, (const uint16_t *)((uintptr_t)ctx->d_srgb_lut | (ctx->lut_luma601 ? 1u : 0u)));
     OFXCV_LAUNCH_CHECK(ctx, "gray_lut4_batch_kernel");
     return OFXCV_OK;
 }

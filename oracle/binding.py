@@ -132,6 +132,16 @@ def set_gaussian_kernel_generation(generation):
     lib().orc_set_gaussian_kernel_generation(C.c_int(generation))
 
 
+def set_luma(standard):
+    """709 (default) or 601: the luma weights of to_byte_grayscale"""
+    lib().orc_set_luma(C.c_int(int(standard)))
+
+
+def set_filter_contraction(on):
+    """1: separable filters / resize's vertical lerp with fused multiply-adds (OpenCV 4.x AVX2 / NEON paths); 0 (default): scalar order"""
+    lib().orc_set_filter_contraction(C.c_int(int(on)))
+
+
 def set_resize_generation(generation):
     """association of cv::resize's exact-2x INTER_AREA rewrite: 0 (default) bilinear = 4.x SIMD, 1 scalar loop, 2 3.x SSE2"""
     lib().orc_set_resize_generation(C.c_int(generation))

@@ -99,6 +99,20 @@ void orc_gaussian_kernel_f32(int n, double sigma, float *k)
  *            otherwise           -> k0*S[0] + sum_k k[k]*(S[k]+S[-k])                (SymmColumnFilter)
  * rows first into an f32 buffer, then columns.
  */
+/* Filter contraction (orc_set_filter_contraction): OpenCV 4.x dispatches the separable filters and the vertical pass of resize to
+ * universal-intrinsics code (AVX2 / NEON: SymmRowSmallVec_32f, RowVec_32f, SymmColumnSmallVec_32f, SymmColumnVec_32f, VResizeLinearVec_32f)
+ * whose taps are v_muladd / v_fma: one rounding where the scalar loops of 2.4 / 3.x (and this file, built with -ffp-contract=off) have two.
+ *   0 (default)  scalar order, every product and sum rounded
+ *   1            the vector paths' form: fma(S[-k] + S[k], k_k, acc) for the symmetric small row / every column filter, fma(S[j], k_j, acc) for
+ *                the general row filter, fma(S0, b0, S1 * b1) for the vertical lerp of resize; the horizontal lerp (HResizeLinear: no float
+ *                vector path) stays as it is.  Restated from memory of the 4.x sources: "parity unpinned" like the rest; the switch
+ *                exists so that the day a cv2 is at hand tests/test_cv2_crosscheck.py can say which variant it is.  optflowgf.cpp itself is plain
+ *                C++ built for the baseline ISA: nothing in it is contracted. */
+static int g_filter_contraction = 0;
+void orc_set_filter_contraction(int on) { g_filter_contraction = on ? 1 : 0; }
+int orc_get_filter_contraction(void) { return g_filter_contraction; }
+static inline float madd(float a, float b, float c) { return g_filter_contraction ? fmaf(a, b, c) : a * b + c; }
+
 void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize, double sigma)
 {
     float kbuf[64];
@@ -117,12 +131,12 @@ void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize
             const int *ix = xi + x + r; /* ix[j] = source column of tap j */
             float s;
             if (ksize == 3) {
-                s = S[ix[0]] * kc[0] + (S[ix[-1]] + S[ix[1]]) * kc[1];
+                s = madd(S[ix[-1]] + S[ix[1]], kc[1], S[ix[0]] * kc[0]);
             } else if (ksize == 5) {
-                s = S[ix[0]] * kc[0] + (S[ix[-1]] + S[ix[1]]) * kc[1] + (S[ix[-2]] + S[ix[2]]) * kc[2];
+                s = madd(S[ix[-2]] + S[ix[2]], kc[2], madd(S[ix[-1]] + S[ix[1]], kc[1], S[ix[0]] * kc[0]));
             } else {
                 s = kern[0] * S[ix[-r]];
-                for (int j = 1; j < ksize; j++) s += S[ix[j - r]] * kern[j];
+                for (int j = 1; j < ksize; j++) s = madd(S[ix[j - r]], kern[j], s);
             }
             D[x] = s;
         }
@@ -133,7 +147,7 @@ void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize
             const float *S0 = tmp + (size_t)orc_border_reflect101(y - 1, h) * w;
             const float *S1 = tmp + (size_t)y * w;
             const float *S2 = tmp + (size_t)orc_border_reflect101(y + 1, h) * w;
-            for (int x = 0; x < w; x++) D[x] = (S0[x] + S2[x]) * kc[1] + S1[x] * kc[0];
+            for (int x = 0; x < w; x++) D[x] = madd(S0[x] + S2[x], kc[1], S1[x] * kc[0]);
         } else {
             const float *S1 = tmp + (size_t)y * w;
             for (int x = 0; x < w; x++) D[x] = kc[0] * S1[x];
@@ -141,7 +155,7 @@ void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize
                 const float *Sa = tmp + (size_t)orc_border_reflect101(y + k, h) * w;
                 const float *Sb = tmp + (size_t)orc_border_reflect101(y - k, h) * w;
                 float f = kc[k];
-                for (int x = 0; x < w; x++) D[x] += f * (Sa[x] + Sb[x]);
+                for (int x = 0; x < w; x++) D[x] = madd(Sa[x] + Sb[x], f, D[x]);
             }
         }
     }
@@ -224,7 +238,7 @@ void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst,
         }
         float b0 = ya0[dy], b1 = ya1[dy];
         float *D = dst + (size_t)dy * dw * cn;
-        for (int i = 0; i < dw * cn; i++) D[i] = r0[i] * b0 + r1[i] * b1;
+        for (int i = 0; i < dw * cn; i++) D[i] = madd(r0[i], b0, r1[i] * b1);
     }
     free(xo); free(yo); free(xa0); free(xa1); free(ya0); free(ya1); free(r0); free(r1);
 }

@@ -20,6 +20,14 @@
 #define ORC_LUMA_R 0.2126f
 #define ORC_LUMA_G 0.7152f
 #define ORC_LUMA_B 0.0722f
+/* ... or Rec.601 (orc_set_luma(601)): which set supportext uses cannot be verified here, so it is a switch of the oracle and of the library
+ * (option "lut.luma"), like the OpenCV generation switches of farneback.c */
+#define ORC_LUMA601_R 0.299f
+#define ORC_LUMA601_G 0.587f
+#define ORC_LUMA601_B 0.114f
+static int g_luma601 = 0;
+void orc_set_luma(int standard) { g_luma601 = standard == 601; }
+int orc_get_luma(void) { return g_luma601 ? 601 : 709; }
 
 static float to_func_srgb(float v)
 {
@@ -75,7 +83,7 @@ void orc_to_byte_grayscale(const float *src, ptrdiff_t src_row_bytes, int ncomp,
         const float *s = (const float *)((const char *)src + y * src_row_bytes);
         uint8_t *d = dst + y * dst_row_bytes;
         for (int x = 0; x < w; x++, s += ncomp) {
-            float l = ORC_LUMA_R * s[0] + ORC_LUMA_G * s[1] + ORC_LUMA_B * s[2];
+            float l = g_luma601 ? ORC_LUMA601_R * s[0] + ORC_LUMA601_G * s[1] + ORC_LUMA601_B * s[2] : ORC_LUMA_R * s[0] + ORC_LUMA_G * s[1] + ORC_LUMA_B * s[2];
             d[x] = (uint8_t)((lut[hipart(l)] + 0x80) >> 8);
         }
     }

@@ -59,6 +59,12 @@ void orc_gaussian_blur_f32(const float *src, int w, int h, float *dst, int ksize
  * ((a+b)+(c+d))/4 = the bilinear form = 4.x SIMD, 1 (((a+b)+c)+d)/4 scalar loop, 2 ((a+c)+(b+d))/4 3.x SSE2 */
 void orc_set_resize_generation(int generation);
 int orc_get_resize_generation(void);
+/* 1: the separable filters and resize's vertical lerp with fused multiply-adds, as OpenCV 4.x's AVX2 / NEON paths (farneback.c) */
+/* luma weights of orc_to_byte_grayscale: 709 (default) or 601 */
+void orc_set_luma(int standard);
+int orc_get_luma(void);
+void orc_set_filter_contraction(int on);
+int orc_get_filter_contraction(void);
 void orc_resize_linear_f32(const float *src, int sw, int sh, int cn, float *dst, int dw, int dh);
 
 /* FarnebackPrepareGaussian: g/xg/xxg hold 2n+1 entries each (index k+n), ig = {ig11,ig03,ig33,ig55} */

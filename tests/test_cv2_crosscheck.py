@@ -46,8 +46,9 @@ def _golden(name):
 
 
 def test_oracle_farneback_stages_vs_cv2(oracle):
-    """Stage by stage, so that the day a cv2 exists the log says WHICH stage and WHICH variant of the two generation switches
-    (getGaussianKernel 2.4 / 3.x vs 4.x; the association of cv::resize's exact-2x INTER_AREA rewrite) agrees with it:
+    """Stage by stage, so that the day a cv2 exists the log says WHICH stage and WHICH variant of the three generation switches
+    (getGaussianKernel 2.4 / 3.x vs 4.x; the association of cv::resize's exact-2x INTER_AREA rewrite; separable filters with separate roundings or
+    fused multiply-adds) agrees with it:
     getGaussianKernel, GaussianBlur on a float image, resize at 2x, 4x and a non-integer factor.  (FarnebackPolyExp and
     FarnebackUpdateFlow_Blur are internal to cv2; past the pyramid image the next observable stage is the whole call, below.)
     Exact counts are printed; the variant that matches the cv2 at hand must match at EVERY sample."""
@@ -64,23 +65,31 @@ def test_oracle_farneback_stages_vs_cv2(oracle):
                 ref = cv2.getGaussianKernel(n, sigma, cv2.CV_32F).ravel()
                 report[("getGaussianKernel", gauss, n)] = int((ref != oracle.gaussian_kernel(n, sigma)).sum())
                 ref = cv2.GaussianBlur(f, (n, n), sigma, sigmaY=sigma, borderType=cv2.BORDER_REFLECT_101)
-                report[("GaussianBlur", gauss, n)] = int((ref != oracle.gaussian_blur(f, n, sigma)).sum())
+                for fc in (0, 1):  # the separable filters with separate roundings (2.4 / 3.x, scalar builds) or fused multiply-adds (4.x AVX2 / NEON)
+                    oracle.set_filter_contraction(fc)
+                    report[("GaussianBlur", gauss, n, "contraction %d" % fc)] = int((ref != oracle.gaussian_blur(f, n, sigma)).sum())
+                oracle.set_filter_contraction(0)
         oracle.set_gaussian_kernel_generation(3)
         blurred = oracle.gaussian_blur(f, 3, 0.5)
         for rz in (0, 1, 2):
             oracle.set_resize_generation(rz)
             for dw, dh in ((320, 240), (160, 120), (213, 160)):
                 ref = cv2.resize(blurred, (dw, dh), interpolation=cv2.INTER_LINEAR)
-                report[("resize", rz, dw)] = int((ref != oracle.resize_linear(blurred, dw, dh)).sum())
+                for fc in (0, 1):
+                    oracle.set_filter_contraction(fc)
+                    report[("resize", rz, dw, "contraction %d" % fc)] = int((ref != oracle.resize_linear(blurred, dw, dh)).sum())
+                oracle.set_filter_contraction(0)
     finally:
         oracle.set_gaussian_kernel_generation(3)
         oracle.set_resize_generation(0)
+        oracle.set_filter_contraction(0)
     for k in sorted(report, key=str):
         print("cv2 %s stage diff %s: %d differing samples" % (cv2.__version__, k, report[k]))
     assert min(report[("getGaussianKernel", g, 9)] + report[("getGaussianKernel", g, 19)] for g in (3, 4)) == 0, report
-    assert min(report[("GaussianBlur", g, 9)] + report[("GaussianBlur", g, 19)] for g in (3, 4)) == 0, report
-    assert min(report[("resize", rz, 320)] for rz in (0, 1, 2)) == 0, report
-    assert report[("resize", 0, 160)] == 0 and report[("resize", 0, 213)] == 0, report
+    fcs = ("contraction 0", "contraction 1")
+    assert min(report[("GaussianBlur", g, 9, c)] + report[("GaussianBlur", g, 19, c)] for g in (3, 4) for c in fcs) == 0, report
+    assert min(report[("resize", rz, 320, c)] for rz in (0, 1, 2) for c in fcs) == 0, report
+    assert min(report[("resize", 0, 160, c)] + report[("resize", 0, 213, c)] for c in fcs) == 0, report
 
 
 def test_oracle_farneback_vs_cv2(oracle):
@@ -97,21 +106,24 @@ def test_oracle_farneback_vs_cv2(oracle):
     try:
         for gen in (3, 4):
             for rz in (0, 1, 2):
-                oracle.set_gaussian_kernel_generation(gen)
-                oracle.set_resize_generation(rz)
-                for name, x, y in cases:
-                    ref = cv2.calcOpticalFlowFarneback(x, y, None, 0.5, 3, 3, 15, 5, 1.1, 0)
-                    mine = oracle.calc_optical_flow_farneback(x, y, blur_mode=oracle.BLUR_FAITHFUL)
-                    err = np.abs(ref - mine)
-                    bad = int((err > 1e-4 * np.maximum(1, np.abs(ref))).sum())
-                    results[(gen, rz, name)] = bad
-                    print("cv2 %s calcOpticalFlowFarneback vs oracle FAITHFUL (getGaussianKernel generation %d, resize generation %d), %s: "
-                          "max |err| %.3g, outside 1e-4: %d of %d, bit-identical %d"
-                          % (cv2.__version__, gen, rz, name, err.max(), bad, err.size, int((ref == mine).sum())))
+                for fc in (0, 1):
+                    oracle.set_gaussian_kernel_generation(gen)
+                    oracle.set_resize_generation(rz)
+                    oracle.set_filter_contraction(fc)
+                    for name, x, y in cases:
+                        ref = cv2.calcOpticalFlowFarneback(x, y, None, 0.5, 3, 3, 15, 5, 1.1, 0)
+                        mine = oracle.calc_optical_flow_farneback(x, y, blur_mode=oracle.BLUR_FAITHFUL)
+                        err = np.abs(ref - mine)
+                        bad = int((err > 1e-4 * np.maximum(1, np.abs(ref))).sum())
+                        results[(gen, rz, fc, name)] = bad
+                        print("cv2 %s calcOpticalFlowFarneback vs oracle FAITHFUL (getGaussianKernel generation %d, resize generation %d, filter contraction %d), %s: "
+                              "max |err| %.3g, outside 1e-4: %d of %d, bit-identical %d"
+                              % (cv2.__version__, gen, rz, fc, name, err.max(), bad, err.size, int((ref == mine).sum())))
     finally:
         oracle.set_gaussian_kernel_generation(3)
         oracle.set_resize_generation(0)
-    assert any(all(results[(gen, rz, name)] == 0 for name, _, _ in cases) for gen in (3, 4) for rz in (0, 1, 2)), results
+        oracle.set_filter_contraction(0)
+    assert any(all(results[(gen, rz, fc, name)] == 0 for name, _, _ in cases) for gen in (3, 4) for rz in (0, 1, 2) for fc in (0, 1)), results
 
 
 def test_oracle_inpaint_vs_cv2(oracle):

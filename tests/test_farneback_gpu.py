@@ -169,6 +169,44 @@ def test_update_flow_blur_matches_direct_oracle(oracle, ofxcv, direct_ctx, w, h,
     err = np.abs(f_flow - flow.cpu().numpy())
     assert (err <= REL_TOL * np.maximum(1, np.abs(f_flow))).all()
 
+@pytest.mark.parametrize("w,h", [(333, 257), (640, 480)])
+def test_pyr_image_filter_contraction_bit_exact(oracle, ofxcv, w, h):
+    """A third generation switch: OpenCV 4.x runs the separable filters and resize's vertical lerp through
+    universal-intrinsics code whose taps are fused multiply-adds; the oracle (orc_set_filter_contraction) and the library
+    (farneback.filter_contraction) follow together: every pyramid image bit-identical in every kernel family (dword / LDS-fused / two-pass),
+    the whole call -- whose flow prolongation is a resize as well -- within 1e-4 at every sample, and the switch is not vacuous."""
+    ga, gb = _gray_pair(oracle, w, h)
+    levels = ofxcv.farneback_num_levels(w, h, 0.5, 3)
+    ctx = ofxcv.Context(0)
+    images = {}
+    try:
+        for fc in (0, 1):
+            oracle.set_filter_contraction(fc)
+            ctx.set_option("farneback.filter_contraction", fc)
+            assert ctx.get_option("farneback.filter_contraction") == fc
+            for fused in (1, 0):
+                ctx.set_option("farneback.fused_pyramid", fused)
+                for k in range(levels + 1):
+                    lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
+                    ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
+                    got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+                    assert np.array_equal(ref, got), "contraction %d fused %d level %d: max diff %g" % (fc, fused, k, np.abs(ref - got).max())
+                    images[(fc, k)] = ref
+            ctx.set_option("farneback.fused_pyramid", 1)
+            ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL)
+            got = ctx.calc_optical_flow_farneback(_dev(ga), _dev(gb)).cpu().numpy()
+            err = np.abs(ref - got)
+            assert (err <= REL_TOL * np.maximum(1, np.abs(ref))).all(), "contraction %d: max err %g" % (fc, err.max())
+            print("filter contraction %d: whole call bit-identical to the oracle at %.6f of the samples" % (fc, (ref == got).mean()))
+    finally:
+        oracle.set_filter_contraction(0)
+        ctx.close()
+    changed = [k for k in range(levels + 1) if not np.array_equal(images[(0, k)], images[(1, k)])]
+    assert changed, "the contracted filters gave the same images at every level"
+    for k in changed:   # one rounding less per tap: last-bit differences only
+        assert np.abs(images[(0, k)] - images[(1, k)]).max() <= 2e-5 * 255
+
+
 
 def _check_flow(oracle, got, ga, gb, **kw):
     direct = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_DIRECT, **kw)
@@ -240,6 +278,41 @@ def test_farneback_1080p_properties(oracle, ofxcv, direct_ctx):
     assert np.abs(got[..., 0] - u)[inner].mean() < 0.3 and np.abs(got[..., 1] - v)[inner].mean() < 0.3
     zero = direct_ctx.calc_optical_flow_farneback(ga, ga)
     assert float(zero[:500, :900].abs().max()) == 0.0   # identical frames: zero far from the bottom/right border
+
+
+def test_gray_lut_luma_weights_switch(oracle, ofxcv):
+    """The luma weights of supportext's to_byte_grayscale_nodither cannot be verified here (empty submodule): Rec.709 (default) and
+    Rec.601 are a switch of the oracle (orc_set_luma) and of the library (lut.luma), bit-exact against each other in every LUT kernel, and they do
+    give different gray images."""
+    rng = np.random.default_rng(8)
+    imgs = [rng.uniform(-0.1, 1.2, size=(37, 53, 4)).astype(np.float32), rng.uniform(-0.1, 1.2, size=(40, 256 + 52, 4)).astype(np.float32),
+            rng.uniform(0, 1, size=(33, 64, 3)).astype(np.float32)]
+    c = ofxcv.Context(0)
+    out = {}
+    try:
+        for std in (709, 601):
+            oracle.set_luma(std)
+            c.set_option("lut.luma", std)
+            assert c.get_option("lut.luma") == std
+            for i, im in enumerate(imgs):
+                ref = oracle.to_byte_grayscale(im)
+                assert np.array_equal(c.to_byte_grayscale(_dev(im)).cpu().numpy(), ref), (std, i)
+                out[(std, i)] = ref
+            wide = [imgs[1], imgs[1][::-1].copy()]
+            import torch
+            dst = [torch.empty((40, 256 + 52), dtype=torch.uint8, device="cuda") for _ in wide]
+            c.to_byte_grayscale_batch([_dev(x) for x in wide], dst)
+            assert np.array_equal(dst[0].cpu().numpy(), out[(std, 1)])
+    finally:
+        oracle.set_luma(709)
+        c.close()
+    assert not np.array_equal(out[(709, 0)], out[(601, 0)])
+    with pytest.raises(ofxcv.OfxcvError):
+        c2 = ofxcv.Context(0)
+        try:
+            c2.set_option("lut.luma", 2020)
+        finally:
+            c2.close()
 
 
 def test_gray_lut_and_scatter(oracle, ofxcv, direct_ctx):
