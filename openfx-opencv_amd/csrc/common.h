@@ -122,6 +122,7 @@ struct ofxcv_ctx {
     int ip_portion = 0;      // option "inpaint.portion": fill-order pixels per portion of the pipelined fill (0 = default)
     DevBuf ip_sched2; // level schedule of the fall-back fill
     int ip_max_tiles = 0;    // option "inpaint.max_tiles": workgroups (tiles) per fill launch; 0 = the chip's share of this call (192 / concurrent fills, at least 48)
+    int ip_dynamic = 0;      // option "inpaint.dynamic_grab": tile schedule, the wavefronts of a tile take its next pixel from an LDS counter (1) instead of every 16th in fill order (0)
     int ip_tiles = 1;        // option "inpaint.tiles": tile schedule of the dataflow fill (a workgroup per occupied tile of a portion, hand-offs inside a tile through LDS); 0 = component schedule (every hand-off through the L2)
     int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)
     int ip_parallel_march = 0;  // option "inpaint.parallel_march": 0 (default) serial front march, pipelined with the fill; 1 the hole's 4-connected

@@ -312,6 +312,10 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         ctx->ip_max_tiles = value;
         return OFXCV_OK;
     }
+    if (!std::strcmp(name, "inpaint.dynamic_grab")) {
+        ctx->ip_dynamic = value != 0;
+        return OFXCV_OK;
+    }
     if (!std::strcmp(name, "inpaint.tiles")) {
         ctx->ip_tiles = value != 0;
         return OFXCV_OK;
