@@ -2546,7 +2546,6 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         for (int c = 0; c < 5; c++) q[j].r0v[c] = r0c[j + 1][c];
                         q[j].tp = gather(x, y, fx1[j], fy1[j]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST1 && p >= DEPTH) {
                     const int j = p - DEPTH, y = min(a + j, h - 1);
@@ -2556,7 +2555,6 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         m1[j][c] = mm.v[c];
                         if (j >= 3) d2[j][c] = mm.v[c] - m1[j - 3][c];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -2628,7 +2626,6 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         for (int c = 0; c < 5; c++) q[i].r0v[c] = r0c[i][c];
                         q[i].tp = gather(x, y, fx2[i], fy2[i]);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (!LAST2 && p >= DEPTH) {
                     const int i = p - DEPTH, y = clampi(a - 1 + i, 0, h - 1);
@@ -2639,7 +2636,6 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
                         if (i == 1 && topw) m2[0][c] = mm.v[c];  // the row above row 0 is row 0
                         if (i >= 3) st_d3(mm.v[c] - m2[i - 3][c], i, c);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
