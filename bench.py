@@ -363,15 +363,18 @@ def main():
     one_in_flight = one_batch_in_flight = three_single = batch16 = lock_hold_us = lock_call_us = None
     if world == 1:
         n1 = max(10, args.steps // 2)
-        lh0 = ctxs[0].lock_hold()
         e1 = timed_regions(ctxs[:1], bufs[:1], n1, 3, 3)
-        lh1 = ctxs[0].lock_hold()
         one_batch_in_flight = n1 * B / statistics.median(e1)
-        # time inside the process-wide runtime lock (hipGraphLaunch of the call's captured launch sequence) per batched call: with G devices driven
-        # from ONE host process the lock is busy hold x G / call time of the time
-        lock_calls = 3 + 3 * n1  # warm-up + three regions
-        lock_hold_us = (lh1[0] - lh0[0]) / 1e3 / max(1, lock_calls)
         lock_call_us = statistics.median(e1) / n1 * 1e6
+        # time inside the process-wide runtime lock (the hipGraphLaunch of the call's captured launch sequence) per batched call, measured on calls
+        # that are waited for one by one: in a saturated loop hipGraphLaunch blocks on the stream's queue and the hold is the call's own GPU time.
+        # With G devices driven from ONE host process the lock is busy hold x G / call time of the time
+        lh0 = ctxs[0].lock_hold()
+        for _ in range(10):
+            step(ctxs[:1], bufs[:1])
+            torch.cuda.synchronize()
+        lh1 = ctxs[0].lock_hold()
+        lock_hold_us = (lh1[0] - lh0[0]) / 1e3 / max(1, lh1[1] - lh0[1])
         one = [{k: v[:1] for k, v in bufs[0].items()}]  # a single pair per call on one stream: what one unbatched caller gets
         e1 = timed_regions(ctxs[:1], one, n1, 3, 3)
         one_in_flight = n1 / statistics.median(e1)
