@@ -84,6 +84,7 @@ struct ofxcv_ctx {
     // (halo_min8 300, was 250: a launch of exactly 256 tall workgroups -- 960x540 x 2 pairs, 480x270 x 8 -- is one round at half occupancy;
     // the five-row form takes those: batches of 2 958 -> 1 024 pairs/s, batches of 8 +0.9 %, single calls and batches of 4 unchanged)
     int fb_halo_geom = 0, fb_halo_min8 = 300, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
+    int fb_pyr_rows = 1;         // option "farneback.pyr_rows": the 3-tap pyramid levels in the wavefront-row form (pyr_direct3w_kernel); 0 = one sample group per lane
     int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
     int lut_luma601 = 0;         // option "lut.luma" 709 (default) | 601: luma weights of the gray conversion (supportext's are not verifiable here)
     int lut4 = 1;                // option "lut.four": gray LUT with four pixels per lane where the images are aligned for it

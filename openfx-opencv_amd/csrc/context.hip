@@ -329,7 +329,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
         struct { const char *n; int *v; int lo, hi; } knobs[] = {
             {"farneback.halo_geom", &ctx->fb_halo_geom, 0, 3},    {"farneback.halo_min8", &ctx->fb_halo_min8, 0, 1 << 30},
             {"farneback.halo_min4", &ctx->fb_halo_min4, 0, 1 << 30}, {"farneback.halo_strip", &ctx->fb_halo_strip, 0, 72},
-            {"farneback.halo_deep", &ctx->fb_halo_deep, 0, 8},    {"farneback.halo_small", &ctx->fb_halo_small, 2, 6},
+            {"farneback.halo_deep", &ctx->fb_halo_deep, 0, 8},    {"farneback.pyr_rows", &ctx->fb_pyr_rows, 0, 1},    {"farneback.halo_small", &ctx->fb_halo_small, 2, 6},
             {"farneback.halo_min5", &ctx->fb_halo_min5, 0, 1 << 30}, {"lut.four", &ctx->lut4, 0, 1},
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
             {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},

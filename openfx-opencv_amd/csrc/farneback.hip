@@ -628,6 +628,87 @@ __global__ __launch_bounds__(256) void pyr_direct3v_kernel(ImgTab imgs, int W, i
     }
 }
 
+// Wavefront-row form of pyr_direct3v_kernel (round 5).  That kernel is bound by the texture addresser, not by memory: 9 (k = 0) / 12 (k = 1) dword
+// loads per lane for four / two samples, 166 MB of a level-0 launch at 2.3 TB/s.  Here a lane loads ONE dword per source row -- its own four
+// columns -- and takes the byte on either side from its neighbour lanes (DPP wave shifts; lanes 0 and 63 only carry those bytes, 62 lanes x 4 = 248
+// columns per wavefront, which is the same eight wavefronts across 1920 columns), and it walks ROWS output rows top to bottom so that every
+// source row is loaded and row-filtered once per wavefront instead of three (k = 0) or two (k = 1) times: 0.31 / 1.25 loads per sample instead
+// of 2.25 / 6.  Frames whose width is a multiple of four; the arithmetic and its order are pyr_direct3v_kernel's.
+template <int NTAP, int ROWS>
+__global__ __launch_bounds__(256) void pyr_direct3w_kernel(ImgTab imgs, int W, int H, int lw, int lh, float k0, float k1, float *__restrict__ I,
+                                                           size_t I_stride, int area_fc) {
+    const int area = area_fc & 15, fc = area_fc >> 4;  // (bit 4: filter contraction, see madd)
+    int tbx, tby, tbz;
+    xcd_tile(tbx, tby, tbz);
+    const uint8_t *__restrict__ img = imgs.p[tbz];
+    const size_t step = imgs.step[tbz];
+    I += (size_t)tbz * I_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = tbx * 248 + (lane - 1) * 4;          // first source column of this lane (lanes 0 / 63: the neighbours' bytes only)
+    const int cl = min(max(c0, 0), W - 4);              // the dword it loads
+    const bool left_edge = c0 == 0, right_edge = c0 + 4 == W;
+    const bool own = lane >= 1 && lane <= 62 && c0 < W;
+    const int dy0 = (tby * 4 + wave) * ROWS;             // first output row of this wavefront
+    if (dy0 >= lh) return;                               // (wave-uniform)
+    constexpr int NS = NTAP == 1 ? ROWS + 2 : 2 * ROWS + 2;  // source rows sy0 - 1 ..
+    const int sy0 = NTAP == 1 ? dy0 : 2 * dy0;
+    unsigned d[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) d[r] = *(const unsigned *)(img + (size_t)reflect101(min(sy0 - 1 + r, H), H) * step + cl);
+    float rf[NS][4];  // row-filtered samples at columns c0 .. c0+3
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        const unsigned hi = d[r] >> 24, lo = d[r] & 255u;
+        const unsigned from_left = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xf, 0xf, true);   // lane i <- lane i-1: column c0 - 1
+        const unsigned from_right = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, true);  // lane i <- lane i+1: column c0 + 4
+        float b[6];
+        b[1] = (float)lo;
+        b[2] = (float)((d[r] >> 8) & 255u);
+        b[3] = (float)((d[r] >> 16) & 255u);
+        b[4] = (float)hi;
+        b[0] = left_edge ? b[2] : (float)from_left;      // reflect101: column -1 is column 1
+        b[5] = right_edge ? b[3] : (float)from_right;    // ... column W is column W - 2
+#pragma unroll
+        for (int j = 0; j < 4; j++) rf[r][j] = madd(b[j] + b[j + 2], k1, b[j + 1] * k0, fc);
+    }
+    if (!own) return;
+    // column filter at source row sy (+ sy+1):  (T[-1] + T[1])*k1 + T[0]*k0
+#pragma unroll
+    for (int i = 0; i < ROWS; i++) {
+        const int dy = dy0 + i;
+        if (dy >= lh) break;
+        if (NTAP == 1) {
+            float *out = I + (size_t)dy * lw + c0;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = madd(rf[i][j] + rf[i + 2][j], k1, rf[i + 1][j] * k0, fc);
+            if ((((uintptr_t)I) & 15) == 0) {  // lw is a multiple of 4, c0 too: one aligned 16-byte store
+                *(float4 *)out = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) out[j] = v[j];
+            }
+        } else {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                t0[j] = madd(rf[2 * i][j] + rf[2 * i + 2][j], k1, rf[2 * i + 1][j] * k0, fc);
+                t1[j] = madd(rf[2 * i + 1][j] + rf[2 * i + 3][j], k1, rf[2 * i + 2][j] * k0, fc);
+            }
+            float *out = I + (size_t)dy * lw + (c0 >> 1);
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) v[q] = resize_combine(t0[2 * q], t0[2 * q + 1], t1[2 * q], t1[2 * q + 1], 0.5f, 0.5f, 0.5f, 0.5f, area, fc);
+            if ((lw & 1) == 0 && (((uintptr_t)I) & 7) == 0) {
+                *(float2 *)out = make_float2(v[0], v[1]);
+            } else {
+                out[0] = v[0];
+                out[1] = v[1];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ F3 polynomial expansion
 //
 // One 64x16 output tile per 256-thread block.  The tile of I plus an n-pixel halo is staged in
@@ -2755,6 +2836,17 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
     bool aligned = true;
     for (int i = 0; i < nimg; i++) aligned = aligned && ((uintptr_t)imgs.p[i] & 3) == 0 && (imgs.step[i] & 3) == 0;
     const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && aligned && (I_stride & 3) == 0;
+    if (dword_ok && ctx->fb_pyr_rows && (W & 3) == 0 && H >= 4 && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
+        // eight (k = 0) / four (k = 1) output rows per wavefront, four wavefronts per workgroup
+        if (ntap == 1)
+            hipLaunchKernelGGL((pyr_direct3w_kernel<1, 8>), dim3(ofxcv_div_up(W, 248), ofxcv_div_up(lh, 32), nimg), dim3(256), 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I,
+                               I_stride, fcb);
+        else
+            hipLaunchKernelGGL((pyr_direct3w_kernel<2, 4>), dim3(ofxcv_div_up(W, 248), ofxcv_div_up(lh, 16), nimg), dim3(256), 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I,
+                               I_stride, area | fcb);
+        OFXCV_LAUNCH_CHECK(ctx, "pyr_direct3w_kernel");
+        return OFXCV_OK;
+    }
     if (dword_ok && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
         dim3 grid(ofxcv_div_up(ofxcv_div_up(W, 4), 64), ofxcv_div_up(lh, 4), nimg), block(64, 4);
         if (ntap == 1) hipLaunchKernelGGL(pyr_direct3v_kernel<1>, grid, block, 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I, I_stride, fcb);

@@ -82,6 +82,37 @@ def test_pyr_image_quarter_and_eighth_levels(oracle, ofxcv, w, h):
         ctx.close()
 
 
+@pytest.mark.parametrize("w,h", [(16, 4), (64, 48), (248, 66), (252, 34), (496, 130), (1000, 36), (1920, 1080)])
+def test_pyr_image_three_tap_levels_wavefront_rows(oracle, ofxcv, w, h):
+    """Levels 0 and 1 of the default pyramid (3 taps; same size / exactly half) on frames whose width is a multiple of four take
+    pyr_direct3w_kernel (one dword per lane and source row, the neighbour bytes from the neighbour lanes, several output rows per wavefront):
+    bit-identical to the oracle and to the one-group-per-lane kernel (option farneback.pyr_rows 0) -- tile seams at 248 columns, both image
+    edges inside one wavefront, heights that end inside a wavefront's rows -- with the filter contraction and resize generations on as well."""
+    ga, _ = _gray_pair(oracle, w, h)
+    ctx = ofxcv.Context(0)
+    try:
+        for fc, rz in ((0, 0), (1, 0), (0, 1), (1, 2)):
+            oracle.set_filter_contraction(fc)
+            oracle.set_resize_generation(rz)
+            ctx.set_option("farneback.filter_contraction", fc)
+            ctx.set_option("farneback.resize_generation", rz)
+            for k in (0, 1):
+                if k == 1 and (w % 2 or h % 2):
+                    continue
+                lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
+                ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
+                ctx.set_option("farneback.pyr_rows", 1)
+                got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+                ctx.set_option("farneback.pyr_rows", 0)
+                other = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
+                assert np.array_equal(ref, got), "level %d (fc %d, resize %d) max diff %g" % (k, fc, rz, np.abs(ref - got).max())
+                assert np.array_equal(ref, other)
+    finally:
+        oracle.set_filter_contraction(0)
+        oracle.set_resize_generation(0)
+        ctx.close()
+
+
 @pytest.mark.parametrize("w,h", [(64, 48), (160, 120), (98, 74), (640, 480)])
 def test_pyr_image_generations_bit_exact(oracle, ofxcv, w, h):
     """The two places where OpenCV generations are known (from their published sources) to differ in the last bit, as matching
