@@ -495,13 +495,14 @@ def main():
                                                             "(`frac` of rounds 1-4; 0.81 in round 4).  Not what the fused launch moves: side key only"},
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one batched call in flight; the pairs include the dependent-launch gap -- the rocprofv3 "
-                               "durations of the same launches are in profiles/r04_bench_default_by_grid.txt",
+                               "durations of the same launches are in profiles/r05_bench_default_by_grid.txt",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_note": "L2 <-> fabric bytes per launch (TCC_EA0 read requests x their size + write requests); Infinity-Cache hits are counted",
-                     "bound_actual": ("the launch moves its minimal bytes (1.43 GB for 8 pairs: every field once per two iterations) at well below the copy rate; what holds it is "
-                                      "the CU: the texture addresser (10 two-dword gathers per pixel row and iteration) and f64 vector issue, each about 40 % busy over the launch, "
-                                      "with two wavefronts per SIMD to overlap them (profiles/r04_experiments.md)" if col else
+                     "bound_actual": ("the launch moves its minimal bytes (1.42 GB for 8 pairs: every field once per two iterations, traffic_over_min 1.02) at about 0.7 of the copy rate; "
+                                      "what holds it is the workgroup, not memory: a round of 32 rows is 19 k cycles for eight wavefronts that hand two f64 column sums and six boundary "
+                                      "rows to each other, two wavefronts per SIMD (155 KB of LDS: R1 ring + hand-off rows), the vector ALU 51 % busy; the same kernel on a quarter of the "
+                                      "pixels with half the chip idle runs its rounds 8 % faster (profiles/r05_experiments.md 1, 4, 10)" if col else
                                       "hbm-side: the kernel moves 1.12x its algorithmic bytes at 0.83 of the achievable copy rate"),
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
                      "valu_busy_frac": (valu_busy * 4 / (1024 * 2.4e9) / main_s) if valu_busy else None,

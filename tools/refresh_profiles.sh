@@ -21,5 +21,6 @@ for cfg in "default" "single" "b16"; do
   cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_${cfg}_kernel_stats.csv
   [ $cfg = default ] && cp $RAW/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv  # the timed workload under the plain name as well
   python $R/tools/trace_by_grid.py $RAW/b_kernel_trace.csv > $OUT/${TAG}_bench_${cfg}_by_grid.txt
+  [ $cfg = default ] && python $R/tools/step_timeline.py $RAW/b_kernel_trace.csv --window 0.15,0.45 > $OUT/${TAG}_step_timeline.txt
 done
 head -c 700 $OUT/${TAG}_bench.json; echo; head -12 $OUT/${TAG}_bench_default_by_grid.txt

@@ -80,11 +80,13 @@ def minus(A, B):
         if cur < e:
             out.append([cur, e])
     return out
-print("%-12s %8s %10s %10s %10s   (us over the window; per step of %d pairs = / steps)" % ("phase", "launches", "sum", "union", "exclusive", args.pairs))
+steps = max(1, len(by.get("gray", [])))  # one gray-LUT launch per step of the bench
+print("%d steps in the window: %.0f us of kernel time (union) per step" % (steps, length(busy) / steps))
+print("%-12s %8s %10s %10s %10s   (us per step of %d pairs)" % ("phase", "launches", "sum", "union", "exclusive", args.pairs))
 for p, iv in sorted(by.items(), key=lambda kv: -length(union(kv[1]))):
     u = union(iv)
     others = union([x for q, v in by.items() if q != p for x in v])
-    print("%-12s %8d %10.0f %10.0f %10.0f" % (p, len(iv), sum(e - s for s, e in iv) / 1e3, length(u), length(minus(u, others))))
+    print("%-12s %8.1f %10.0f %10.0f %10.0f" % (p, len(iv) / steps, sum(e - s for s, e in iv) / 1e3 / steps, length(u) / steps, length(minus(u, others)) / steps))
 # gaps inside the iteration chain: consecutive iterate* dispatches, end -> next start, when nothing of the chain runs in between
 chain = [r for r in rows if r[2].startswith("iterate")]
 gaps = collections.defaultdict(list)
