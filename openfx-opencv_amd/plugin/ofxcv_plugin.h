@@ -158,7 +158,13 @@ struct ImageGuard {
             img.scale_y = sc[1];
         }
         if (s.prop->propGetString(img.handle, kOfxImagePropField, 0, &str) == kOfxStatOK && str) img.field = str;
-        if (s.prop->propGetString(img.handle, kOfxImagePropUniqueIdentifier, 0, &str) == kOfxStatOK && str) img.unique_id = str;
+        // (tagged with the clip it came from: a host that hands out the same identifiers on different clips or instances does not get one clip's frames
+        // for another's -- the device-side cache trusts the name; frames of one clip of one instance, the playback case, still find each other)
+        if (s.prop->propGetString(img.handle, kOfxImagePropUniqueIdentifier, 0, &str) == kOfxStatOK && str && *str) {
+            char tag[40];
+            std::snprintf(tag, sizeof tag, "%p:", (void *)clip);
+            img.unique_id = std::string(tag) + str;
+        }
     }
     ~ImageGuard() {
         if (img.handle) s.effect->clipReleaseImage(img.handle);

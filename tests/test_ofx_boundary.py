@@ -422,10 +422,11 @@ def test_vectorgenerator_sequence_with_image_identifiers(host):
     pl = Plugin(host, "VectorGenerator")
     outs = {}
 
-    def render(inst, t, ids):
+    def render(inst, t, ids, frames=None):
+        frames = seq if frames is None else frames
         out = np.full((h, w, 4), -9.0, np.float32)
         for u in (t - 1, t, t + 1):
-            pl.set_image(inst, "Source", float(u), seq[u], "OfxBitDepthFloat")
+            pl.set_image(inst, "Source", float(u), frames[u], "OfxBitDepthFloat")
             if ids:
                 assert host.mh_set_image_id(inst, b"Source", C.c_double(float(u)), ids[u].encode()) == 0
         pl.set_image(inst, "Output", float(t), out, "OfxBitDepthFloat")
@@ -441,10 +442,18 @@ def test_vectorgenerator_sequence_with_image_identifiers(host):
     for t in (1, 2, 3):
         assert np.array_equal(outs[(True, t)], outs[(False, t)]), t
     inst = pl.instance()
+    assert np.array_equal(render(inst, 2, ids), outs[(True, 2)])    # frames 1 .. 3 on the device under this clip's names
     seq[3][...] = synth.flow_pair(w, h, seed=91)[0]                 # new pixels in frame 3 ...
     stale = render(inst, 2, ids)                                    # ... under its old name: the frame on the device is used
     assert np.array_equal(stale, outs[(True, 2)])
     ids[3] = "ofxcv-test-seq-3-v2"                                  # renamed, as a host does when pixels change
     fresh = render(inst, 2, ids)
     assert np.array_equal(fresh, render(inst, 2, None)) and not np.array_equal(fresh, stale)
+    # a second instance whose host hands out the SAME identifiers for other pixels (identifiers that are only unique per clip): the names carry the
+    # clip they came from, so it gets its own frames
+    other = pl.instance()
+    seq_b = [synth.flow_pair(w, h, seed=60 + i)[0].copy() for i in range(5)]
+    got_b = render(other, 2, ids, seq_b)
+    assert np.array_equal(got_b, render(other, 2, None, seq_b)) and not np.array_equal(got_b, fresh)
+    pl.destroy(other)
     pl.destroy(inst)
