@@ -93,7 +93,7 @@ struct ofxcv_ctx {
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
     int fb_col_min = 128;        // option "farneback.col_min": workgroups (tile columns x pairs) below which no launch takes that form; from there on a cost model decides per level how many pairs do (col_pairs in farneback.hip); values below the default force the form (tests)
     int fb_col_split = 1;        // option "farneback.col_split": the pairs of a call that do not fill a round of the chip in that form keep the overlapped strips (1); 0 = all pairs or none
-    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (the second geometry the tests walk; no ring)
+    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (three wavefronts per SIMD: the boundary rows of the two steps share one LDS buffer beside the ring; 317 against 325 us per launch, not the default)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
     int fb_reuse_prep = 0;       // option "farneback.reuse_prep" (measurement probe): skip the pyramid images / polynomial expansions, the scratch still holds those of the same frames

@@ -2133,7 +2133,10 @@ struct ColArgs {
 
 template <int NW>
 struct ColLds {
-    float b[2][NW][3][5][64];
+    // the boundary rows of the two steps: a buffer each -- or, where twelve wavefronts must fit beside the R1 ring, ONE that the steps take turns in
+    // (a wavefront's slot then carries its writes in sequence: step 1 and step 2 of round 0, of round 1, ...; put_boundary / get_boundary)
+    static constexpr int NB = NW > 8 ? 1 : 2;
+    float b[NB][NW][3][5][64];
     // the token of step s: the running column sums of five channels per lane as {P0, P1} {P2, P3} {P4} and, written LAST and read FIRST, the ticket
     // they are for.  LDS executes a wavefront's accesses in issue order, so a reader that finds the tag finds the sums behind it: no fence, no
     // separate flag, one LDS round trip per link.
@@ -2141,7 +2144,7 @@ struct ColLds {
         double a[64][2], b[64][2], c[64];
         int tag[64];
     } tok[2];
-    int wr[2][NW], rd[2][NW];
+    int wr[NB][NW], rd[NB][NW];
 };
 
 __device__ __forceinline__ int lds_flag_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -2223,7 +2226,13 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     static_assert(RW >= 3, "the three boundary rows");
     constexpr int DEPTH = 1;  // rows whose samples are in flight before the first is consumed (2 and 4 measured the same: r05_experiments.md)
     __shared__ ColLds<NW> lds;
-    static_assert(!RING || (K1 == kHaloIter && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
+    static_assert(!RING || (K1 == kHaloIter && ((RW == 4 && NW == 8) || (RW == 3 && NW == 12))),
+                  "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows or twelve of three");
+    // Fill groups are four image rows whatever the wavefronts' rows.  Eight wavefronts of four rows: ticket t fills group t + 6.  Twelve of three: three of
+    // every four tickets fill a group (tickets 4m + j, j < 3, fill group 3m + j + 4): twelve rows per four tickets either way.  Lead 4 is what a 64-row
+    // ring allows there -- group g overwrites group g - 16, whose last reader (ticket floor((4g - 56) / 3) for step 2's rows one above) must be a
+    // whole round (twelve tickets) behind the filler; brute-forced over 400 groups in r05_experiments.md.
+    constexpr int kLead = RW == 4 ? kRingLead : 4;  // (three leads the same launch time, two 44 % more: r05_experiments.md 14)
     __shared__ typename std::conditional<RING, ColRing, int>::type ring;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
@@ -2238,7 +2247,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     const size_t oflow_step = fout.step[tbz];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < 128) lds.tok[threadIdx.x >> 6].tag[threadIdx.x & 63] = 0;
-    if (threadIdx.x < 2 * NW) {
+    if (threadIdx.x < ColLds<NW>::NB * NW) {
         (&lds.wr[0][0])[threadIdx.x] = 0;
         (&lds.rd[0][0])[threadIdx.x] = 0;
     }
@@ -2325,7 +2334,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
     if constexpr (RING) {
-        if (wave < kRingLead) ring_fill(wave);  // groups 0 .. L-1: what the first tickets need before any of them has filled anything
+        if (wave < kLead) ring_fill(wave);  // groups 0 .. L-1: what the first tickets need before any of them has filled anything
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -2388,9 +2397,11 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     // T = that group - L.  Wavefront j has then published at least (T - j) / 8 + 1 fills: lanes 0 .. 7 each check one wavefront's counter.
     auto ring_wait = [&](int ticket) __attribute__((always_inline)) {
         if constexpr (RING) {
-            const int T = (4 * ticket + 3 + kRingD) / 4 - kRingLead;
+            // the last group this ticket's rows can reach, and the ticket that fills it
+            const int gk = (RW * ticket + RW - 1 + kRingD) / 4 - kLead;
+            const int T = RW == 4 ? gk : (gk < 0 ? -1 : 4 * (gk / 3) + gk % 3);
             const int l = fresh_lane();
-            const int need = (l < NW && T >= l) ? (T - l) / 8 + 1 : 0;
+            const int need = (l < NW && T >= l) ? (T - l) / NW + 1 : 0;
             unsigned n = 0;
             while (__builtin_amdgcn_ballot_w64(lds_flag_ld(&ring.filled[l & 15]) < need) != 0) {
                 __builtin_amdgcn_s_sleep(1);
@@ -2483,23 +2494,32 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
     // the last three rows of this wavefront's step-s field for the wavefront below
+    // shared buffer: write number NSEQ * r + s of the slot (NSEQ = the steps of a round that hand rows on: the last step of a level does not)
+    constexpr bool SHB = ColLds<NW>::NB == 1;
+    constexpr int NSEQ = (!LAST1 && TWO && !LAST2) ? 2 : 1;
     auto put_boundary = [&](int s, int r, const float (&m)[RW][5]) __attribute__((always_inline)) {
-        lds_wait(&lds.rd[s][wave], r, ca);  // the reader is done with what round r-1 left here
+        const int sb = SHB ? 0 : s, seq = SHB ? NSEQ * r + s : r;
+        // (shared buffer: the last wavefront's rows of the last round have no reader -- wavefront 0 would take them a round later -- and its second
+        // write would wait for the read of its first for ever)
+        if (SHB && wave == NW - 1 && r == ca.rounds - 1) return;
+        lds_wait(&lds.rd[sb][wave], seq, ca);  // the reader is done with what was here before
         const int l = fresh_lane();
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) lds.b[s][wave][k][c][l] = m[RW - 3 + k][c];
-        lds_post(&lds.wr[s][wave], r + 1, l);
+            for (int c = 0; c < 5; c++) lds.b[sb][wave][k][c][l] = m[RW - 3 + k][c];
+        lds_post(&lds.wr[sb][wave], seq + 1, l);
     };
     auto get_boundary = [&](int s, int r, float (&pv)[3][5]) __attribute__((always_inline)) {
-        lds_wait(&lds.wr[s][pw], wave == 0 ? r : r + 1, ca);
+        const int rr = wave == 0 ? r - 1 : r;  // wavefront 0 takes what the last wavefront left in the round before
+        const int sb = SHB ? 0 : s, seq = SHB ? NSEQ * rr + s : rr;
+        lds_wait(&lds.wr[sb][pw], seq + 1, ca);
         const int l = fresh_lane();
 #pragma unroll
         for (int k = 0; k < 3; k++)
 #pragma unroll
-            for (int c = 0; c < 5; c++) pv[k][c] = lds.b[s][pw][k][c][l];
-        lds_post(&lds.rd[s][pw], wave == 0 ? r : r + 1, l);
+            for (int c = 0; c < 5; c++) pv[k][c] = lds.b[sb][pw][k][c][l];
+        lds_post(&lds.rd[sb][pw], seq + 1, l);
     };
 
     // This wavefront's rows of the difference field (the reference's srow1[x] - srow0[x]) of a round, requested one round ahead (20
@@ -2584,7 +2604,9 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             stamp(r, 1);   // rows of the difference field requested
             chain(0, ticket, sum, P);
             stamp(r, 2);   // chain of step 1 passed
-            ring_fill(ticket + kRingLead);  // (holding the token: every reader of the rows this overwrites is done)
+            // (holding the token: every reader of the rows this overwrites is done)
+            if (RW == 4) ring_fill(ticket + kLead);
+            else if ((ticket & 3) != 3) ring_fill(3 * (ticket >> 2) + (ticket & 3) + kLead);
             ring_wait(ticket);
             stamp(r, 3);   // fill issued, the rows this ticket reads have landed
         }
@@ -3205,7 +3227,8 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     if (iter_pair && ctx->fb_col_trace) {
         if (ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
         else OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, true);
-    } else if (iter_pair && g.nw == 12) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, false, false);
+    } else if (iter_pair && g.nw == 12 && ctx->fb_col_ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, true, false);
+    else if (iter_pair && g.nw == 12) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, false, false);
     else if (k1 == kHaloIter && k2 == kHaloIter && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, false);
     else if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, false);
     else if (k1 == kHaloIter && k2 == kHaloLast && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, 4, 8, true, false);

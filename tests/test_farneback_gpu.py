@@ -418,7 +418,7 @@ def test_opencv_order_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx
 
 # the three evaluations of OpenCV's running sums the library has: mode 2 (serial column scan, the independent cross-check), the
 # overlapped-strip form and the column-owning form (farneback.col_min 1 forces it on every level of any frame)
-_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0), dict(col_min=1, col_geom=1))
+_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0), dict(col_min=1, col_geom=1), dict(col_min=1, col_geom=1, col_ring=0))
 # strip / wavefront geometries of the overlapped-strip form the library otherwise picks by level size
 _HALO_GEOMS = (dict(halo_geom=1), dict(halo_geom=2), dict(halo_geom=3), dict(halo_geom=2, halo_strip=33), dict(halo_geom=2, halo_strip=35),
                dict(halo_geom=3, halo_strip=65), dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=70), dict(halo_geom=3, halo_strip=72),
