@@ -2232,7 +2232,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     // every four tickets fill a group (tickets 4m + j, j < 3, fill group 3m + j + 4): twelve rows per four tickets either way.  Lead 4 is what a 64-row
     // ring allows there -- group g overwrites group g - 16, whose last reader (ticket floor((4g - 56) / 3) for step 2's rows one above) must be a
     // whole round (twelve tickets) behind the filler; brute-forced over 400 groups in r05_experiments.md.
-    constexpr int kLead = RW == 4 ? kRingLead : 4;  // (three leads the same launch time, two 44 % more: r05_experiments.md 14)
+    constexpr int kLead = RW == 3 ? 4 : kRingLead;  // (twelve of three: three leads the same launch time, two 44 % more: r05_experiments.md 14)
     __shared__ typename std::conditional<RING, ColRing, int>::type ring;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
@@ -2334,7 +2334,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
     if constexpr (RING) {
-        if (wave < kLead) ring_fill(wave);  // groups 0 .. L-1: what the first tickets need before any of them has filled anything
+        for (int g0 = wave; g0 < kLead; g0 += NW) ring_fill(g0);  // groups 0 .. L-1: what the first tickets need before any of them has filled anything
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
@@ -3223,7 +3223,7 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     hipLaunchKernelGGL((iterate_col_kernel<K1, K2, RW, NW, RING, TRACE>), grid, dim3(64 * NW), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
     // the R1 ring in LDS (option farneback.col_ring, default on): the steps pairs that open with an iteration -- the ring's fill schedule rides on the
     // step-1 token -- in the eight-by-four geometry; everything else gathers from memory
-    const bool ring = ctx->fb_col_ring && g.nw == 8 && g.rw == 4;
+    const bool ring = ctx->fb_col_ring && g.nw == 8 && g.rw == 4;  // (the other geometries' ring variants are launched by name below)
     if (iter_pair && ctx->fb_col_trace) {
         if (ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
         else OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, true);
