@@ -558,12 +558,14 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu, direct_leg=False):
     med = statistics.median
 
     # ---- end to end: f32 RGBA host frames -> flow written into a host RGBA image (PCIe inclusive) ----
-    a, b = synth.flow_pair(1920, 1080)
-    prev, _ = synth.flow_pair(1920, 1080, seed=11)
+    # consecutive frames of one shot (round 6; before, the backward pair was two unrelated textures: every gather of its level walk left the
+    # +-4 px window the column-owning kernel keeps in LDS -- not what playback looks like)
+    shot = synth.sequence(1920, 1080, 4)
+    prev, a, b = shot[0], shot[1], shot[2]
 
     def host_rate(nthreads, seconds=1.5, named=False):
         """every calling thread renders output frames (own context, own host buffers) for `seconds`; >= 1 s per leg.
-        named: the threads render the output frames of ONE endless sequence in order (thread i takes frames i, i + threads, ...) and
+        named: the threads render the output frames of ONE endless sequence in order (a free thread takes the next frame, as a host's render queue hands them out) and
         pass a name with every frame (ofxcv_vectorgen_flows_host_keyed; an OFX host's kOfxImagePropUniqueIdentifier): per output frame
         one frame the device has not seen, two it has."""
         cs = [ofxcv.Context(dev) for _ in range(nthreads)]
@@ -577,15 +579,21 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu, direct_leg=False):
         counts = [0] * nthreads
         stop = threading.Event()
 
-        ring = [a, b, prev]  # the buffers come round again under new names
+        ring = shot  # the buffers come round again under new names (the shot runs forth and back: neighbouring times are neighbouring frames)
+        nr = len(ring)
+
+        next_frame = [0]
+        frame_lock = threading.Lock()
 
         def work(i):
             c, o, (x, y, z) = cs[i], outs[i], srcs[i]
-            t = i
             while not stop.is_set():
                 if named:
-                    c.vectorgen_flows_host(ring[t % 3], ring[(t + 1) % 3], ring[(t - 1) % 3], o, 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
-                    t += nthreads
+                    with frame_lock:    # a host hands out the output frames of a sequence in order, whichever render thread is free
+                        t = next_frame[0]
+                        next_frame[0] += 1
+                    c.vectorgen_flows_host(ring[synth.pingpong(t, nr)], ring[synth.pingpong(t + 1, nr)], ring[synth.pingpong(t - 1, nr)], o, 1, 2, 4, 8,
+                                           keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
                 else:
                     c.vectorgen_flows_host(x, y, z, o, 1, 2, 4, 8)
                 counts[i] += 1
@@ -596,19 +604,26 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu, direct_leg=False):
         stop.set()
         [t.join() for t in th]
         el = time.perf_counter() - t0
+        co = [c.host_coalesce_stats() for c in cs]
+        if sum(x[0] for x in co):
+            coalesced["%s_%d" % ("named" if named else "unnamed", nthreads)] = round(sum(x[2] for x in co) / sum(x[0] for x in co), 2)
         for c in cs:
             c.close()
         return 2 * sum(counts) / el
-    out["end_to_end"] = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs, one "
+    coalesced = {}
+    end_to_end = {"workload": "ofxcv_vectorgen_flows_host: one default VectorGenerator output frame (forward + backward flow = 2 frame pairs, one "
                                      "batched Farneback call), three 1920x1080 f32 RGBA host frames in, one host RGBA frame out, PCIe inclusive; "
                                      "every calling thread renders for 1.5 s",
                          "unit": "frame-pairs/s", "calling_threads_1": host_rate(1), "calling_threads_2": host_rate(2), "calling_threads_4": host_rate(4),
+                         "calling_threads_8": host_rate(8),
                          "playback_named_frames": {
                              "workload": "the same output frames as consecutive frames of a sequence whose frames the caller names "
                                          "(ofxcv_vectorgen_flows_host_keyed; an OFX host's kOfxImagePropUniqueIdentifier): the 8-bit gray image of a "
                                          "named frame stays on the device, so each output frame uploads ONE f32 frame instead of three",
                              "calling_threads_1": host_rate(1, named=True), "calling_threads_2": host_rate(2, named=True),
-                             "calling_threads_4": host_rate(4, named=True)}}
+                             "calling_threads_4": host_rate(4, named=True), "calling_threads_8": host_rate(8, named=True)}}
+    # concurrent calls of one device are coalesced (option host.coalesce): mean pairs of the batched call a render thread's two pairs rode in
+    end_to_end["coalesced_mean_pairs_per_call"] = coalesced
 
     # ---- Telea inpaint (configs[0] size and configs[1]) ----
     ctx = ofxcv.Context(dev)
@@ -727,6 +742,7 @@ def extra_legs(ofxcv, synth, torch, np, dev, with_cpu, direct_leg=False):
         del bufs
     c0.close()
     out["farneback_4k"] = leg
+    out["end_to_end"] = end_to_end   # last: the driver keeps the tail of the line
     return out
 
 

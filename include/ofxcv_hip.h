@@ -98,6 +98,17 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    single-pair calls, the first while the third frame is still on the wire; 2 (default) 1 while this is the
  *                                    only host-image call in flight in the process, else 0 (several render threads keep the link busy anyway);
  *   "host.cache_mb"           n      budget of the device's cache of named frames (ofxcv_vectorgen_flows_host_keyed), default 512, 0 = off;
+ *   "host.coalesce"           0|1|2  host-image calls of several render threads on one device (the reference is eRenderFullySafe, VectorGenerator.cpp:108):
+ *                                    1 (default) a call that finds "host.coalesce_min" (3) host-image calls in flight on its device, itself included, hands
+ *                                    its frame pairs to the device's submission queue; the first caller that finds no coalesced call running runs everything
+ *                                    queued as ONE batched Farneback call (its own pairs at once when nothing else is queued), the callers download their own
+ *                                    images.  0 every call runs its own; 2 every call goes through the queue (tests).  Same results bit for bit.
+ *   "host.coalesce_max"       n      frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip in the
+ *                                    column-owning form of level 0: 8 pairs at 1920x1080, 4 at 3840x2160;
+ *   "host.coalesce_depth"     1..4   coalesced calls in flight per device: 1 (default) the next one is formed when the running one has finished,
+ *                                    n > 1: up to n beside each other (measured slower from 4 render threads on: the calls get smaller);
+ *   "host.coalesce_eager"     0|1    the queue's batched call is launched kernel by kernel (1, default: no runtime lock held, the first kernels run while
+ *                                    the rest is enqueued) or replayed from a captured hipGraph (0);
  *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
  *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
  *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share
@@ -239,9 +250,15 @@ int ofxcv_vectorgen_flows_host_keyed(ofxcv_ctx *ctx, const float *h_ref, ptrdiff
 /* named frames of this context's calls that were found on the device / that were uploaded, converted and kept */
 long ofxcv_host_cache_hits(const ofxcv_ctx *ctx);
 long ofxcv_host_cache_misses(const ofxcv_ctx *ctx);
-/* the cache of the context's device: bytes and frames held; ofxcv_host_cache_clear drops every entry no call is using */
+/* the cache of the context's device: bytes and frames held; ofxcv_host_cache_clear drops every entry no call is using (and the idle batch
+ * contexts of the device's submission queue: what a host calls before it unloads the plugin) */
 int ofxcv_host_cache_stats(ofxcv_ctx *ctx, size_t *bytes, int *frames);
 int ofxcv_host_cache_clear(ofxcv_ctx *ctx);
+
+/* host-image calls of this context that were served by the device's submission queue (option "host.coalesce"), the frame pairs they brought,
+ * and the sum over those calls of the pairs of the batched call each rode in (batch_pairs / calls = mean size of the call a render thread's
+ * pairs ended up in) */
+int ofxcv_host_coalesce_stats(const ofxcv_ctx *ctx, long *calls, long *pairs, long *batch_pairs);
 
 /* How the host-image calls on this context moved their frames (context option "host.register"): copied straight from the
  * host's pageable images (1, default: ofxcv_host_direct_calls), with the host's buffers registered for the call and addressed

@@ -59,7 +59,7 @@ OPTFLOW_FARNEBACK_GAUSSIAN = 256  # cv::OPTFLOW_FARNEBACK_GAUSSIAN: Gaussian win
 EXPORTS = [
     "ofxcv_device_count", "ofxcv_ctx_create", "ofxcv_ctx_destroy", "ofxcv_last_error", "ofxcv_status_string",
     "ofxcv_ctx_device", "ofxcv_lock_hold", "ofxcv_ctx_stream", "ofxcv_ctx_synchronize", "ofxcv_ctx_set_option", "ofxcv_ctx_get_option", "ofxcv_profile_enable", "ofxcv_profile_read", "ofxcv_to_byte_grayscale", "ofxcv_to_byte_grayscale_batch", "ofxcv_calc_optical_flow_farneback", "ofxcv_calc_optical_flow_farneback_batch", "ofxcv_calc_optical_flow_farneback_batch_rgba",
-    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_col_pairs", "ofxcv_farneback_num_levels",
+    "ofxcv_flow_to_rgba", "ofxcv_vectorgen_flow_host", "ofxcv_vectorgen_flows_host", "ofxcv_vectorgen_flows_host_keyed", "ofxcv_host_cache_hits", "ofxcv_host_cache_misses", "ofxcv_host_cache_stats", "ofxcv_host_cache_clear", "ofxcv_host_coalesce_stats", "ofxcv_host_zero_copy_calls", "ofxcv_host_direct_calls", "ofxcv_farneback_plane_pitch", "ofxcv_farneback_col_pairs", "ofxcv_farneback_num_levels",
     "ofxcv_farneback_level_geom", "ofxcv_farneback_pyr_image", "ofxcv_farneback_polyexp",
     "ofxcv_farneback_update_matrices", "ofxcv_farneback_update_flow_blur",
     "ofxcv_inpaint_mask", "ofxcv_inpaint_telea", "ofxcv_inpaint", "ofxcv_inpaint_fallback_count", "ofxcv_inpaint_render_host",
@@ -314,6 +314,13 @@ class Context:
         b, n = C.c_size_t(), C.c_int()
         self._check(lib().ofxcv_host_cache_stats(self._h, C.byref(b), C.byref(n)))
         return b.value, n.value
+
+    def host_coalesce_stats(self):
+        """(calls, pairs, batch_pairs): host-image calls of this context served by the device's submission queue, their pairs, and the
+        summed size (pairs) of the batched calls they rode in"""
+        a, b, c = C.c_long(), C.c_long(), C.c_long()
+        self._check(lib().ofxcv_host_coalesce_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def host_cache_clear(self):
         self._check(lib().ofxcv_host_cache_clear(self._h))

@@ -23,7 +23,7 @@ struct DevBuf {
 // cache of captured Farneback launch sequences (see ofxcv_calc_optical_flow_farneback)
 #define OFXCV_FB_MAX_LEVELS 10
 #define OFXCV_FB_MAX_BATCH OFXCV_FARNEBACK_MAX_BATCH  // frame pairs per batched call (pointer tables travel as kernel arguments)
-constexpr int kFbGraphSlots = 4;
+constexpr int kFbGraphSlots = 12;  // (the batch context of the host path's submission queue replays calls of 1 .. 16 pairs)
 struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
     int n, width, height, levels, winsize, iterations, poly_n, flags;
     double pyr_scale, poly_sigma;
@@ -38,6 +38,7 @@ struct FbGraphKey {  // compared with memcmp: zero-filled before it is set
 struct FbGraph {
     FbGraphKey key;
     hipGraphExec_t exec = nullptr;
+    unsigned long used = 0;  // stamp of its last replay: the least recently used entry goes
 };
 
 struct ofxcv_ctx {
@@ -56,7 +57,7 @@ struct ofxcv_ctx {
                                     // Measured (profiles/r03_scheduling.txt): +1-3 % with several calls in flight, but single calls on a
                                     // context with a high-priority stream were seen to run 3x slower (236 instead of 725 pairs/s): off.
     FbGraph fb_graphs[kFbGraphSlots];
-    unsigned fb_graph_next = 0;
+    unsigned long fb_graph_clock = 0;
     bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
     int fb_polyexp_variant = 5;
     int fb_pyr_bytewise = 0;     // option "farneback.pyr_bytewise": 1 = the coarse pyramid levels take the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel)
@@ -146,6 +147,18 @@ struct ofxcv_ctx {
                                    // third frame is still on the wire (1), as one batched call after the third upload (0), or 1 when this
                                    // is the only host-image call in flight in the process and 0 otherwise (2, default)
     long host_split_calls = 0;
+    int host_coalesce = 1;         // option "host.coalesce": host-image calls that find another one in flight on their device hand their frame pairs to the
+                                   // device's submission queue, which runs everything queued as ONE batched Farneback call (1, default); 0 never; 2 always
+                                   // (also a lone call: tests)
+    int host_coalesce_max = 0;     // option "host.coalesce_max": frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip
+                                   // in the column-owning form of level 0 (8 pairs at 1920x1080, 4 at 3840x2160)
+    int host_coalesce_depth = 1;   // option "host.coalesce_depth": coalesced calls in flight per device (1: the next one is formed when the running one has finished
+                                   // -- whatever arrived meanwhile rides in it; 2: a second one may be enqueued behind / beside it)
+    int host_coalesce_min = 3;     // option "host.coalesce_min": host-image calls in flight on the device (this one included) from which a call goes to the queue
+    int host_coalesce_eager = 1;   // option "host.coalesce_eager": the batch context launches its kernels one by one (1, default: they start executing while the rest
+                                   // is being enqueued, and no runtime lock is held) instead of replaying a captured hipGraph (0: the GPU idles for most of a hipGraphLaunch)
+    long host_coalesced_calls = 0, host_coalesced_pairs = 0, host_coalesced_batches = 0;  // calls of this context served by the queue, their pairs, the pairs of the batches they rode in
+    int fb_reserve_pairs = 0;      // the Farneback scratch is sized for at least this many pairs (the batch context of the submission queue: no re-allocation as batches grow)
     int host_cache_mb = 512;       // option "host.cache_mb": budget of the device's cache of named frames' gray images (0 = off)
     long host_cache_hits = 0, host_cache_misses = 0;  // named frames of this context's calls found on the device / uploaded and kept
     long host_direct_calls = 0;

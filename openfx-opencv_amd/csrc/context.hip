@@ -334,7 +334,9 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
             {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
             {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20},
-            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}, {"farneback.reuse_prep", &ctx->fb_reuse_prep, 0, 1}};
+            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}, {"farneback.reuse_prep", &ctx->fb_reuse_prep, 0, 1},
+            {"host.coalesce", &ctx->host_coalesce, 0, 2}, {"host.coalesce_max", &ctx->host_coalesce_max, 0, OFXCV_FARNEBACK_MAX_BATCH},
+            {"host.coalesce_depth", &ctx->host_coalesce_depth, 1, 4}, {"host.coalesce_eager", &ctx->host_coalesce_eager, 0, 1}, {"host.coalesce_min", &ctx->host_coalesce_min, 1, 64}};
         for (auto &k : knobs)
             if (!std::strcmp(name, k.n)) {
                 if (value < k.lo || value > k.hi) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);
@@ -374,6 +376,7 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "host.split")) *value = ctx->host_split;
     else if (!std::strcmp(name, "host.cache_mb")) *value = ctx->host_cache_mb;
     else if (!std::strcmp(name, "host.split_calls")) *value = (int)ctx->host_split_calls;
+    else if (!std::strcmp(name, "host.coalesce")) *value = ctx->host_coalesce;
     else if (!std::strcmp(name, "farneback.batch_mb")) *value = ctx->fb_batch_mb;
     else if (!std::strcmp(name, "farneback.col")) *value = ctx->fb_col;
     else if (!std::strcmp(name, "farneback.col_min")) *value = ctx->fb_col_min;

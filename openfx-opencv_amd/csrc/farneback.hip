@@ -3671,17 +3671,21 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
     Layout L;
     int rc = make_layout(ctx, n, width, height, pyr_scale, levels, L);
     if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->fb_planes, L.planes_bytes());
+    // (a context that serves calls of varying batch size -- the per-device batch context of the host path, vectorgen.hip -- sizes its scratch for
+    // fb_reserve_pairs once: a scratch that grows is freed and re-allocated, and the captured launch sequences hold its addresses)
+    Layout Lr = L;
+    Lr.n = std::max(n, std::min(ctx->fb_reserve_pairs, kMaxBatch));
+    rc = ofxcv_reserve(ctx, ctx->fb_planes, Lr.planes_bytes());
     if (rc) return rc;
-    rc = ofxcv_reserve(ctx, ctx->fb_tmp, L.tmp_bytes());
+    rc = ofxcv_reserve(ctx, ctx->fb_tmp, Lr.tmp_bytes());
     if (rc) return rc;
     if (levels > 0) {
-        rc = ofxcv_reserve(ctx, ctx->fb_flow, L.flow_bytes());
+        rc = ofxcv_reserve(ctx, ctx->fb_flow, Lr.flow_bytes());
         if (rc) return rc;
     }
     const bool need_vsum = ctx->fb_opencv_rounding || (flags & OFXCV_OPTFLOW_FARNEBACK_GAUSSIAN);
     if (need_vsum) {
-        rc = ofxcv_reserve(ctx, ctx->fb_vsum, L.vsum_bytes());
+        rc = ofxcv_reserve(ctx, ctx->fb_vsum, Lr.vsum_bytes());
         if (rc) return rc;
     }
     if (ctx->fb_col && !ctx->fb_col_flag.ptr) {  // the trace area of iterate_col_kernel
@@ -3733,7 +3737,10 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
     for (FbGraph &c : ctx->fb_graphs)
         if (c.exec && !std::memcmp(&c.key, &key, sizeof(key))) g = &c;
     if (!g) {
-        FbGraph *slot = &ctx->fb_graphs[ctx->fb_graph_next++ % kFbGraphSlots];
+        FbGraph *slot = &ctx->fb_graphs[0];  // an empty slot, else the least recently replayed one
+        for (FbGraph &c : ctx->fb_graphs)
+            if (!c.exec) { slot = &c; break; }
+            else if (c.used < slot->used) slot = &c;
         // Relaxed mode: the captured region itself makes no capture-unsafe call, and other host threads (each with
         // its own context: allocations, synchronising copies) must not be able to invalidate this capture.  If the
         // capture cannot be completed anyway, the call falls back to plain launches and stops using graphs.
@@ -3776,6 +3783,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         // rocgdb with every other locked operation parked on this lock
         std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex(ctx->device));
         const auto hold0 = std::chrono::steady_clock::now();
+        g->used = ++ctx->fb_graph_clock;
         const hipError_t le = hipGraphLaunch(g->exec, s);
         ctx->lock_hold_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - hold0).count();
         ctx->lock_holds++;

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -328,6 +329,258 @@ __global__ __launch_bounds__(256) void flows_to_rgba_kernel(const float2 *__rest
     *(float4 *)((char *)dst + (ptrdiff_t)y * dst_row_bytes + (size_t)x * 16) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// ---- concurrent host-image calls of one device, coalesced into ONE batched Farneback call ----
+// VectorGenerator is eRenderFullySafe with host frame threading off (VectorGenerator.cpp:108, GenericOpenCVPlugin.cpp:350-357): a host renders
+// several output frames at once, each render() on its own thread with its own context.  Left alone, every thread submits its own call of two
+// pairs, and the GPU runs 2-pair calls (<= 1 115 pairs/s at 1920x1080) where one call of 8 pairs reaches 1 660: the coarse levels are
+// latency-bound and level 0 only takes the column-owning form (two iterations per launch) from 6 pairs on.  So a call that finds another
+// host-image call in flight on its device does not start a Farneback call of its own: it uploads and converts its frames as ever, waits for
+// them, and hands its pairs to the device's SUBMISSION QUEUE.  The first caller that finds no coalesced call running becomes the leader: it
+// takes everything queued with its own geometry and parameters (its own pairs at once when it is alone: no added latency), gathers the gray
+// frames into the slots of the device's batch context (one launch; the slots keep the pointers of the captured launch sequence fixed), runs ONE
+// batched Farneback call there, composes every caller's RGBA image (or copies its flows back) on the same stream, waits, and wakes the callers,
+// who download their own images.  Callers that arrive while a call runs queue up and ride in the next one.  All ordering between contexts goes
+// through the host (the callers' frames are complete before they queue, the batch is complete before they are woken): no cross-context events.
+// Results are those of the callers' own calls bit for bit (a batch is bit-identical to its single calls).
+namespace {
+// measurement aid (environment OFXCV_HOST_TRACE=1; tools/host_queue_trace.py): per host-image call the times of its phases in microseconds since the
+// first traced call -- entry, frames enqueued, frames complete (= queued), its batched call started / finished, the caller woke up, image downloaded --
+// the pairs of the call it rode in and whether this thread led it
+struct HostTrace {
+    static bool on() {
+        static const bool v = [] { const char *e = std::getenv("OFXCV_HOST_TRACE"); return e && e[0] == '1'; }();
+        return v;
+    }
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::vector<double> &log() { static std::vector<double> *v = new std::vector<double>(); return *v; }
+    static double now() {
+        static const auto t0 = std::chrono::steady_clock::now();
+        return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+struct FlowSig {  // what two requests must share to ride in one call
+    int w, h, levels, iterations, poly_n, rounding, gauss_gen, contraction, resize_gen;
+    double poly_sigma;
+    bool operator==(const FlowSig &o) const {
+        return w == o.w && h == o.h && levels == o.levels && iterations == o.iterations && poly_n == o.poly_n && rounding == o.rounding &&
+               gauss_gen == o.gauss_gen && contraction == o.contraction && resize_gen == o.resize_gen && poly_sigma == o.poly_sigma;
+    }
+};
+struct BatchStatus {  // shared by the requests of one batched call: set by the leader once the call has completed
+    std::atomic<int> aborted{0};
+};
+struct FlowReq {
+    FlowSig sig;
+    int n_other = 0;
+    const uint8_t *gray[3] = {nullptr, nullptr, nullptr};  // device, rows gray_pitch apart; complete once `ready` has fired
+    hipEvent_t ready = nullptr;   // recorded on the caller's compute stream behind its last conversion
+    hipStream_t stream = nullptr; // the caller's compute stream: the leader makes it wait for the batched call
+    float *d_rgba = nullptr;  // all four channels mapped: the leader composes the image here (rows width * 16 bytes) ...
+    ChanMap cm;
+    double rsx = 1, rsy = 1;
+    float *d_flow[2] = {nullptr, nullptr};  // ... otherwise it copies the flows here
+    bool no_graph = true;  // (the oldest request of a call decides; never changes a result)
+    int state = 0;  // 0 queued, 1 riding in a call that is being enqueued, 2 enqueued: the caller's stream waits for it
+    int rc = OFXCV_OK, batch_pairs = 0;
+    std::shared_ptr<BatchStatus> status;
+    const volatile unsigned *abort_word = nullptr;  // the batch context's (iterate_col_kernel's bounded waits)
+    double t_start = 0, t_end = 0, t_launched = 0;  // its batched call as the leader saw it (HostTrace): begun, everything enqueued, complete
+    bool led = false;
+    char err[256] = {0};
+};
+struct FrameTab {
+    const uint4 *src[2 * OFXCV_FARNEBACK_MAX_BATCH];
+};
+__global__ __launch_bounds__(256) void gather_frames_kernel(FrameTab t, uint4 *__restrict__ dst, size_t vec_per_frame) {
+    const uint4 *__restrict__ s = t.src[blockIdx.y];
+    uint4 *__restrict__ d = dst + (size_t)blockIdx.y * vec_per_frame;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_frame; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+class FlowQueue {
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<FlowReq *> q_;
+    int running_ = 0;
+    static constexpr int kMaxDepth = 4;
+    ofxcv_ctx *bctx_[kMaxDepth] = {};
+    bool slot_busy_[kMaxDepth] = {};
+
+    static void fail_all(const std::vector<FlowReq *> &batch, int rc, const char *text) {
+        for (FlowReq *r : batch) {
+            r->rc = rc;
+            std::snprintf(r->err, sizeof(r->err), "%s", text);
+        }
+    }
+    // The leader's work, queue unlocked: nobody else touches this slot's batch context meanwhile.  Everything is ENQUEUED here, nothing waited
+    // for: the batch stream waits for the callers' frames (their `ready` events), the callers' streams wait for the batched call (its `done`
+    // event).  Event operations across contexts take the runtime lock like everywhere else in the library (they must not run beside another
+    // thread's stream capture on ROCm 7.2).
+    ofxcv_ctx *enqueue(int device, int slot, const std::vector<FlowReq *> &batch, int reserve_pairs) {
+        ofxcv_ctx *&b = bctx_[slot];
+        if (!b) {
+            const int rc = ofxcv_ctx_create(device, &b);
+            if (rc) {
+                fail_all(batch, rc, "host-image queue: the batch context could not be created");
+                return nullptr;
+            }
+            b->host_coalesce = 0;
+        }
+        const FlowSig &sg = batch[0]->sig;
+        auto run_on = [&]() -> int {
+            OFXCV_HIP_CHECK(b, hipSetDevice(b->hip_device));
+            const struct { const char *name; int *cur; int want; } opts[] = {{"farneback.opencv_rounding", &b->fb_opencv_rounding, sg.rounding},
+                                                                           {"farneback.gaussian_kernel_generation", &b->fb_gauss_generation, sg.gauss_gen},
+                                                                           {"farneback.filter_contraction", &b->fb_filter_contraction, sg.contraction},
+                                                                           {"farneback.resize_generation", &b->fb_resize_generation, sg.resize_gen}};
+            for (const auto &o : opts)
+                if (*o.cur != o.want) {
+                    const int rc = ofxcv_ctx_set_option(b, o.name, o.want);  // (drops the captured launch sequences)
+                    if (rc) return rc;
+                }
+            b->fb_no_graph = batch[0]->no_graph;
+            b->fb_reserve_pairs = std::max(b->fb_reserve_pairs, reserve_pairs);
+            int np = 0;
+            for (const FlowReq *r : batch) np += r->n_other;
+            const size_t gray_pitch = align_up((size_t)sg.w, 256), gray = gray_pitch * sg.h, flow_bytes = align_up((size_t)sg.w * sg.h * 8, 256);
+            const int cap = std::max(np, b->fb_reserve_pairs);
+            int rc = ofxcv_reserve(b, b->d_stage, (size_t)cap * (2 * gray + flow_bytes));
+            if (rc) return rc;
+            // slots by pair: pair p reads the frames 2p, 2p + 1 and writes flow p -- the same pointers whoever rides in the call
+            char *dp = (char *)b->d_stage.ptr;
+            FrameTab ft = {};
+            const uint8_t *prevs[OFXCV_FARNEBACK_MAX_BATCH], *nexts[OFXCV_FARNEBACK_MAX_BATCH];
+            float *flows[OFXCV_FARNEBACK_MAX_BATCH];
+            size_t gsteps[OFXCV_FARNEBACK_MAX_BATCH], fsteps[OFXCV_FARNEBACK_MAX_BATCH];
+            int p = 0;
+            for (const FlowReq *r : batch)
+                for (int k = 0; k < r->n_other; k++, p++) {
+                    ft.src[2 * p] = (const uint4 *)r->gray[0];
+                    ft.src[2 * p + 1] = (const uint4 *)r->gray[k + 1];
+                    prevs[p] = (const uint8_t *)(dp + (size_t)(2 * p) * gray);
+                    nexts[p] = (const uint8_t *)(dp + (size_t)(2 * p + 1) * gray);
+                    flows[p] = (float *)(dp + (size_t)cap * 2 * gray + (size_t)p * flow_bytes);
+                    gsteps[p] = gray_pitch;
+                    fsteps[p] = (size_t)sg.w * 8;
+                }
+            {
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(b->device));
+                for (const FlowReq *r : batch) OFXCV_HIP_CHECK(b, hipStreamWaitEvent(b->compute, r->ready, 0));
+            }
+            const size_t vec = gray / 16;
+            hipLaunchKernelGGL(gather_frames_kernel, dim3((unsigned)std::min<size_t>(512, (vec + 255) / 256), 2 * np), dim3(256), 0, b->compute, ft, (uint4 *)dp, vec);
+            OFXCV_LAUNCH_CHECK(b, "gather_frames_kernel");
+            // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
+            rc = ofxcv_calc_optical_flow_farneback_batch(b, np, prevs, gsteps, nexts, gsteps, flows, fsteps, sg.w, sg.h, 0.5, sg.levels, 3, sg.iterations, sg.poly_n,
+                                                         sg.poly_sigma, 0, b->compute);
+            if (rc) return rc;
+            p = 0;
+            for (const FlowReq *r : batch) {
+                if (r->d_rgba) {
+                    hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(sg.w, 256), sg.h), dim3(256), 0, b->compute, (const float2 *)flows[p],
+                                       (const float2 *)(r->n_other > 1 ? flows[p + 1] : nullptr), sg.w, sg.h, r->d_rgba, (ptrdiff_t)sg.w * 16, r->cm, r->rsx, r->rsy);
+                    OFXCV_LAUNCH_CHECK(b, "flows_to_rgba_kernel");
+                } else {
+                    for (int k = 0; k < r->n_other; k++)
+                        OFXCV_HIP_CHECK(b, hipMemcpyAsync(r->d_flow[k], flows[p + k], (size_t)sg.w * sg.h * 8, hipMemcpyDeviceToDevice, b->compute));
+                }
+                p += r->n_other;
+            }
+            {
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(b->device));
+                OFXCV_HIP_CHECK(b, hipEventRecord(b->ev_done, b->compute));
+                for (const FlowReq *r : batch) OFXCV_HIP_CHECK(b, hipStreamWaitEvent(r->stream, b->ev_done, 0));
+            }
+            auto st = std::make_shared<BatchStatus>();
+            for (FlowReq *r : batch) {
+                r->batch_pairs = np;
+                r->status = st;
+                r->abort_word = b->fb_col_abort;
+            }
+            return OFXCV_OK;
+        };
+        const int rc = run_on();
+        if (rc) {
+            (void)hipStreamSynchronize(b->compute);  // whatever was enqueued before the failure: nothing of it may outlive the callers' buffers
+            fail_all(batch, rc, b->err);
+            return nullptr;
+        }
+        return b;
+    }
+
+public:
+    static FlowQueue &of(int device) {
+        static FlowQueue *q = new FlowQueue[64];  // intentionally leaked, like the cache above
+        return q[device & 63];
+    }
+    // Queues the request and returns when the batched call it rides in has been enqueued (the caller's stream then waits for that call) -- or,
+    // for the leader, when that call has completed: a device runs `depth` coalesced calls at a time, and what arrives while they run rides in the next.
+    int submit(int device, FlowReq &r, int max_pairs, int depth) {
+        max_pairs = std::max(2, std::min(max_pairs, OFXCV_FARNEBACK_MAX_BATCH));
+        depth = std::max(1, std::min(depth, (int)kMaxDepth));
+        std::unique_lock<std::mutex> lk(mu_);
+        q_.push_back(&r);
+        for (;;) {
+            if (r.state == 2) return r.rc;
+            if (r.state == 0 && running_ < depth) {
+                // lead: the oldest request decides geometry and parameters; every queued request that shares them rides along, in order of arrival
+                std::vector<FlowReq *> batch;
+                const FlowSig sg = q_.front()->sig;
+                int np = 0;
+                for (size_t i = 0; i < q_.size();) {
+                    FlowReq *c = q_[i];
+                    if (c->sig == sg && np + c->n_other <= max_pairs) {
+                        np += c->n_other;
+                        c->state = 1;
+                        batch.push_back(c);
+                        q_.erase(q_.begin() + (ptrdiff_t)i);
+                    } else
+                        i++;
+                }
+                int slot = 0;
+                while (slot_busy_[slot]) slot++;  // (running_ < depth <= kMaxDepth: one is free)
+                slot_busy_[slot] = true;
+                running_++;
+                lk.unlock();
+                const double t_start = HostTrace::on() ? HostTrace::now() : 0;
+                ofxcv_ctx *b = enqueue(device, slot, batch, max_pairs);
+                const double t_launched = HostTrace::on() ? HostTrace::now() : 0;
+                std::shared_ptr<BatchStatus> st = batch[0]->status;
+                lk.lock();
+                for (FlowReq *c : batch) {  // the riders go on: their streams wait for the call, they enqueue their downloads behind it
+                    c->state = 2;
+                    c->t_start = t_start;
+                    c->t_launched = t_launched;
+                }
+                r.led = true;
+                cv_.notify_all();
+                lk.unlock();
+                if (b) {  // the leader keeps the slot until the call has completed
+                    (void)hipEventSynchronize(b->ev_done);
+                    if (ofxcv_col_abort_check(b) != OFXCV_OK && st) st->aborted.store(1);
+                }
+                r.t_end = HostTrace::on() ? HostTrace::now() : 0;
+                lk.lock();
+                running_--;
+                slot_busy_[slot] = false;
+                cv_.notify_all();
+                continue;
+            }
+            cv_.wait(lk);
+        }
+    }
+    // the idle batch contexts (streams, scratch, captured launch sequences) go; the next coalesced call re-creates them
+    void shutdown() {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (int i = 0; i < kMaxDepth; i++)
+            if (bctx_[i] && !slot_busy_[i]) {
+                ofxcv_ctx_destroy(bctx_[i]);
+                bctx_[i] = nullptr;
+            }
+    }
+};
+}  // namespace
+
 constexpr int kNotRegistered = 12345;  // internal: the registered-buffer path does not apply, stage through the pinned ring
 
 static int flows_host_registered(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_bytes, int n_other, const float *const h_other[2],
@@ -427,6 +680,16 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     const int nf = 1 + n_other;
     const size_t row = (size_t)width * ncomp * sizeof(float), drow = (size_t)width * 16;
+    double tr[16] = {HostTrace::on() ? HostTrace::now() : 0};
+    struct TraceOut {
+        double *t;
+        ~TraceOut() {
+            if (!HostTrace::on()) return;
+            t[6] = HostTrace::now();
+            std::lock_guard<std::mutex> lk(HostTrace::mu());
+            HostTrace::log().insert(HostTrace::log().end(), t, t + 16);
+        }
+    } trace_out{tr};
     if (ctx->host_register == 2) {  // opt-in: the host's buffers registered for the call, the kernel stores into the host image
         int rc0 = flows_host_registered(ctx, h_ref, ref_row_bytes, n_other, h_other, other_row_bytes, ncomp, width, height, h_dst, dst_row_bytes,
                                         chan_u_mask, chan_v_mask, render_scale_x, render_scale_y, levels, iterations, poly_n, poly_sigma);
@@ -509,12 +772,13 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     // stay with the batched form.  Same results either way (a batch is bit-identical to its single calls).
     // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
     const size_t gsteps[2] = {gray_pitch, gray_pitch}, fsteps[2] = {(size_t)width * 8, (size_t)width * 8};
-    struct InFlight {
-        static std::atomic<int> &n() { static std::atomic<int> v{0}; return v; }
+    struct InFlight {  // host-image calls in flight on this (logical) device
+        static std::atomic<int> &n(int device) { static std::atomic<int> v[64]; return v[device & 63]; }
+        std::atomic<int> &c;
         int mine;
-        InFlight() : mine(n().fetch_add(1) + 1) {}
-        ~InFlight() { n().fetch_sub(1); }
-    } in_flight;
+        explicit InFlight(int device) : c(n(device)), mine(c.fetch_add(1) + 1) {}
+        ~InFlight() { c.fetch_sub(1); }
+    } in_flight(ctx->device);
     bool avail[3] = {false, false, false}, pair_done[2] = {false, false};
     int to_upload = 0;
     for (int f = 0; f < nf; f++) to_upload += !(pins.e[f] && !pins.fill[f]);
@@ -548,9 +812,11 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     };
     // Cached frames first: whatever only needs them is enqueued BEFORE the first copy call (a copy from pageable memory returns
     // when the runtime has staged the frame).  Frames another thread is filling right now come last.
+    tr[9] = HostTrace::on() ? HostTrace::now() : 0;   // scratch reserved, named frames looked up
     for (int f = 0; f < nf; f++)
         if (pins.e[f] && !pins.fill[f] && !pins.pending[f] && (rc = take_cached(f))) return rc;
     if ((rc = enqueue_ready_pairs())) return rc;
+    tr[10] = HostTrace::on() ? HostTrace::now() : 0;  // cached frames taken
     // uploads on the copy stream; the compute stream converts frame f as soon as it has arrived
     const int rows_per_chunk = std::max(1, (int)((size_t)(4u << 20) / row));  // ring: ~4 MiB per DMA
     auto upload = [&](int f) -> int {
@@ -590,11 +856,16 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         return enqueue_ready_pairs();
     };
     for (int f = 0; f < nf; f++)
-        if (!avail[f] && !pins.pending[f] && (rc = upload(f))) return rc;
+        if (!avail[f] && !pins.pending[f]) {
+            tr[13] += 1;
+            if ((rc = upload(f))) return rc;
+        }
+    tr[11] = HostTrace::on() ? HostTrace::now() : 0;  // own uploads + conversions enqueued
     // Frames some other thread was filling when this call looked them up.  Its own entries are published by now, so waiting is
     // safe; should the other thread have given up, the frame is uploaded after all (unnamed).
     for (int f = 0; f < nf; f++)
         if (!avail[f]) {
+            tr[14] += 1;
             if (pins.cache->wait_published(pins.e[f])) {
                 if ((rc = take_cached(f)) || (rc = enqueue_ready_pairs())) return rc;
             } else {
@@ -608,21 +879,73 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     if (split) ctx->host_split_calls++;
     // The two flows of an output frame are independent pairs with the same first frame: one batched call (every launch of
     // the level walk carries both).
-    if (!split) {
+    bool composed = false;
+    // Another host-image call is in flight on this device (several render threads): the pairs go to the device's submission queue and ride in ONE
+    // batched Farneback call with whatever the other threads have queued (FlowQueue above); a lone call runs its own.
+    const bool coalesce = !split && ctx->host_coalesce && (ctx->host_coalesce == 2 || in_flight.c.load() >= ctx->host_coalesce_min);
+    tr[1] = HostTrace::on() ? HostTrace::now() : 0;
+    std::shared_ptr<BatchStatus> batch_status;
+    const volatile unsigned *batch_abort_word = nullptr;
+    // after this call's streams have drained (so the batched call it rode in has completed): did a bounded wait of iterate_col_kernel run out there?
+    auto coalesced_abort = [&]() -> int {
+        if ((batch_status && batch_status->aborted.load()) || (batch_abort_word && *batch_abort_word))
+            return ofxcv_fail(ctx, OFXCV_ERR_HIP, "calc_optical_flow_farneback: a bounded wait inside iterate_col_kernel ran out in the coalesced call; its flows are not valid");
+        return OFXCV_OK;
+    };
+    if (coalesce) {
+        {
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));  // behind the last conversion: the frames are complete when it fires
+        }
+        tr[2] = HostTrace::on() ? HostTrace::now() : 0;
+        FlowReq rq;
+        rq.sig = {width, height, levels, iterations, poly_n, ctx->fb_opencv_rounding, ctx->fb_gauss_generation, ctx->fb_filter_contraction, ctx->fb_resize_generation, poly_sigma};
+        rq.n_other = n_other;
+        rq.no_graph = ctx->fb_no_graph || ctx->host_coalesce_eager;
+        rq.ready = ctx->ev_done;
+        rq.stream = ctx->compute;
+        for (int f = 0; f < nf; f++) rq.gray[f] = d_gray[f];
+        if (direct_down) {
+            rq.d_rgba = d_rgba;
+            rq.cm = cm;
+            rq.rsx = render_scale_x;
+            rq.rsy = render_scale_y;
+        } else {
+            rq.d_flow[0] = d_flow[0];
+            rq.d_flow[1] = d_flow[1];
+        }
+        // pairs per coalesced call: what fills ONE round of the chip in the column-owning form of level 0 (a workgroup per 60-pixel tile column and pair,
+        // one workgroup per CU: 8 pairs at 1920x1080, 4 at 3840x2160) -- measured: 12 queued pairs run faster as 8 + (4 + newcomers) than as 12
+        int max_pairs = ctx->host_coalesce_max;
+        if (max_pairs <= 0) max_pairs = std::max(2, std::min(OFXCV_FARNEBACK_MAX_BATCH, (ctx->num_cus / std::max(1, ofxcv_div_up(width, 60))) & ~1));
+        rc = FlowQueue::of(ctx->device).submit(ctx->device, rq, max_pairs, ctx->host_coalesce_depth);
+        if (rc) return ofxcv_fail(ctx, rc, "%s", rq.err);
+        OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
+        ctx->host_coalesced_calls++;
+        ctx->host_coalesced_pairs += n_other;
+        ctx->host_coalesced_batches += rq.batch_pairs;
+        composed = direct_down;
+        batch_status = rq.status;
+        batch_abort_word = rq.abort_word;
+        tr[3] = rq.t_start; tr[4] = rq.t_end; tr[5] = HostTrace::on() ? HostTrace::now() : 0; tr[7] = rq.batch_pairs; tr[8] = rq.led ? 1 : 0; tr[15] = rq.t_launched;
+    } else if (!split) {
         const uint8_t *prevs[2] = {d_gray[0], d_gray[0]}, *nexts[2] = {d_gray[1], n_other > 1 ? d_gray[2] : nullptr};
         rc = ofxcv_calc_optical_flow_farneback_batch(ctx, n_other, prevs, gsteps, nexts, gsteps, d_flow, fsteps, width, height, 0.5, levels, 3,
                                                      iterations, poly_n, poly_sigma, 0, ctx->compute);
         if (rc) return rc;
     }
     if (direct_down) {
-        hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
-                           (const float2 *)d_flow[1], width, height, d_rgba, (ptrdiff_t)drow, cm, render_scale_x, render_scale_y);
-        OFXCV_LAUNCH_CHECK(ctx, "flows_to_rgba_kernel");
+        if (!composed) {
+            hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(width, 256), height), dim3(256), 0, ctx->compute, (const float2 *)d_flow[0],
+                               (const float2 *)d_flow[1], width, height, d_rgba, (ptrdiff_t)drow, cm, render_scale_x, render_scale_y);
+            OFXCV_LAUNCH_CHECK(ctx, "flows_to_rgba_kernel");
+        }
         if ((size_t)dst_row_bytes == drow)
             OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_dst, d_rgba, drow * height, hipMemcpyDeviceToHost, ctx->compute));
         else
             OFXCV_HIP_CHECK(ctx, hipMemcpy2DAsync(h_dst, (size_t)dst_row_bytes, d_rgba, drow, drow, height, hipMemcpyDeviceToHost, ctx->compute));
         OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+        if ((rc = coalesced_abort())) return rc;
         return ofxcv_col_abort_check(ctx);  // (the host images of a call whose kernel gave up are not valid: fail, do not hand them over)
     }
     for (int k = 0; k < n_other; k++) {
@@ -635,6 +958,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(h_flow[k], d_flow[k], (size_t)width * height * 8, hipMemcpyDeviceToHost, ctx->compute));
     }
     OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(ctx->compute));
+    if ((rc = coalesced_abort())) return rc;
     {
         const int arc = ofxcv_col_abort_check(ctx);
         if (arc) return arc;
@@ -749,5 +1073,22 @@ extern "C" int ofxcv_host_cache_clear(ofxcv_ctx *ctx) {
     if (!ctx) return OFXCV_ERR_INVALID;
     OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
     GrayCache::of(ctx->device).clear(ctx);
+    FlowQueue::of(ctx->device).shutdown();
+    return OFXCV_OK;
+}
+// measurement aid (not part of the public header): copies up to n doubles of the host-call trace (OFXCV_HOST_TRACE=1; 16 per call) and clears it
+extern "C" int ofxcv_debug_host_trace(double *out, int n) {
+    std::lock_guard<std::mutex> lk(HostTrace::mu());
+    std::vector<double> &v = HostTrace::log();
+    const int m = (int)std::min<size_t>(v.size(), (size_t)std::max(0, n));
+    if (out) std::memcpy(out, v.data(), sizeof(double) * m);
+    v.clear();
+    return m;
+}
+extern "C" int ofxcv_host_coalesce_stats(const ofxcv_ctx *ctx, long *calls, long *pairs, long *batch_pairs) {
+    if (!ctx) return OFXCV_ERR_INVALID;
+    if (calls) *calls = ctx->host_coalesced_calls;
+    if (pairs) *pairs = ctx->host_coalesced_pairs;
+    if (batch_pairs) *batch_pairs = ctx->host_coalesced_batches;
     return OFXCV_OK;
 }

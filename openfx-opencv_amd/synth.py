@@ -65,6 +65,25 @@ def flow_pair(w, h, seed=1234):
     return _rgba(a), _rgba(b)
 
 
+def sequence(w, h, n, seed=1234):
+    """n consecutive f32 RGBA frames of one shot: frame k(q) = a(q - k d(q)) with d = known_flow, so neighbouring frames differ by ~d
+    (2.5 +- 1 px, -1.25 +- 0.75 px) in either direction -- what the three source frames of a VectorGenerator output frame (t - 1, t, t + 1,
+    VectorGenerator.cpp:597-638) look like during playback."""
+    a = texture(w, h, seed)
+    u, v = known_flow(w, h)
+    x = np.arange(w, dtype=np.float64)[None, :]
+    y = np.arange(h, dtype=np.float64)[:, None]
+    return [_rgba(a if k == 0 else _bilinear(a, x - k * u, y - k * v)) for k in range(n)]
+
+
+def pingpong(t, n):
+    """index into n buffers for frame time t of an endless shot that runs 0, 1, ..., n-1, n-2, ..., 1, 0, 1, ...: neighbouring times are
+    always neighbouring frames"""
+    p = 2 * (n - 1)
+    r = t % p
+    return r if r < n else p - r
+
+
 def inpaint_frame(w, h, seed=1234, hole_seed=42, n_holes=12):
     """8-bit RGBA texture (every channel >= 1) with n_holes seeded filled ellipses set to (0,0,0,255)."""
     lum = texture(w, h, seed)

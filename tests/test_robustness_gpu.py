@@ -422,3 +422,107 @@ def test_named_frames_from_several_threads(ofxcv):
     assert not errors, errors
     print("hits / misses per thread:", counts)
     plain.close()
+
+
+def test_coalesced_host_call_equals_its_own_call(ofxcv):
+    """Option host.coalesce = 2 sends a lone host-image call through the device's submission queue (gray frames gathered into the batch
+    context's slots, ONE batched Farneback call there, the RGBA image composed -- or the flows copied back -- on the batch stream): the same
+    output as the call's own Farneback call (host.coalesce = 0) for the full channel map, a partial one, one direction, a render scale,
+    named frames and the pinned-ring form; the counters tell which path ran."""
+    from openfx_opencv_amd import synth
+    w, h = 333, 200
+    ref, nxt = synth.flow_pair(w, h, seed=7)
+    prev, _ = synth.flow_pair(w, h, seed=19)
+    own, queued, ring = ofxcv.Context(0), ofxcv.Context(0), ofxcv.Context(0)
+    own.set_option("host.coalesce", 0)
+    queued.set_option("host.coalesce", 2)
+    queued.set_option("host.split", 0)    # (a lone call otherwise takes the split form: two single-pair calls of its own)
+    ring.set_option("host.coalesce", 2)
+    ring.set_option("host.split", 0)
+    ring.set_option("host.register", 0)
+    assert queued.get_option("host.coalesce") == 2
+    n = 0
+    for fu, fv, bu, bv, rx, ry in [(1, 2, 4, 8, 1.0, 1.0), (4, 8, 1, 2, 0.5, 0.25), (3, 12, 0, 0, 1.0, 2.0), (1, 0, 0, 8, 1.0, 1.0), (1, 2, 2, 4, 2.0, 1.0)]:
+        outs = []
+        for c in (own, queued, ring):
+            o = np.full((h, w, 4), -3.0, np.float32)
+            c.vectorgen_flows_host(ref, nxt, prev, o, fu, fv, bu, bv, rx, ry)
+            outs.append(o)
+        n += 1
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (fu, fv, bu, bv)
+        assert queued.host_coalesce_stats() == (n, 2 * n, 2 * n) and own.host_coalesce_stats() == (0, 0, 0)
+    # one direction
+    a, b = np.zeros((h, w, 4), np.float32), np.zeros((h, w, 4), np.float32)
+    own.vectorgen_flow_host(ref, nxt, a, 0b0101, 0b1010)
+    queued.vectorgen_flow_host(ref, nxt, b, 0b0101, 0b1010)
+    assert np.array_equal(a, b) and queued.host_coalesce_stats() == (n + 1, 2 * n + 1, 2 * n + 1)
+    # named frames, found on the device the second time
+    queued.host_cache_clear()
+    for rep in range(2):
+        b[:] = 0
+        queued.vectorgen_flows_host(ref, nxt, prev, b, 1, 2, 4, 8, keys=("cq:1", "cq:2", "cq:0"))
+        own.vectorgen_flows_host(ref, nxt, prev, a, 1, 2, 4, 8)
+        assert np.array_equal(a, b)
+    assert queued.host_cache_hits() == 3
+    # other numerics switches travel with the request (the batch context takes them over)
+    for c in (own, queued):
+        c.set_option("farneback.gaussian_kernel_generation", 4)
+        c.set_option("farneback.resize_generation", 1)
+    own.vectorgen_flows_host(ref, nxt, prev, a, 1, 2, 4, 8)
+    queued.vectorgen_flows_host(ref, nxt, prev, b, 1, 2, 4, 8)
+    assert np.array_equal(a, b)
+    for c in (own, queued, ring):
+        c.host_cache_clear()
+        c.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("nthreads", [4, 8])
+def test_coalesced_host_calls_from_render_threads(ofxcv, nthreads):
+    """VectorGenerator is eRenderFullySafe (VectorGenerator.cpp:108): several render threads, one context each, render output frames at
+    once.  Their calls are coalesced per device: whoever finds the queue idle runs everything queued as one batched Farneback call.  Every
+    output frame is the frame the thread's own call gives (two frame sizes in flight at once: requests of another geometry never share a
+    call), and calls did ride together."""
+    import threading
+    from openfx_opencv_amd import synth
+    sizes = [(320, 200), (256, 144)]
+    seqs = [[synth.flow_pair(w, h, seed=70 + i)[0] for i in range(10)] for (w, h) in sizes]
+    plain = ofxcv.Context(0)
+    plain.set_option("host.coalesce", 0)
+    plain.host_cache_clear()
+    want = {}
+    for si, (w, h) in enumerate(sizes):
+        for t in range(1, 9):
+            o = np.zeros((h, w, 4), np.float32)
+            plain.vectorgen_flows_host(seqs[si][t], seqs[si][t + 1], seqs[si][t - 1], o, 1, 2, 4, 8)
+            want[(si, t)] = o
+    errors, stats = [], []
+    start = threading.Barrier(nthreads)
+
+    def work(k):
+        try:
+            c = ofxcv.Context(0)
+            si = k % 2 if k >= nthreads // 2 else 0           # most threads share a size, some render the other one
+            w, h = sizes[si]
+            start.wait()
+            for rep in range(4):
+                for t in range(1 + k % 8, 9, 3):
+                    o = np.full((h, w, 4), -1.0, np.float32)
+                    keys = ("q%d:%d" % (si, t), "q%d:%d" % (si, t + 1), "q%d:%d" % (si, t - 1)) if rep % 2 else None
+                    c.vectorgen_flows_host(seqs[si][t], seqs[si][t + 1], seqs[si][t - 1], o, 1, 2, 4, 8, keys=keys)
+                    if not np.array_equal(o, want[(si, t)]):
+                        errors.append((k, rep, t))
+            stats.append(c.host_coalesce_stats())
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    calls, pairs, batch_pairs = (sum(s[i] for s in stats) for i in range(3))
+    print("coalesced calls %d, their pairs %d, mean pairs of the call they rode in %.2f" % (calls, pairs, batch_pairs / max(1, calls)))
+    assert calls > 0 and batch_pairs > pairs      # some calls shared a batched call
+    plain.host_cache_clear()
+    plain.close()

@@ -18,12 +18,12 @@ ap.add_argument("--threads", default="1,2,4,8")
 ap.add_argument("--size", default="1920x1080")
 ap.add_argument("--block", type=int, default=16, help="frames per device block in --sequence mode (0 = device by calling thread)")
 ap.add_argument("--sequence", type=int, default=0, help="N > 0: the threads render the output frames of ONE sequence of N distinct frames in order "
-                "(thread i takes frames i, i + threads, ...), every frame named (ofxcv_vectorgen_flows_host_keyed): what an OFX host that provides "
+                "(a free thread takes the next frame, as a host hands them out), every frame named (ofxcv_vectorgen_flows_host_keyed): what an OFX host that provides "
                 "kOfxImagePropUniqueIdentifier gets during playback")
 args = ap.parse_args()
 W, H = (int(v) for v in args.size.split("x"))
-ref, nxt = synth.flow_pair(W, H, seed=11)
-prev, _ = synth.flow_pair(W, H, seed=12)
+shot = synth.sequence(W, H, 4)          # consecutive frames of one shot
+prev, ref, nxt = shot[0], shot[1], shot[2]
 if args.devices > torch.cuda.device_count():
     os.environ["OFXCV_VIRTUAL_DEVICES"] = str(args.devices)
 ndev = max(1, min(args.devices, ofxcv.lib().ofxcv_device_count()))
@@ -42,21 +42,25 @@ for nt in [int(v) for v in args.threads.split(",")]:
     counts = [0] * nt
     stop = threading.Event()
     if args.sequence:
-        seq = [synth.flow_pair(W, H, seed=200 + k)[0] for k in range(min(args.sequence, 8))]
-        seq = [seq[k % len(seq)].copy() for k in range(args.sequence)]     # N buffers (distinct names; the pixels repeat: generation is slow)
+        nseq = max(6, args.sequence // 6 * 6)                                # whole periods of the forth-and-back run: the wrap-around is seamless
+        seq = [shot[synth.pingpong(k, 4)].copy() for k in range(nseq)]        # N buffers (distinct names; the pixels repeat: generation is slow)
+        args.sequence = nseq
         ctxs[0].host_cache_clear()
+    next_frame = [0]
+    frame_lock = threading.Lock()
     def work(i):
         c, f = ctxs[i], frames[i]
-        t = i
         while not stop.is_set():
             if args.sequence:
                 n = args.sequence
+                with frame_lock:    # a host hands out the output frames of a sequence in order, whichever render thread is free
+                    t = next_frame[0]
+                    next_frame[0] += 1
                 a, b, p = t % n, (t + 1) % n, (t - 1) % n
                 # names by position in an endless sequence (the N buffers come round again under new names): every output frame
                 # has ONE frame the device has not seen, as in playback
                 cc = per_dev[i][(t // args.block) % ndev] if by_block else c
                 cc.vectorgen_flows_host(seq[a], seq[b], seq[p], f[3], 1, 2, 4, 8, keys=("f%d" % t, "f%d" % (t + 1), "f%d" % (t - 1)))
-                t += nt
             else:
                 c.vectorgen_flows_host(f[0], f[1], f[2], f[3], 1, 2, 4, 8)
             counts[i] += 1
@@ -74,6 +78,9 @@ for nt in [int(v) for v in args.threads.split(",")]:
     allc = ctxs + ([c for row in per_dev for c in row] if per_dev else [])
     if args.sequence:
         print("    named frames over all contexts: found %d / uploaded %d" % (sum(c.host_cache_hits() for c in allc), sum(c.host_cache_misses() for c in allc)), flush=True)
+    co = [c.host_coalesce_stats() for c in allc]
+    if sum(x[0] for x in co):
+        print("    coalesced calls %d of %d, mean pairs of the batched call they rode in %.2f" % (sum(x[0] for x in co), n, sum(x[2] for x in co) / sum(x[0] for x in co)), flush=True)
     lh = [c.lock_hold() for c in allc]
     print("    runtime lock: %.1f us held per Farneback call (%d holds)" % (sum(a for a, _ in lh) / 1e3 / max(1, sum(b for _, b in lh)), sum(b for _, b in lh)), flush=True)
     for c in allc:
