@@ -467,11 +467,12 @@ def main():
         "value_one_batch_in_flight": one_batch_in_flight,  # one batched call of `pairs_per_batched_call` pairs at a time
         "value_three_single_pair_calls_in_flight": three_single,  # the configuration BENCH_r01 / BENCH_r02 quoted as `value`
         "value_batches_of_16": batch16,  # one batched call of 16 pairs at a time (the call's maximum)
-        "host_lock_hold_us_per_call": lock_hold_us,  # inside the process-wide runtime lock per batched call (its hipGraphLaunch)
+        "host_lock_hold_us_per_call": lock_hold_us,  # inside the process-wide runtime lock per batched call: 0 with eager launches (the default since round 6)
         "host_lock": None if lock_hold_us is None else {
             "hold_us_per_batched_call": lock_hold_us, "call_us": lock_call_us, "utilisation_at_8_gpus_in_one_process": 8 * lock_hold_us / lock_call_us,
-            "note": "ofxcv_lock_hold: time a batched call of %d pairs spends inside the runtime lock (one hipGraphLaunch) / the call's GPU time; x 8 = how busy "
-                    "the ONE lock of a host process would be with eight devices (one process per GPU, as this benchmark's --gpus N, never meets it)" % B},
+            "note": "ofxcv_lock_hold: time a batched call of %d pairs spends inside the runtime lock / the call's GPU time; x 8 = how busy the ONE lock of a "
+                    "host process would be with eight devices.  Since round 6 a call's launches are enqueued eagerly (farneback.graph 0): no lock is "
+                    "held (0 holds); with farneback.graph 1 it is one hipGraphLaunch of 200-350 us" % B},
         "col_aborts": col_aborts,  # 1 if a bounded LDS wait of iterate_col_kernel ever ran out (never seen)
         "value_direct_window": statistics.median(drates) if drates else None,
         "value_direct_window_stats": None if not drates else dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "

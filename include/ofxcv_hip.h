@@ -87,7 +87,9 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    association of three float additions: 0 (default) ((a+b)+(c+d))/4 = bilinear = the 4.x SIMD path,
  *                                    1 (((a+b)+c)+d)/4 = the scalar loop (2.4.x, builds without SIMD), 2 ((a+c)+(b+d))/4 = the 3.x SSE2 path;
  *   "lut.four"                  0|1  gray LUT with four pixels per lane where the images are aligned for it (default 1);
- *   "farneback.graph"           0|1  replay the launch sequence of a call from a captured hipGraph (default 1);
+ *   "farneback.graph"           0|1  0 (default): the launches of a call are enqueued one by one (0.3 ms of host time for a call of 8 pairs at 1920x1080; no
+ *                                    runtime lock held); 1: captured once into a hipGraph and replayed with one hipGraphLaunch under the process-wide runtime
+ *                                    lock (the default of rounds 1-5; same speed, but the lock bounds a host process that drives several GPUs);
  *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
  *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
  *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);

@@ -58,7 +58,11 @@ struct ofxcv_ctx {
                                     // context with a high-priority stream were seen to run 3x slower (236 instead of 725 pairs/s): off.
     FbGraph fb_graphs[kFbGraphSlots];
     unsigned long fb_graph_clock = 0;
-    bool fb_no_graph = false, fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
+    // option "farneback.graph": 0 (default since round 6) the ~110 launches of a call are enqueued one by one -- 0.3 ms of host time for a call of 8 pairs,
+    // the first kernels run while the rest is enqueued, and NO runtime lock is held; 1 the call is captured once per (pointers, geometry, parameters) and
+    // replayed with one hipGraphLaunch under the runtime lock (rounds 1-5; measured equal within the box-to-box spread: tools/graph_vs_eager.py)
+    bool fb_no_graph = true;
+    bool fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
     int fb_polyexp_variant = 5;
     int fb_pyr_bytewise = 0;     // option "farneback.pyr_bytewise": 1 = the coarse pyramid levels take the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel)
     int fb_gauss_generation = 3;    // option "farneback.gaussian_kernel_generation": getGaussianKernel of OpenCV 2.4 / 3.x (3) or 4.x (4)

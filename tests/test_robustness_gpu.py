@@ -60,7 +60,9 @@ def test_graph_replay_and_eager_agree(ofxcv, oracle):
     a, b = synth.flow_pair(320, 240)
     ga, gb = _dev(oracle.to_byte_grayscale(a)), _dev(oracle.to_byte_grayscale(b))
     c1, c2 = ofxcv.Context(0), ofxcv.Context(0)
-    c2.set_option("farneback.graph", 0)
+    c1.set_option("farneback.graph", 1)      # captured once, replayed (the default of rounds 1-5)
+    c2.set_option("farneback.graph", 0)      # eager launches (the default)
+    assert ofxcv.Context(0).get_option("farneback.graph") == 0
     f_out = torch.empty((240, 320, 2), device="cuda")
     first = c1.calc_optical_flow_farneback(ga, gb, f_out).clone()          # capture + launch
     again = c1.calc_optical_flow_farneback(ga, gb, f_out).clone()          # replay of the cached graph
@@ -292,6 +294,8 @@ def test_virtual_devices_have_their_own_caches_and_locks(ofxcv, monkeypatch):
     w, h = 256, 144
     seq = [synth.flow_pair(w, h, seed=70 + i)[0] for i in range(3)]
     ctxs = [ofxcv.Context(d) for d in range(3)]
+    for c in ctxs:
+        c.set_option("farneback.graph", 1)   # (the lock-hold counter counts graph launches; the default, eager launches, holds no lock)
     with pytest.raises(ofxcv.OfxcvError):
         ofxcv.Context(3)
     for c in ctxs:
