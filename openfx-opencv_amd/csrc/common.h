@@ -18,6 +18,7 @@
 struct DevBuf {
     void *ptr = nullptr;
     size_t bytes = 0;
+    void *raw = nullptr;  // what hipMalloc returned (ptr = raw + the placement skew of ofxcv_reserve)
 };
 
 // cache of captured Farneback launch sequences (see ofxcv_calc_optical_flow_farneback)
@@ -42,8 +43,8 @@ struct FbGraph {
 };
 
 struct ofxcv_ctx {
-    int device = 0;      // LOGICAL device: index of the runtime lock (OFXCV_LOCK_PER_DEVICE) and of the per-device caches
-    int hip_device = 0;  // the HIP device behind it (OFXCV_VIRTUAL_DEVICES=N maps N logical devices onto the physical ones: device % physical count)
+    int device = 0;      // LOGICAL device: index of the per-device caches and queues
+    int hip_device = 0;  // the HIP device behind it (OFXCV_VIRTUAL_DEVICES=N maps N logical devices onto the physical ones: device % physical count); index of the runtime lock with OFXCV_LOCK_PER_DEVICE
     long lock_hold_ns = 0, lock_holds = 0;  // time this context's Farneback calls spent holding the runtime lock exclusively (graph capture / launch)
     hipStream_t compute = nullptr;  // default stream for kernels when the caller passes NULL
     hipStream_t copy = nullptr;     // H2D / D2H staging stream of the host-buffer entry points
@@ -69,6 +70,8 @@ struct ofxcv_ctx {
     int fb_filter_contraction = 0;  // option "farneback.filter_contraction": 1 = the separable filters of the pyramid and resize's vertical lerp as fused multiply-adds (OpenCV 4.x AVX2 / NEON paths); 0 = scalar order (2.4 / 3.x)
     int fb_resize_generation = 0;   // option "farneback.resize_generation": association of cv::resize's exact-2x INTER_AREA rewrite (farneback.hip: resize_combine)
     int num_cus = 256;
+    int max_lds = 160 * 1024;       // LDS a workgroup may use on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    bool is_gfx950 = true;          // LDS-DMA of 16 bytes per lane (buffer_load_dwordx4 ... lds) exists on gfx950 only: the R1 ring of iterate_col_kernel
     hipStream_t last_stream = nullptr;  // last caller-supplied stream (ofxcv_stream)
     char err[512] = {0};
 
@@ -101,7 +104,7 @@ struct ofxcv_ctx {
     int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (three wavefronts per SIMD: the boundary rows of the two steps share one LDS buffer beside the ring; 317 against 325 us per launch, not the default)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
-    int fb_reuse_prep = 0;       // option "farneback.reuse_prep" (measurement probe): skip the pyramid images / polynomial expansions, the scratch still holds those of the same frames
+    int fb_reuse_prep = 0;       // environment OFXCV_DEBUG_REUSE_PREP=1, read per call (measurement probe, not an option): skip the pyramid images / polynomial expansions, the scratch still holds those of the same frames
     int fb_col_ring = 1;         // option "farneback.col_ring": the step pairs of the column-owning form that open with an iteration gather R1 from a ring of rows in LDS filled by LDS-DMA (1, default); 0 = every gather from memory (cross-check, A/B)
     DevBuf fb_col_flag;          // the trace area of iterate_col_kernel (farneback.col_trace)
     unsigned *fb_col_abort = nullptr;  // the abort word of iterate_col_kernel: 64 bytes of pinned, host-coherent memory the kernel stores to when a bounded
@@ -208,7 +211,8 @@ static inline hipStream_t ofxcv_stream(ofxcv_ctx *ctx, void *stream) {
 // (A shared_mutex because readers may come back if a later runtime makes concurrent launches safe.)
 // One lock per device: the structures that raced are per-device (the stream list a graph launch walks), and a host
 // process that drives several GPUs from its render threads must not serialise all of them on one lock.
-std::shared_mutex &ofxcv_capture_mutex(int device);
+int ofxcv_lock_index(const ofxcv_ctx *ctx);  // ctx->hip_device (debug environment OFXCV_LOCK_BY_LOGICAL=1: ctx->device, the round-5 indexing)
+std::shared_mutex &ofxcv_capture_mutex(int hip_device);  // (the PHYSICAL device: logical devices that share a GPU share its lock)
 // Waits for everything this context has in flight (its own streams and the last caller-supplied one); never a
 // device-wide synchronisation, which would stall -- and invalidate the captures of -- other contexts' threads.
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx);

@@ -19,15 +19,26 @@ int ofxcv_fail(ofxcv_ctx *ctx, int status, const char *fmt, ...) {
 // The lock around the runtime operations that were seen to crash against each other on ROCm 7.2 (stream capture, graph
 // instantiation / launch / destruction, stream creation, device allocations and frees, host registration, context teardown).
 // Several of them touch process-global runtime state (memory-object maps, capture bookkeeping), so the lock is PROCESS-WIDE.
-// OFXCV_LOCK_PER_DEVICE=1 selects one lock per device: only for a multi-device soak
-// (tools/bench_host_threads.py --devices N, 4+ threads per device) -- no such run has been possible on the one-GPU boxes.
-std::shared_mutex &ofxcv_capture_mutex(int device) {
+// OFXCV_LOCK_PER_DEVICE=1 selects one lock per PHYSICAL device (it used to be indexed by the logical device, so with
+// OFXCV_VIRTUAL_DEVICES several "per-device" locks covered one GPU and admitted exactly the concurrent hipGraphLaunch pairs the lock exists
+// to prevent -- the round-5 soak that did not return ran in that configuration).  The per-device form has still not run on two physical
+// devices (one-GPU boxes only); since round 6 a Farneback call launches eagerly and takes no lock at all, so what is left under the lock is
+// rare (allocations when a scratch grows, stream creation, cross-context event operations of a few microseconds).
+std::shared_mutex &ofxcv_capture_mutex(int hip_device) {
     static std::shared_mutex m[64];
     static const bool per_device = [] {
         const char *e = std::getenv("OFXCV_LOCK_PER_DEVICE");
         return e && e[0] == '1';
     }();
-    return m[per_device ? ((unsigned)device & 63u) : 0u];
+    return m[per_device ? ((unsigned)hip_device & 63u) : 0u];
+}
+// (debug, tools/soak_hang_hunt.sh: OFXCV_LOCK_BY_LOGICAL=1 restores the round-5 indexing -- one lock per LOGICAL device -- to reproduce that round's hang)
+int ofxcv_lock_index(const ofxcv_ctx *ctx) {
+    static const bool by_logical = [] {
+        const char *e = std::getenv("OFXCV_LOCK_BY_LOGICAL");
+        return e && e[0] == '1';
+    }();
+    return by_logical ? ctx->device : ctx->hip_device;
 }
 
 int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
@@ -39,15 +50,20 @@ int ofxcv_ctx_quiesce(ofxcv_ctx *ctx) {
 
 int ofxcv_reserve(ofxcv_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.bytes) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
     if (b.ptr) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
-        OFXCV_HIP_CHECK(ctx, hipFree(b.ptr));
-        b.ptr = nullptr;
+        OFXCV_HIP_CHECK(ctx, hipFree(b.raw ? b.raw : b.ptr));
+        b.ptr = b.raw = nullptr;
         b.bytes = 0;
     }
-    OFXCV_HIP_CHECK(ctx, hipMalloc(&b.ptr, bytes));
+    // measurement aid (tools/col_time.py): environment OFXCV_SCRATCH_SKEW=bytes places every scratch buffer that far (a multiple of 256) behind the
+    // address hipMalloc returned -- does a kernel's time depend on where its fields lie in the channel interleave?
+    size_t skew = 0;
+    if (const char *e = std::getenv("OFXCV_SCRATCH_SKEW")) skew = (size_t)std::strtoull(e, nullptr, 0) & ~(size_t)255;
+    OFXCV_HIP_CHECK(ctx, hipMalloc(&b.raw, bytes + skew));
+    b.ptr = (char *)b.raw + skew;
     b.bytes = bytes;
     return OFXCV_OK;
 }
@@ -99,7 +115,7 @@ int ofxcv_prof_drain(ofxcv_ctx *ctx) {
 
 int ofxcv_farneback_streams(ofxcv_ctx *ctx) {
     if (ctx->prep) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));  // stream creation: see ofxcv_ctx_create
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));  // stream creation: see ofxcv_ctx_create
     int lo = 0, hi = 0;  // (numerically lower = higher priority)
     OFXCV_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
     if (ctx->fb_priority >= 1) OFXCV_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->prep, hipStreamNonBlocking, hi));
@@ -171,9 +187,15 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
         // stream creation changes the runtime's stream list, which another thread's hipGraphLaunch walks: under the runtime lock
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
         OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, ctx->hip_device));
+        OFXCV_HIP_CHECK(ctx, hipDeviceGetAttribute(&ctx->max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->hip_device));
+        {
+            hipDeviceProp_t prop;
+            OFXCV_HIP_CHECK(ctx, hipGetDeviceProperties(&prop, ctx->hip_device));
+            ctx->is_gfx950 = std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        }
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->compute, hipStreamNonBlocking));
         OFXCV_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
         for (int i = 0; i < 3; i++) OFXCV_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
@@ -193,7 +215,7 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
 void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->hip_device);
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
     (void)ofxcv_ctx_quiesce(ctx);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     for (FbGraph &g : ctx->fb_graphs)
@@ -206,7 +228,7 @@ void ofxcv_ctx_destroy(ofxcv_ctx *ctx) {
     if (ctx->ev_coarse) (void)hipEventDestroy(ctx->ev_coarse);
     DevBuf *bufs[] = {&ctx->fb_planes, &ctx->fb_tmp, &ctx->fb_flow, &ctx->fb_coef, &ctx->fb_vsum, &ctx->fb_col_flag, &ctx->d_stage, &ctx->ip_tmp, &ctx->ip_maps, &ctx->ip_img, &ctx->ip_work, &ctx->ip_flag, &ctx->ip_trace, &ctx->ip_sched2, &ctx->ip_tmap, &ctx->ip_omap, &ctx->seg_work};
     for (DevBuf *b : bufs)
-        if (b->ptr) (void)hipFree(b->ptr);
+        if (b->ptr) (void)hipFree(b->raw ? b->raw : b->ptr);
     if (ctx->ip_host_state && ctx->ip_host_state_free) ctx->ip_host_state_free(ctx->ip_host_state);
     if (ctx->d_srgb_lut) (void)hipFree(ctx->d_srgb_lut);
     if (ctx->fb_col_abort) (void)hipHostFree(ctx->fb_col_abort);
@@ -243,7 +265,7 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx) { return ctx ? (void *)ctx->compute
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
     if (!ctx || !name) return OFXCV_ERR_INVALID;
     // captured launch sequences bake the kernel choice in: drop them whenever an option changes
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
     for (FbGraph &g : ctx->fb_graphs)
         if (g.exec) {
             (void)hipGraphExecDestroy(g.exec);
@@ -334,7 +356,7 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
             {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
             {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20},
-            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}, {"farneback.reuse_prep", &ctx->fb_reuse_prep, 0, 1},
+            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1},
             {"host.coalesce", &ctx->host_coalesce, 0, 2}, {"host.coalesce_max", &ctx->host_coalesce_max, 0, OFXCV_FARNEBACK_MAX_BATCH},
             {"host.coalesce_depth", &ctx->host_coalesce_depth, 1, 4}, {"host.coalesce_eager", &ctx->host_coalesce_eager, 0, 1}, {"host.coalesce_min", &ctx->host_coalesce_min, 1, 64}};
         for (auto &k : knobs)

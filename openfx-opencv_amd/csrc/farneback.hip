@@ -945,12 +945,24 @@ __device__ __forceinline__ Buf make_buf(const void *p, size_t bytes) {
     b.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
     return b;
 }
+// AUX: cache policy bits of the instruction (gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1); 0 everywhere except where a kernel streams a field once
+template <int AUX = 0>
 __device__ __forceinline__ float buf_ld(const Buf &b, unsigned voff_bytes, unsigned soff_bytes) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff_bytes, (int)soff_bytes, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, (int)voff_bytes, (int)soff_bytes, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_st(const Buf &b, float v, unsigned voff_bytes, unsigned soff_bytes) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)voff_bytes, (int)soff_bytes, AUX);
 }
+#ifndef OFXCV_COL_LD_AUX
+#define OFXCV_COL_LD_AUX 0
+#endif
+#ifndef OFXCV_COL_R0_AUX
+#define OFXCV_COL_R0_AUX 0
+#endif
+#ifndef OFXCV_COL_ST_AUX
+#define OFXCV_COL_ST_AUX 0
+#endif
 // two horizontally adjacent taps of one plane.  Written as two dword loads; the compiler merges each pair into one
 // buffer_load_dwordx2.  Measured on the fused iteration kernel: keeping them apart (20 gather instructions per pixel
 // instead of 10) makes the launch 46 -> 56 us -- for gathers the per-instruction address work dominates, unlike the
@@ -2537,7 +2549,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             // every load where it is issued as soon as register pressure rises: 20 serial round trips per round, measured 414 -> 598 us.)
             const unsigned vo = y < h ? vx : 0xC0000000u;
 #pragma unroll
-            for (int c = 0; c < 5; c++) d[j][c] = buf_ld(bD, vo, so + c * pb);
+            for (int c = 0; c < 5; c++) d[j][c] = buf_ld<OFXCV_COL_LD_AUX>(bD, vo, so + c * pb);
         }
     };
 
@@ -2550,7 +2562,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         for (int i = 0; i <= RW; i++) {
             const unsigned so = (unsigned)clampi(a - 1 + i, 0, h - 1) * rb;
 #pragma unroll
-            for (int c = 0; c < 5; c++) r0n[i][c] = buf_ld(bR0, vx, so + c * pb);
+            for (int c = 0; c < 5; c++) r0n[i][c] = buf_ld<OFXCV_COL_R0_AUX>(bR0, vx, so + c * pb);
         }
     };
     if (!LAST1) load_r0(0);
@@ -2709,7 +2721,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         auto st_d3 = [&](float dv, int i, int c) __attribute__((always_inline)) {  // d''_t, t = a - 2 + i: rows a-1+i and a-4+i of M''
             const int t = a - 2 + i;
             // lanes that own no column and rows outside the image store to an out-of-range offset: dropped by the bounds check, no branch
-            buf_st(bDo, dv, (own && t >= 0 && t < h) ? vx : 0xC0000000u, (unsigned)clampi(t, 0, h - 1) * rb + c * pb);
+            buf_st<OFXCV_COL_ST_AUX>(bDo, dv, (own && t >= 0 && t < h) ? vx : 0xC0000000u, (unsigned)clampi(t, 0, h - 1) * rb + c * pb);
         };
         {
             Px q[RW];
@@ -3223,11 +3235,13 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     hipLaunchKernelGGL((iterate_col_kernel<K1, K2, RW, NW, RING, TRACE>), grid, dim3(64 * NW), 0, s, R0, R1, Din, Dout, fin, fout, pr, w, h, pitch, scale, ca, L.planes, rg)
     // the R1 ring in LDS (option farneback.col_ring, default on): the steps pairs that open with an iteration -- the ring's fill schedule rides on the
     // step-1 token -- in the eight-by-four geometry; everything else gathers from memory
-    const bool ring = ctx->fb_col_ring && g.nw == 8 && g.rw == 4;  // (the other geometries' ring variants are launched by name below)
+    // (the ring needs ColLds + ColRing = 159 KB of LDS and 16-byte LDS-DMA -- gfx950; anywhere else the launches gather from memory)
+    const bool ring_ok = ctx->is_gfx950 && (size_t)ctx->max_lds >= sizeof(ColLds<8>) + sizeof(ColRing);
+    const bool ring = ring_ok && ctx->fb_col_ring && g.nw == 8 && g.rw == 4;  // (the other geometries' ring variants are launched by name below)
     if (iter_pair && ctx->fb_col_trace) {
         if (ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
         else OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, true);
-    } else if (iter_pair && g.nw == 12 && ctx->fb_col_ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, true, false);
+    } else if (iter_pair && g.nw == 12 && ctx->fb_col_ring && ring_ok) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, true, false);
     else if (iter_pair && g.nw == 12) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, false, false);
     else if (k1 == kHaloIter && k2 == kHaloIter && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, false);
     else if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, false);
@@ -3663,6 +3677,13 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
     }
     const RgbaTab *rgba_p = have_rgba ? &rgba : nullptr;
     hipStream_t s = ofxcv_stream(ctx, stream);
+    // measurement probe (tools/reuse_prep_probe.py), deliberately NOT an option of the C ABI: with OFXCV_DEBUG_REUSE_PREP=1 in the
+    // environment a call skips its pyramid images and polynomial expansions and reads what the previous call left in the scratch -- only
+    // meaningful when the frames, geometry and batch are those of that call
+    {
+        const char *e = std::getenv("OFXCV_DEBUG_REUSE_PREP");
+        ctx->fb_reuse_prep = e && e[0] == '1';
+    }
     levels = num_levels(width, height, pyr_scale, levels);
     if (levels > kMaxLevels) levels = kMaxLevels;
 
@@ -3694,7 +3715,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         OFXCV_HIP_CHECK(ctx, hipMemsetAsync(ctx->fb_col_flag.ptr, 0, kColFlagBytes, s));
     }
     if (ctx->fb_col && !ctx->fb_col_abort) {  // its abort word: pinned, host-coherent (the host reads it at its synchronisation points without a copy)
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         void *p = nullptr;
         OFXCV_HIP_CHECK(ctx, hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(p, 0, 64);
@@ -3748,7 +3769,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         // one capture at a time per device, and no device allocation / free / context teardown of another host thread
         // during it (ofxcv_capture_mutex): either was seen to invalidate a capture on ROCm 7.2.  Launches, copies
         // and graph replays of other threads stay concurrent.
-        std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> capture_lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         const auto hold0 = std::chrono::steady_clock::now();
         if (slot->exec) {  // evicted entry: destroyed under the exclusive lock (see common.h)
             (void)hipGraphExecDestroy(slot->exec);
@@ -3781,7 +3802,7 @@ int ofxcv_calc_optical_flow_farneback_batch_rgba(ofxcv_ctx *ctx, int n, const ui
         // exclusive as well: two threads inside hipGraphLaunch at once (different graph execs, different streams) crashed in
         // hip::Graph::UpdateStreams on ROCm 7.2 -- about 1 in 30 runs of four concurrent render threads, backtrace under
         // rocgdb with every other locked operation parked on this lock
-        std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> launch_lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         const auto hold0 = std::chrono::steady_clock::now();
         g->used = ++ctx->fb_graph_clock;
         const hipError_t le = hipGraphLaunch(g->exec, s);

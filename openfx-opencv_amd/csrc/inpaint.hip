@@ -993,7 +993,7 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     // pinned host mirror of the per-pixel part of that scratch: the portions of the pipelined fill are handed over with
     // true asynchronous copies (a copy from pageable memory costs the host ~20 us and there are five per portion)
     if (ctx->ip_pinned_bytes < total) {
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         if (ctx->ip_pinned) {
             OFXCV_HIP_CHECK(ctx, hipStreamSynchronize(s));
             (void)hipHostFree(ctx->ip_pinned);

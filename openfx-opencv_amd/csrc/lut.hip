@@ -56,7 +56,7 @@ int ensure_lut(ofxcv_ctx *ctx, hipStream_t s) {
     for (int i = 0; i < 0x10000; ++i) lut[i] = (uint16_t)to_fixed_8_8(srgb_encode(bucket_midpoint((uint16_t)i)));
     for (int b = 0; b < 256; ++b) lut[high_half(srgb_decode(b / 255.0f))] = (uint16_t)(b << 8);
     {
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         OFXCV_HIP_CHECK(ctx, hipMalloc((void **)&ctx->d_srgb_lut, lut.size() * sizeof(uint16_t)));
     }
     OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_srgb_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void scale_flow_kernel(float2 *__restrict__ fl
 
 int reserve_pinned(ofxcv_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_pinned_bytes) return OFXCV_OK;
-    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+    std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
     if (ctx->h_pinned) {
         int rc = ofxcv_ctx_quiesce(ctx);
         if (rc) return rc;
@@ -139,6 +139,7 @@ namespace {
 struct GrayEntry {
     std::string key;
     int w = 0, h = 0, ncomp = 0;
+    int luma601 = 0;  // the conversion's luma weights (option "lut.luma"): part of what the gray bytes are
     size_t bytes = 0;
     uint8_t *ptr = nullptr;
     hipEvent_t ready = nullptr;
@@ -156,7 +157,7 @@ class GrayCache {
     void drop(size_t i, ofxcv_ctx *ctx) {  // mu_ held; entry unpinned: nothing of it is in flight (its users synchronised before unpinning)
         GrayEntry *e = entries_[i];
         {
-            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
             if (e->ptr) (void)hipFree(e->ptr);
             if (e->ready) (void)hipEventDestroy(e->ready);
             (void)hipGetLastError();
@@ -177,7 +178,7 @@ public:
         *fill = *pending = false;
         std::unique_lock<std::mutex> lk(mu_);
         for (GrayEntry *e : entries_)
-            if (e->w == w && e->h == h && e->ncomp == ncomp && !e->failed && e->key == key) {
+            if (e->w == w && e->h == h && e->ncomp == ncomp && e->luma601 == ctx->lut_luma601 && !e->failed && e->key == key) {
                 // Another thread may still be enqueueing the work that fills it (*pending).  Not waited for here: a caller takes all its
                 // frames first, and two callers that each fill what the other waits for would wait for ever -- wait_published() is
                 // called after the caller has published its own entries.
@@ -214,7 +215,7 @@ public:
         }
         if (!e) {
             e = new GrayEntry();
-            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
             if (hipMalloc((void **)&e->ptr, bytes) != hipSuccess || hipEventCreateWithFlags(&e->ready, hipEventDisableTiming) != hipSuccess) {
                 (void)hipGetLastError();
                 if (e->ptr) (void)hipFree(e->ptr);
@@ -225,6 +226,7 @@ public:
         e->recorded = e->failed = false;
         e->key = key;
         e->w = w; e->h = h; e->ncomp = ncomp;
+        e->luma601 = ctx->lut_luma601;
         e->bytes = bytes;
         e->pins = 1;
         e->stamp = ++clock_;
@@ -275,7 +277,7 @@ struct HostRegistrations {
     int n = 0;
     explicit HostRegistrations(ofxcv_ctx *c) : ctx(c) {}
     bool add(const void *ptr, size_t bytes) {
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         if (hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) != hipSuccess) {
             (void)hipGetLastError();  // e.g. already registered by the host application itself (or by another render thread
             return false;             // reading the same source frame): this call stages through the ring
@@ -300,7 +302,7 @@ struct HostRegistrations {
     }
     void release_all() {
         if (!n) return;
-        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+        std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
         for (int i = 0; i < n; i++) (void)hipHostUnregister(p[i]);
         (void)hipGetLastError();
         n = 0;
@@ -464,7 +466,7 @@ class FlowQueue {
                     fsteps[p] = (size_t)sg.w * 8;
                 }
             {
-                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(b->device));
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(b)));
                 for (const FlowReq *r : batch) OFXCV_HIP_CHECK(b, hipStreamWaitEvent(b->compute, r->ready, 0));
             }
             const size_t vec = gray / 16;
@@ -487,7 +489,7 @@ class FlowQueue {
                 p += r->n_other;
             }
             {
-                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(b->device));
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(b)));
                 OFXCV_HIP_CHECK(b, hipEventRecord(b->ev_done, b->compute));
                 for (const FlowReq *r : batch) OFXCV_HIP_CHECK(b, hipStreamWaitEvent(r->stream, b->ev_done, 0));
             }
@@ -802,7 +804,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     // "dependency created on uncaptured work in another stream" while another thread was capturing).
     auto take_cached = [&](int f) -> int {
         {
-            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
             OFXCV_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->compute, pins.e[f]->ready, 0));
         }
         OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(d_gray[f], pins.e[f]->ptr, gray, hipMemcpyDeviceToDevice, ctx->compute));
@@ -845,7 +847,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         if (pins.e[f]) {  // a named frame: its gray image goes into the cache entry as well
             OFXCV_HIP_CHECK(ctx, hipMemcpyAsync(pins.e[f]->ptr, d_gray[f], gray, hipMemcpyDeviceToDevice, ctx->compute));
             {
-                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+                std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
                 OFXCV_HIP_CHECK(ctx, hipEventRecord(pins.e[f]->ready, ctx->compute));
             }
             pins.cache->published(pins.e[f], true);
@@ -894,7 +896,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
     };
     if (coalesce) {
         {
-            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ctx->device));
+            std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(ctx)));
             OFXCV_HIP_CHECK(ctx, hipEventRecord(ctx->ev_done, ctx->compute));  // behind the last conversion: the frames are complete when it fires
         }
         tr[2] = HostTrace::on() ? HostTrace::now() : 0;

@@ -87,7 +87,7 @@ OfxStatus render(OfxImageEffectHandle instance, OfxPropertySetHandle inArgs, Ofx
     if (w <= 0 || h <= 0) return kOfxStatFailed;
     // image1 (RGBA, alpha 255) and the dilated mask, computed on the GPU (:303-318)
     std::vector<unsigned char> image1((size_t)w * h * 4), mask((size_t)w * h);
-    ofxcv_ctx *ctx = ThreadContext::get();
+    ThreadContext::Lease ctx = ThreadContext::get();
     check_hip(ctx, ofxcv_inpaint_render_host(ctx, (const uint8_t *)src.img.data, src.img.row_bytes, w, h, t1, t2, image1.data(),
                                              (ptrdiff_t)w * 4, mask.data()));
 

@@ -173,18 +173,29 @@ struct ImageGuard {
     ImageGuard &operator=(const ImageGuard &) = delete;
 };
 
-// One libofxcv_hip context per calling host thread AND device (render may be called concurrently: VectorGenerator is
-// eRenderFullySafe, VectorGenerator.cpp:108).  Which device: threads are spread round-robin over the visible devices -- unless the
-// caller asks for one (get(device)): frames that travel with names (kOfxImagePropUniqueIdentifier) stay on the device they were
-// uploaded to, so VectorGenerator sends BLOCKS of consecutive frame times to the same device whatever thread renders them
-// (device_for_time) and a sequence's frames are found again on an 8-GPU node as they are on one GPU.  The contexts live as long as
-// the thread.  A HIP failure maps to kOfxStatFailed / kOfxStatErrMemory.
+// Contexts of libofxcv_hip are LEASED per render() call from a pool per device (render may be called concurrently: VectorGenerator is
+// eRenderFullySafe, VectorGenerator.cpp:108; a context serves one call at a time).  A device holds as many contexts as it has ever had renders
+// in flight at once -- not one per render thread and device (named frames are routed by frame time, so with per-thread
+// contexts every render thread ended up with streams, staging and Farneback scratch on every GPU).  Which device: a thread's unnamed
+// renders go to its home device (threads are spread round-robin over the visible devices) -- unless the caller asks for one (get(device)):
+// frames that travel with names (kOfxImagePropUniqueIdentifier) stay on the device they were uploaded to, so VectorGenerator sends BLOCKS
+// of consecutive frame times to the same device whatever thread renders them (device_for_time) and a sequence's frames are found again
+// on an 8-GPU node as they are on one GPU.  A HIP failure maps to kOfxStatFailed / kOfxStatErrMemory.
 class ThreadContext {
   public:
     static constexpr int kMaxDevices = 64;
+    // (one hipGetDeviceCount + getenv per process, not per render; re-read after OfxActionUnload)
+    static int device_count() {
+        int n = cached_count().load(std::memory_order_relaxed);
+        if (n < 0) {
+            n = ofxcv_device_count();
+            cached_count().store(n, std::memory_order_relaxed);
+        }
+        return n;
+    }
     // the device of a named frame time: blocks of OFXCV_FRAMES_PER_DEVICE (default 16) consecutive frames per device, round-robin
     static int device_for_time(double time) {
-        const int n = ofxcv_device_count();
+        const int n = device_count();
         if (n <= 1) return 0;
         static const int per = [] {
             const char *e = std::getenv("OFXCV_FRAMES_PER_DEVICE");
@@ -194,66 +205,82 @@ class ThreadContext {
         const long blk = (long)std::floor(time / per);
         return (int)(((blk % n) + n) % n);
     }
-    static ofxcv_ctx *get(int device = -1) {
-        thread_local Holder h;
-        std::lock_guard<std::mutex> lock(h.mu);  // uncontended except against release_all()
-        const int n = ofxcv_device_count();
+    // a context of `device` for the duration of one render() (converts to ofxcv_ctx *); back to the pool on scope exit
+    class Lease {
+      public:
+        Lease(ofxcv_ctx *c, int d) : ctx_(c), dev_(d) {}
+        Lease(Lease &&o) noexcept : ctx_(o.ctx_), dev_(o.dev_) { o.ctx_ = nullptr; }
+        Lease(const Lease &) = delete;
+        Lease &operator=(const Lease &) = delete;
+        ~Lease() {
+            if (!ctx_) return;
+            Pool &p = pool(dev_);
+            std::lock_guard<std::mutex> lock(p.mu);
+            p.idle.push_back(ctx_);
+        }
+        operator ofxcv_ctx *() const { return ctx_; }
+
+      private:
+        ofxcv_ctx *ctx_;
+        int dev_;
+    };
+    static Lease get(int device = -1) {
+        const int n = device_count();
         if (n <= 0) throw SuiteError(kOfxStatFailed);
         if (device < 0) {
-            if (h.home < 0) {
+            thread_local int home = -1;  // this thread's place in the round-robin over the devices
+            if (home < 0) {
                 static std::atomic<int> next{0};
-                h.home = next.fetch_add(1);
+                home = next.fetch_add(1);
             }
-            device = h.home % n;
+            device = home % n;
         }
         device = (device % n) % kMaxDevices;
-        if (!h.ctx[device]) {
-            int rc = ofxcv_ctx_create(device, &h.ctx[device]);
-            if (rc == OFXCV_ERR_MEMORY) throw std::bad_alloc();
-            if (rc != OFXCV_OK) throw SuiteError(kOfxStatFailed);
+        Pool &p = pool(device);
+        {
+            std::lock_guard<std::mutex> lock(p.mu);
+            if (!p.idle.empty()) {
+                ofxcv_ctx *c = p.idle.back();  // the most recently used: its scratch is sized and warm
+                p.idle.pop_back();
+                return Lease(c, device);
+            }
         }
-        return h.ctx[device];
+        ofxcv_ctx *c = nullptr;
+        int rc = ofxcv_ctx_create(device, &c);
+        if (rc == OFXCV_ERR_MEMORY) throw std::bad_alloc();
+        if (rc != OFXCV_OK) throw SuiteError(kOfxStatFailed);
+        return Lease(c, device);
     }
-    // OfxActionUnload: the host guarantees no render is in flight; every context this plugin binary created on any
-    // thread is destroyed (streams, scratch, pinned staging, registrations), threads that render again re-create theirs
+    // OfxActionUnload: the host guarantees no render is in flight, so every context this plugin binary created is idle in its pool:
+    // all are destroyed (streams, scratch, pinned staging), with the named frames kept on their devices; renders after that re-create theirs
     static void release_all() {
-        std::lock_guard<std::mutex> lock(registry_mu());
-        for (Holder *h : registry()) {
-            std::lock_guard<std::mutex> hl(h->mu);
-            for (ofxcv_ctx *&c : h->ctx)
-                if (c) {
-                    (void)ofxcv_host_cache_clear(c);  // the named frames kept on its device (no call is using any: nothing is in flight)
-                    ofxcv_ctx_destroy(c);
-                    c = nullptr;
-                }
+        for (int d = 0; d < kMaxDevices; d++) {
+            Pool &p = pool(d);
+            std::lock_guard<std::mutex> lock(p.mu);
+            bool first = true;
+            for (ofxcv_ctx *c : p.idle) {
+                if (first) (void)ofxcv_host_cache_clear(c);  // (per device: the named frames and the submission queue's batch contexts)
+                first = false;
+                ofxcv_ctx_destroy(c);
+            }
+            p.idle.clear();
         }
+        cached_count().store(-1, std::memory_order_relaxed);
     }
 
   private:
-    struct Holder {
-        ofxcv_ctx *ctx[kMaxDevices] = {};
-        int home = -1;  // this thread's place in the round-robin over the devices
+    struct Pool {
         std::mutex mu;
-        Holder() {
-            std::lock_guard<std::mutex> lock(registry_mu());
-            registry().push_back(this);
-        }
-        ~Holder() {
-            {
-                std::lock_guard<std::mutex> lock(registry_mu());
-                auto &r = registry();
-                for (size_t i = 0; i < r.size(); i++)
-                    if (r[i] == this) {
-                        r.erase(r.begin() + i);
-                        break;
-                    }
-            }
-            for (ofxcv_ctx *c : ctx)
-                if (c) ofxcv_ctx_destroy(c);
-        }
+        std::vector<ofxcv_ctx *> idle;
     };
-    static std::mutex &registry_mu() { static std::mutex m; return m; }
-    static std::vector<Holder *> &registry() { static std::vector<Holder *> r; return r; }
+    static Pool &pool(int device) {
+        static Pool *pools = new Pool[kMaxDevices];  // intentionally leaked: no static destructor runs while a host unloads the plugin
+        return pools[device];
+    }
+    static std::atomic<int> &cached_count() {
+        static std::atomic<int> v{-1};
+        return v;
+    }
 };
 
 inline void check_hip(ofxcv_ctx *ctx, int rc) {

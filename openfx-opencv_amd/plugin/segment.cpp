@@ -93,7 +93,7 @@ OfxStatus render(OfxImageEffectHandle instance, OfxPropertySetHandle inArgs, Ofx
     const int h = src.img.height() & -(1 << level);
     if (w <= 0 || h <= 0) return kOfxStatOK;
     std::vector<unsigned char> image1((size_t)w * h * 4);
-    ofxcv_ctx *ctx = ThreadContext::get();
+    ThreadContext::Lease ctx = ThreadContext::get();
     const double sr = (int)t2 > 0 ? (double)(int)t2 : 1.0;
     const double sp = t1 / 25.0 >= 1.0 ? t1 / 25.0 : 1.0;   // threshold 1 (1..255, default 250) -> spatial radius (default 10)
     check_hip(ctx, ofxcv_segment_render_host(ctx, (const uint8_t *)src.img.data, src.img.row_bytes, w, h, sp, sr, level, image1.data(),

@@ -240,7 +240,7 @@ void calc_optical_flow(OfxImageEffectHandle effect, double time, const Image &re
     const int y1 = std::max(std::max(rw.y1, ref.bounds.y1), dst.bounds.y1), y2 = std::min(std::min(rw.y2, ref.bounds.y2), dst.bounds.y2);
     if (x1 >= x2 || y1 >= y2) return;
     // named frames: the device of this frame time's block (they are found again there whatever thread renders the neighbouring frames)
-    ofxcv_ctx *ctx = ThreadContext::get(ref.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
+    ThreadContext::Lease ctx = ThreadContext::get(ref.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
     if (x1 == ref.bounds.x1 && y1 == ref.bounds.y1 && x2 == ref.bounds.x2 && y2 == ref.bounds.y2) {
         float *d0 = (float *)((char *)dst.data + (ptrdiff_t)(y1 - dst.bounds.y1) * dst.row_bytes) + (size_t)(x1 - dst.bounds.x1) * 4;
         // (the frames with the names the host gives their pixels, as in the two-direction call of render())
@@ -322,7 +322,7 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
                 if (ch[i] == 3) bu |= 1u << i;
                 if (ch[i] == 4) bv |= 1u << i;
             }
-            ofxcv_ctx *ctx = ThreadContext::get(r.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
+            ThreadContext::Lease ctx = ThreadContext::get(r.unique_id.empty() ? -1 : ThreadContext::device_for_time(time));
             float *d0 = (float *)((char *)o.data + (ptrdiff_t)(r.bounds.y1 - o.bounds.y1) * o.row_bytes) + (size_t)(r.bounds.x1 - o.bounds.x1) * 4;
             // The frames travel with the names the host gives their pixels (kOfxImagePropUniqueIdentifier; "" = none): rendering
             // frame t+1 after frame t finds two of its three source frames on the device already.  A name covers the whole image:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What keeping a frame's pyramid images and polynomial expansions on the device could save at most: the same call
-with and without its preparation work (option farneback.reuse_prep: the scratch still holds the expansions of the same frames, results are
+with and without its preparation work (environment OFXCV_DEBUG_REUSE_PREP=1, read per call: the scratch still holds the expansions of the same frames, results are
 unchanged), for the call shapes of a render thread -- one pair, the two pairs of an output frame -- and a batch of 8.
 usage: python tools/reuse_prep_probe.py"""
 import os, sys, time
@@ -17,10 +17,10 @@ with torch.cuda.stream(c.stream):
     for n in (1, 2, 8):
         res = {}
         for reuse in (0, 1, 0, 1):
-            c.set_option("farneback.reuse_prep", 0)
+            os.environ["OFXCV_DEBUG_REUSE_PREP"] = "0"
             fl = c.calc_optical_flow_farneback_batch(ga[:n], gb[:n])   # fills the scratch with these frames' expansions
             ref = [f.clone() for f in fl]
-            c.set_option("farneback.reuse_prep", reuse)
+            os.environ["OFXCV_DEBUG_REUSE_PREP"] = str(reuse)
             for _ in range(3):
                 c.calc_optical_flow_farneback_batch(ga[:n], gb[:n], fl)
             torch.cuda.synchronize()

@@ -11,7 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--threads", type=int, default=8)
 ap.add_argument("--seconds", type=float, default=10)
 ap.add_argument("--cache-mb", type=int, default=1)
+ap.add_argument("--devices", type=int, default=1, help="logical devices (OFXCV_VIRTUAL_DEVICES over the physical ones); thread k renders on device k % N")
+ap.add_argument("--opts", default="", help="context options of the render threads: k=v,k=v")
 args = ap.parse_args()
+if args.devices > 1:
+    os.environ["OFXCV_VIRTUAL_DEVICES"] = str(args.devices)
 w, h, n = 384, 216, 12
 seq = [synth.flow_pair(w, h, seed=300 + i)[0] for i in range(n + 2)]
 plain = ofxcv.Context(0)
@@ -25,7 +29,9 @@ bad, calls, stats = [], [0] * args.threads, []
 stop = threading.Event()
 def work(k):
     rng = random.Random(k)
-    c = ofxcv.Context(0)
+    c = ofxcv.Context(k % args.devices)
+    for kv in filter(None, args.opts.split(",")):
+        c.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     c.set_option("host.cache_mb", args.cache_mb)
     c.set_option("host.split", rng.choice((0, 1, 2)))
     o = np.zeros((h, w, 4), np.float32)
