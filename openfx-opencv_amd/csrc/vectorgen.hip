@@ -404,6 +404,7 @@ class FlowQueue {
     std::condition_variable cv_;
     std::vector<FlowReq *> q_;
     int running_ = 0;
+    long batches_ = 0, batch_pairs_ = 0, batch_max_ = 0;  // coalesced calls formed on this device, their pairs, the largest
     static constexpr int kMaxDepth = 4;
     ofxcv_ctx *bctx_[kMaxDepth] = {};
     bool slot_busy_[kMaxDepth] = {};
@@ -539,6 +540,9 @@ public:
                     } else
                         i++;
                 }
+                batches_++;
+                batch_pairs_ += np;
+                batch_max_ = std::max(batch_max_, (long)np);
                 int slot = 0;
                 while (slot_busy_[slot]) slot++;  // (running_ < depth <= kMaxDepth: one is free)
                 slot_busy_[slot] = true;
@@ -574,6 +578,8 @@ public:
     // the idle batch contexts (streams, scratch, captured launch sequences) go; the next coalesced call re-creates them
     void shutdown() {
         std::lock_guard<std::mutex> lk(mu_);
+        if (HostTrace::on() && batches_)
+            std::fprintf(stderr, "ofxcv: submission queue: %ld coalesced calls, %.2f pairs on average, largest %ld\n", batches_, (double)batch_pairs_ / batches_, batch_max_);
         for (int i = 0; i < kMaxDepth; i++)
             if (bctx_[i] && !slot_busy_[i]) {
                 ofxcv_ctx_destroy(bctx_[i]);
