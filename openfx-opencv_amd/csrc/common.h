@@ -63,9 +63,9 @@ struct ofxcv_ctx {
     // the first kernels run while the rest is enqueued, and NO runtime lock is held; 1 the call is captured once per (pointers, geometry, parameters) and
     // replayed with one hipGraphLaunch under the runtime lock (rounds 1-5; measured equal within the box-to-box spread: tools/graph_vs_eager.py)
     bool fb_no_graph = true;
-    bool fb_no_fuse = false, fb_one_stream = false, fb_unfused_pyr = false;  // ofxcv_ctx_set_option
-    int fb_polyexp_variant = 5;
-    int fb_pyr_bytewise = 0;     // option "farneback.pyr_bytewise": 1 = the coarse pyramid levels take the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel)
+    bool fb_one_stream = false;     // pyramid + polynomial expansion on the call's own stream (set when a graph capture could not be completed)
+    int fb_pyr_mode = 1;            // option "farneback.fused_pyramid": 1 (default) LDS-fused / direct pyramid kernels; 0 the two-pass kernels; test hooks: 2 the coarse
+                                    // levels by the general byte-wise tile kernel (cross-check of pyr_fused_al_kernel), 3 the 3-tap levels without the wavefront-row form
     int fb_gauss_generation = 3;    // option "farneback.gaussian_kernel_generation": getGaussianKernel of OpenCV 2.4 / 3.x (3) or 4.x (4)
     int fb_filter_contraction = 0;  // option "farneback.filter_contraction": 1 = the separable filters of the pyramid and resize's vertical lerp as fused multiply-adds (OpenCV 4.x AVX2 / NEON paths); 0 = scalar order (2.4 / 3.x)
     int fb_resize_generation = 0;   // option "farneback.resize_generation": association of cv::resize's exact-2x INTER_AREA rewrite (farneback.hip: resize_combine)
@@ -85,23 +85,10 @@ struct ofxcv_ctx {
     DevBuf fb_coef;    // polyexp / blur coefficient tables
     DevBuf fb_vsum;    // f64 column sums of the OpenCV-rounding validation mode
     int fb_opencv_rounding = 1;  // 1 (default) OpenCV's running-sum order, strip-parallel; 0 direct window sums (fast opt-in); 2 OpenCV's order as a serial column scan
-    // Geometry hooks of the overlapped-strip form (iterate3h_kernel), for tests and A/B runs -- the forms they select are otherwise only
-    // reached at particular level sizes; validated in ofxcv_ctx_set_option.  Option "farneback.halo_geom" 0 by size, 1 four wavefronts of 5 rows, 2 four of 8 or 9,
-    // 3 eight of 8 or 9; "farneback.halo_min8" / "halo_min4": workgroups from which the eight- / four-wavefront tall form is used;
-    // "farneback.halo_strip": computed rows per strip (33..36 / 65..72) instead of the choice by launch rounds
-    // (halo_min8 300, was 250: a launch of exactly 256 tall workgroups -- 960x540 x 2 pairs, 480x270 x 8 -- is one round at half occupancy;
-    // the five-row form takes those: batches of 2 958 -> 1 024 pairs/s, batches of 8 +0.9 %, single calls and batches of 4 unchanged)
-    int fb_halo_geom = 0, fb_halo_min8 = 300, fb_halo_min4 = 1 << 30, fb_halo_strip = 0;
-    int fb_pyr_rows = 1;         // option "farneback.pyr_rows": the 3-tap pyramid levels in the wavefront-row form (pyr_direct3w_kernel); 0 = one sample group per lane
-    int fb_halo_deep = 2;        // option "farneback.halo_deep": wavefronts per SIMD of a launch up to which the small form keeps all gathers of a wavefront in flight (0 = never)
+    int fb_halo_geom = 0;        // option "farneback.halo_geom": test hook of the overlapped-strip form's geometry (encoding: farneback.hip halo_geom); 0 = by level size
     int lut_luma601 = 0;         // option "lut.luma" 709 (default) | 601: luma weights of the gray conversion (supportext's are not verifiable here)
-    int lut4 = 1;                // option "lut.four": gray LUT with four pixels per lane where the images are aligned for it
-    int fb_halo_min5 = 200;      // option "farneback.halo_min5": workgroups (of 37 stored rows) from which a small level takes eight wavefronts of 5 rows
-    int fb_halo_small = 3;       // option "farneback.halo_small": wavefronts of the small levels: 3 (default) eight of 3 rows, 2 eight of 2, 4 four of 3, 5 four of 5
     int fb_col = 1;              // option "farneback.col": column-owning form (iterate_col_kernel: two steps of a level per launch) on the levels whose launches fill the chip
     int fb_col_min = 128;        // option "farneback.col_min": workgroups (tile columns x pairs) below which no launch takes that form; from there on a cost model decides per level how many pairs do (col_pairs in farneback.hip); values below the default force the form (tests)
-    int fb_col_split = 1;        // option "farneback.col_split": the pairs of a call that do not fill a round of the chip in that form keep the overlapped strips (1); 0 = all pairs or none
-    int fb_col_geom = 0;         // option "farneback.col_geom": 0 eight wavefronts of 4 rows per round (32-row rounds: step 2 finds the lines of step 1 in the L2), 1 twelve of 3 (three wavefronts per SIMD: the boundary rows of the two steps share one LDS buffer beside the ring; 317 against 325 us per launch, not the default)
     int fb_col_spin = 1 << 22;   // option "farneback.col_spin": polls of one LDS wait before the kernel raises the abort word
     int fb_col_trace = 0;        // option "farneback.col_trace": the (iterate, iterate) launches run the instantiation that stamps the shader clock per phase (ofxcv_debug_col_trace)
     int fb_reuse_prep = 0;       // environment OFXCV_DEBUG_REUSE_PREP=1, read per call (measurement probe, not an option): skip the pyramid images / polynomial expansions, the scratch still holds those of the same frames
@@ -126,12 +113,9 @@ struct ofxcv_ctx {
     void (*ip_host_state_free)(void *) = nullptr;
     void *ip_pinned = nullptr;   // pinned mirror of the per-pixel upload arrays of the pipelined fill
     size_t ip_pinned_bytes = 0;
-    int ip_per_wg = 0;       // option "inpaint.pixels_per_workgroup" (A/B)
-    int ip_max_wg = 0;       // option "inpaint.max_workgroups": workgroups per component and portion of the pipelined fill (0 = 8)
     int ip_portion = 0;      // option "inpaint.portion": fill-order pixels per portion of the pipelined fill (0 = default)
     DevBuf ip_sched2; // level schedule of the fall-back fill
     int ip_max_tiles = 0;    // option "inpaint.max_tiles": workgroups (tiles) per fill launch; 0 = the chip's share of this call (192 / concurrent fills, at least 48)
-    int ip_dynamic = 0;      // option "inpaint.dynamic_grab": tile schedule, the wavefronts of a tile take its next pixel from an LDS counter (1) instead of every 16th in fill order (0)
     int ip_tiles = 1;        // option "inpaint.tiles": tile schedule of the dataflow fill (a workgroup per occupied tile of a portion, hand-offs inside a tile through LDS); 0 = component schedule (every hand-off through the L2)
     int ip_spin_limit = -1;  // option "inpaint.spin_limit" (tests force the fall-back with 0)
     int ip_parallel_march = 0;  // option "inpaint.parallel_march": 0 (default) serial front march, pipelined with the fill; 1 the hole's 4-connected
@@ -159,11 +143,7 @@ struct ofxcv_ctx {
                                    // (also a lone call: tests)
     int host_coalesce_max = 0;     // option "host.coalesce_max": frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip
                                    // in the column-owning form of level 0 (8 pairs at 1920x1080, 4 at 3840x2160)
-    int host_coalesce_depth = 1;   // option "host.coalesce_depth": coalesced calls in flight per device (1: the next one is formed when the running one has finished
-                                   // -- whatever arrived meanwhile rides in it; 2: a second one may be enqueued behind / beside it)
     int host_coalesce_min = 3;     // option "host.coalesce_min": host-image calls in flight on the device (this one included) from which a call goes to the queue
-    int host_coalesce_eager = 1;   // option "host.coalesce_eager": the batch context launches its kernels one by one (1, default: they start executing while the rest
-                                   // is being enqueued, and no runtime lock is held) instead of replaying a captured hipGraph (0: the GPU idles for most of a hipGraphLaunch)
     long host_coalesced_calls = 0, host_coalesced_pairs = 0, host_coalesced_batches = 0;  // calls of this context served by the queue, their pairs, the pairs of the batches they rode in
     int fb_reserve_pairs = 0;      // the Farneback scratch is sized for at least this many pairs (the batch context of the submission queue: no re-allocation as batches grow)
     int host_cache_mb = 512;       // option "host.cache_mb": budget of the device's cache of named frames' gray images (0 = off)

@@ -179,10 +179,6 @@ int ofxcv_ctx_create(int device, ofxcv_ctx **out) {
     if (!ctx) return OFXCV_ERR_MEMORY;
     ctx->device = device;
     ctx->hip_device = device % n;
-    if (const char *e = getenv("OFXCV_FARNEBACK_WINDOW")) {  // lets a plugin user pick the window evaluation without a new parameter
-        if (!std::strcmp(e, "direct")) ctx->fb_opencv_rounding = 0;
-        else if (!std::strcmp(e, "opencv")) ctx->fb_opencv_rounding = 1;
-    }
     if (const char *e = getenv("OFXCV_STREAM_PRIORITY")) ctx->fb_priority = atoi(e);
     int rc = OFXCV_OK;
     auto init = [&]() -> int {
@@ -271,117 +267,34 @@ int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value) {
             (void)hipGraphExecDestroy(g.exec);
             g.exec = nullptr;
         }
-    if (!std::strcmp(name, "farneback.polyexp_variant")) {
-        ctx->fb_polyexp_variant = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.opencv_rounding")) {
-        ctx->fb_opencv_rounding = value < 0 ? 0 : (value > 2 ? 1 : value);
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.gaussian_kernel_generation")) {
-        if (value != 3 && value != 4) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.gaussian_kernel_generation: 3 (OpenCV 2.4 / 3.x) or 4 (4.x)");
-        ctx->fb_gauss_generation = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "lut.luma")) {
-        if (value != 709 && value != 601) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "lut.luma: 709 (Rec.709 weights, default) or 601");
-        ctx->lut_luma601 = value == 601;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.filter_contraction")) {
-        if (value != 0 && value != 1) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.filter_contraction: 0 (scalar order) or 1 (fused multiply-adds, OpenCV 4.x vector paths)");
-        ctx->fb_filter_contraction = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.resize_generation")) {
-        if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "farneback.resize_generation: 0, 1 or 2");
-        ctx->fb_resize_generation = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "host.register")) {
-        ctx->host_register = value < 0 ? 0 : (value > 2 ? 1 : value);
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "host.cache_mb")) {
-        if (value < 0 || value > (1 << 18)) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "host.cache_mb: 0 (off) .. 262144");
-        ctx->host_cache_mb = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "host.split")) {
-        if (value < 0 || value > 2) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "host.split: 0, 1 or 2");
-        ctx->host_split = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.pixels_per_workgroup")) {
-        ctx->ip_per_wg = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.max_workgroups")) {
-        ctx->ip_max_wg = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.portion")) {
-        ctx->ip_portion = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.parallel_march")) {
-        ctx->ip_parallel_march = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.max_tiles")) {
-        if (value < 0 || value > 240) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "inpaint.max_tiles: 0 (automatic) .. 240");
-        ctx->ip_max_tiles = value;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.dynamic_grab")) {
-        ctx->ip_dynamic = value != 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.tiles")) {
-        ctx->ip_tiles = value != 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "inpaint.spin_limit")) {
-        ctx->ip_spin_limit = value;
-        return OFXCV_OK;
-    }
-    {
-        // test / A-B hooks (csrc/common.h has one line per hook): name, target, accepted range
-        struct { const char *n; int *v; int lo, hi; } knobs[] = {
-            {"farneback.halo_geom", &ctx->fb_halo_geom, 0, 3},    {"farneback.halo_min8", &ctx->fb_halo_min8, 0, 1 << 30},
-            {"farneback.halo_min4", &ctx->fb_halo_min4, 0, 1 << 30}, {"farneback.halo_strip", &ctx->fb_halo_strip, 0, 72},
-            {"farneback.halo_deep", &ctx->fb_halo_deep, 0, 8},    {"farneback.pyr_rows", &ctx->fb_pyr_rows, 0, 1},    {"farneback.halo_small", &ctx->fb_halo_small, 2, 6},
-            {"farneback.halo_min5", &ctx->fb_halo_min5, 0, 1 << 30}, {"lut.four", &ctx->lut4, 0, 1},
-            {"farneback.col", &ctx->fb_col, 0, 1},                {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
-            {"farneback.col_geom", &ctx->fb_col_geom, 0, 1},      {"farneback.col_trace", &ctx->fb_col_trace, 0, 1}, {"farneback.col_split", &ctx->fb_col_split, 0, 1},
-            {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.pyr_bytewise", &ctx->fb_pyr_bytewise, 0, 1}, {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20},
-            {"farneback.col_ring", &ctx->fb_col_ring, 0, 1},
-            {"host.coalesce", &ctx->host_coalesce, 0, 2}, {"host.coalesce_max", &ctx->host_coalesce_max, 0, OFXCV_FARNEBACK_MAX_BATCH},
-            {"host.coalesce_depth", &ctx->host_coalesce_depth, 1, 4}, {"host.coalesce_eager", &ctx->host_coalesce_eager, 0, 1}, {"host.coalesce_min", &ctx->host_coalesce_min, 1, 64}};
-        for (auto &k : knobs)
-            if (!std::strcmp(name, k.n)) {
-                if (value < k.lo || value > k.hi) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);
-                *k.v = value;
-                return OFXCV_OK;
-            }
-    }
-    if (!std::strcmp(name, "farneback.graph")) {
-        ctx->fb_no_graph = value == 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fuse_iterations")) {
-        ctx->fb_no_fuse = value == 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.prep_stream")) {
-        ctx->fb_one_stream = value == 0;
-        return OFXCV_OK;
-    }
-    if (!std::strcmp(name, "farneback.fused_pyramid")) {
-        ctx->fb_unfused_pyr = value == 0;
-        return OFXCV_OK;
-    }
+    int luma = ctx->lut_luma601 ? 601 : 709, graph = ctx->fb_no_graph ? 0 : 1;
+    // every option: name, target, accepted range (include/ofxcv_hip.h documents them; 25 in all)
+    struct { const char *n; int *v; int lo, hi; } knobs[] = {
+        // what the results are
+        {"farneback.opencv_rounding", &ctx->fb_opencv_rounding, 0, 2}, {"farneback.gaussian_kernel_generation", &ctx->fb_gauss_generation, 3, 4},
+        {"farneback.filter_contraction", &ctx->fb_filter_contraction, 0, 1}, {"farneback.resize_generation", &ctx->fb_resize_generation, 0, 2},
+        {"lut.luma", &luma, 601, 709},
+        // how a Farneback call is planned and launched (never changes a result)
+        {"farneback.graph", &graph, 0, 1}, {"farneback.col", &ctx->fb_col, 0, 1}, {"farneback.col_min", &ctx->fb_col_min, 1, 1 << 30},
+        {"farneback.col_ring", &ctx->fb_col_ring, 0, 1}, {"farneback.col_spin", &ctx->fb_col_spin, 1, 1 << 30}, {"farneback.col_trace", &ctx->fb_col_trace, 0, 1},
+        {"farneback.batch_mb", &ctx->fb_batch_mb, 1, 1 << 20}, {"farneback.halo_geom", &ctx->fb_halo_geom, 0, (72 << 8) | 0x7f},
+        {"farneback.fused_pyramid", &ctx->fb_pyr_mode, 0, 3},
+        // host images
+        {"host.register", &ctx->host_register, 0, 2}, {"host.split", &ctx->host_split, 0, 2}, {"host.cache_mb", &ctx->host_cache_mb, 0, 1 << 18},
+        {"host.coalesce", &ctx->host_coalesce, 0, 2}, {"host.coalesce_max", &ctx->host_coalesce_max, 0, OFXCV_FARNEBACK_MAX_BATCH},
+        {"host.coalesce_min", &ctx->host_coalesce_min, 1, 64},
+        // inpaint
+        {"inpaint.tiles", &ctx->ip_tiles, 0, 1}, {"inpaint.max_tiles", &ctx->ip_max_tiles, 0, 240}, {"inpaint.spin_limit", &ctx->ip_spin_limit, -1, 1 << 30},
+        {"inpaint.portion", &ctx->ip_portion, 0, 1 << 30}, {"inpaint.parallel_march", &ctx->ip_parallel_march, 0, 1 << 30}};
+    for (auto &k : knobs)
+        if (!std::strcmp(name, k.n)) {
+            if (value < k.lo || value > k.hi || (k.v == &luma && value != 601 && value != 709))
+                return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "option '%s': %d outside %d..%d", name, value, k.lo, k.hi);
+            *k.v = value;
+            ctx->lut_luma601 = luma == 601;
+            ctx->fb_no_graph = graph == 0;
+            return OFXCV_OK;
+        }
     return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "unknown option '%s'", name);
 }
 
@@ -393,7 +306,6 @@ int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value) {
     else if (!std::strcmp(name, "farneback.filter_contraction")) *value = ctx->fb_filter_contraction;
     else if (!std::strcmp(name, "lut.luma")) *value = ctx->lut_luma601 ? 601 : 709;
     else if (!std::strcmp(name, "farneback.graph")) *value = ctx->fb_no_graph ? 0 : 1;
-    else if (!std::strcmp(name, "farneback.fuse_iterations")) *value = ctx->fb_no_fuse ? 0 : 1;
     else if (!std::strcmp(name, "host.register")) *value = ctx->host_register;
     else if (!std::strcmp(name, "host.split")) *value = ctx->host_split;
     else if (!std::strcmp(name, "host.cache_mb")) *value = ctx->host_cache_mb;

@@ -1241,253 +1241,6 @@ __global__ __launch_bounds__(256) void blur_solve_update_kernel(const float *__r
     }
 }
 
-// Specialisation for the 3x3 window the reference uses (winSize = 3, VectorGenerator.cpp:395).
-//
-// Row walker: one wavefront owns 64 consecutive columns and walks down ROWS image rows.  Per row each
-// lane loads ONE new value per plane of M (a single coalesced 256-byte request per plane); its left and
-// right window neighbours arrive by DPP wave shifts (the wavefront shuffle of the 3-wide window
-// reduction) and only lanes 0 and 63 fetch the wave's halo column.  The f64 horizontal sum of the new
-// window row joins the two previous row sums held in registers, so the vertical reuse of the window
-// costs no memory traffic and no LDS.  The next row's M and R0 values are requested before the current
-// row's 2x2 solve and R1 gather, so a wave always has loads in flight.  ROWS is a template parameter:
-// the row loop is fully unrolled, which removes the register rotation of the window (a quarter of the
-// VALU instructions of a rolled loop).  Summation order (per window row left to right, rows top to
-// bottom) is that of the oracle's direct evaluation: results are bit-identical to it.
-//
-// Measured on MI355X (tools/ubench/l1rate.hip, tools/bench_stage.py): a coalesced dword wave-load costs
-// ~5 clk of the CU's texture addresser and a dwordx2/x4 one ~18 clk, and 2- or 4-pixel lanes were
-// slower (VGPR pressure halves the occupancy while the per-row dependent chain stays), hence one pixel
-// per lane and dword accesses throughout.
-__device__ __forceinline__ float dpp_from_left(float v, float edge) {  // lane i <- lane i-1, lane 0 <- edge
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_from_right(float v, float edge) {  // lane i <- lane i+1, lane 63 <- edge
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
-
-template <bool UPDATE, int ROWS>
-__global__ __launch_bounds__(256) void iterate3_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                       const float *__restrict__ Min, float *__restrict__ Mout,
-                                                       float *__restrict__ flow, size_t flow_step, int w, int h, int pitch,
-                                                       double scale, int r1q) {
-    const int lane = threadIdx.x & 63;
-    int tbx, tby;
-    xcd_tile(tbx, tby);
-    const int x = tbx * 256 + threadIdx.x;
-    if ((x & ~63) >= w) return;  // whole wave outside
-    const int y0 = tby * ROWS;
-    const bool live = x < w;
-    const int xc = min(x, w - 1);
-    // halo column of this wave: lane 0 fetches x-1, lane 63 fetches x+1 (clamped = replicated border)
-    const bool edge_lane = lane == 0 || lane == 63;
-    const unsigned ve = 4u * (unsigned)(lane == 0 ? max(xc - 1, 0) : min(xc + 1, w - 1));
-    const unsigned vc = 4u * (unsigned)xc;
-    const size_t plane = (size_t)pitch * h;
-    const unsigned pb = (unsigned)(plane * 4), rb = (unsigned)pitch * 4u;  // plane / row strides in bytes
-    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
-              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, UPDATE ? 5 * plane * sizeof(float) : 0);
-
-    // one raw row of M: the lane's value per plane + the halo value in the edge lanes
-    auto load_row = [&](int yy, float mc[5], float me[5]) {
-        const unsigned so = (unsigned)yy * rb;  // wave-uniform
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            mc[c] = buf_ld(bM, vc, so + c * pb);
-            me[c] = 0.f;
-        }
-        if (edge_lane) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) me[c] = buf_ld(bM, ve, so + c * pb);
-        }
-    };
-    auto hsum = [&](const float mc[5], const float me[5], double hs[5]) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            float ml = dpp_from_left(mc[c], me[c]), mr = dpp_from_right(mc[c], me[c]);
-            hs[c] = ((double)ml + (double)mc[c]) + (double)mr;
-        }
-    };
-
-    // window row sums: hs[r] holds image row y0 - 1 + r
-    double hs[ROWS + 2][5];
-    float mc[ROWS + 2][5], me[ROWS + 2][5], r0v[ROWS][5];
-    load_row(max(y0 - 1, 0), mc[0], me[0]);
-    load_row(y0, mc[1], me[1]);
-    load_row(min(y0 + 1, h - 1), mc[2], me[2]);
-    if (UPDATE) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0v[0][c] = buf_ld(bR0, vc, (unsigned)y0 * rb + c * pb);
-    }
-    hsum(mc[0], me[0], hs[0]);
-    hsum(mc[1], me[1], hs[1]);
-#pragma unroll
-    for (int r = 0; r < ROWS; r++) {
-        const int y = y0 + r;
-        if (y >= h) break;  // wave-uniform
-        if (r + 1 < ROWS) {  // request the next row before the dependent solve + gather of this one
-            load_row(min(y + 2, h - 1), mc[r + 3 < ROWS + 2 ? r + 3 : 0], me[r + 3 < ROWS + 2 ? r + 3 : 0]);
-            if (UPDATE) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) r0v[r + 1][c] = buf_ld(bR0, vc, (unsigned)min(y + 1, h - 1) * rb + c * pb);
-            }
-        }
-        hsum(mc[r + 2], me[r + 2], hs[r + 2]);
-        double acc[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) acc[c] = (hs[r][c] + hs[r + 1][c]) + hs[r + 2][c];
-        double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-        double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-        float fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-        float fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
-        if (flow && live) *(float2 *)((char *)flow + (size_t)y * flow_step + (size_t)x * 8) = make_float2(fxv, fyv);
-        if (UPDATE) {
-            const TapsQ tp = gather_taps_any(bR1, r1q != 0, xc, y, w, h, pitch, pb, fxv, fyv);
-            M5 mm = update_matrices_finish(r0v[r], tp, xc, y, w, h, fxv, fyv);
-            if (live) {
-#pragma unroll
-                for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], vc, (unsigned)y * rb + c * pb);
-            }
-        }
-    }
-}
-
-// Two iterations per launch (winSize 3).  M is the only state that is carried from one iteration to the next, and
-// an iteration reads it through a 3x3 window: a workgroup that stages its 62x14 output tile plus a 2-pixel ring of
-// M in LDS runs iteration i on tile + 1 ring (64x16: exactly one wavefront per ring row, that intermediate M stays
-// in LDS) and iteration i+1 on the tile.  The work is cut into two halves of 8 ring rows: first-iteration rows
-// 0..7, second-iteration rows that are complete by then, first-iteration rows 8..15, the remaining second-iteration
-// rows -- so the second gather of a pixel follows its first one within one phase (it finds R1's lines in the
-// cache instead of re-fetching them from HBM), and every wave meets "its" pixel row again, so R0 stays in
-// registers.  Algorithmic bytes per pixel for TWO iterations are 160; this kernel moves about
-// M-in 27 + R0 23 + R1 ~30 + M-out 20.  Every pixel evaluates exactly the operations of two single iterations in
-// the same order, so results are bit-identical to them.  Window positions outside the image hold the replicated
-// border value, as in the single-iteration kernels.
-constexpr int kFtW = 62, kFtH = 14, kFtThreads = 512;
-constexpr int kFtS0 = kFtW + 4;  // row stride of the staged M-in region (tile + 2 ring): 66
-constexpr int kFtS1 = kFtW + 2;  // row stride of the intermediate M region (tile + 1 ring): 64 = one wavefront
-static_assert(kFtS1 == 64 && kFtH + 2 == 2 * (kFtThreads / 64), "one wavefront per ring row, two rounds of eight rows");
-
-// 3x3 window sum + 2x2 solve from LDS.  rowp(c, r) = address of column lx - 1 of window row r (0..2) of plane c.
-template <typename RowPtr>
-__device__ __forceinline__ void box_solve_rows(RowPtr rowp, double scale, float &fxv, float &fyv) {
-    double acc[5];
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float *p0 = rowp(c, 0), *p1 = rowp(c, 1), *p2 = rowp(c, 2);
-        double h0 = ((double)p0[0] + (double)p0[1]) + (double)p0[2];
-        double h1 = ((double)p1[0] + (double)p1[1]) + (double)p1[2];
-        double h2 = ((double)p2[0] + (double)p2[1]) + (double)p2[2];
-        acc[c] = (h0 + h1) + h2;
-    }
-    double g11_ = acc[0] * scale, g12_ = acc[1] * scale, g22_ = acc[2] * scale, h1_ = acc[3] * scale, h2_ = acc[4] * scale;
-    double idet = 1. / (g11_ * g22_ - g12_ * g12_ + 1e-3);
-    fxv = (float)((g11_ * h2_ - g12_ * h1_) * idet);
-    fyv = (float)((g22_ * h1_ - g12_ * h2_) * idet);
-}
-
-// LEVEL0 only tags the symbol: the launches on the full-resolution level get their own row in a kernel trace
-template <bool LEVEL0>
-__global__ __launch_bounds__(kFtThreads) void iterate3x2_kernel(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                                const float *__restrict__ Min, float *__restrict__ Mout, int w, int h,
-                                                                int pitch, double scale) {
-    __shared__ float s0[5 * (kFtH + 4) * kFtS0];  // M-in on tile + 2 ring
-    // M after the first iteration on tile + 1 ring.  Only ring rows 0..7 have their own storage: rows 8..15 are written in the
-    // second half, when the first eight rows of s0 are dead (the first half read s0 rows 0..9, the second reads 8..17), and
-    // live there.  34 KB instead of 44 KB of LDS: four workgroups (8 waves per SIMD) per CU instead of three.
-    __shared__ float s1a[5 * 8 * kFtS1];
-    int tbx, tby;
-    xcd_tile(tbx, tby);
-    const int x0 = tbx * kFtW, y0 = tby * kFtH;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave index in an SGPR
-    const size_t plane = (size_t)pitch * h;
-    const unsigned pb = (unsigned)(plane * 4);
-    const Buf bM = make_buf(Min, 5 * plane * sizeof(float)), bR0 = make_buf(R0, 5 * plane * sizeof(float)),
-              bR1 = make_buf(R1, 5 * plane * sizeof(float)), bMo = make_buf(Mout, 5 * plane * sizeof(float));
-    constexpr int n0 = (kFtH + 4) * kFtS0;
-    auto s1row = [&](int c, int r) -> float * { return r < 8 ? s1a + (c * 8 + r) * kFtS1 : s0 + c * n0 + (r - 8) * kFtS0; };
-    // ring rows whose pixel lies inside the image: rows beyond it are replicas (their first-iteration result may be computed
-    // from s0 rows that are already being overwritten and is never read: the second iteration clamps its window rows)
-    const int rlo = y0 == 0 ? 1 : 0, rhi = min(kFtH + 1, h - y0);
-
-    // ring position (r, lane) <-> image pixel (clamp(y0 - 1 + r), clamp(x0 - 1 + lane)); wave `wave` owns ring rows
-    // `wave` (first half) and 8 + `wave` (second half) and keeps their R0 values in registers for the second iteration
-    const int xr = x0 - 1 + lane, x = clampi(xr, 0, w - 1);
-    struct Px {  // one pixel between "flow known, taps requested" and "M written"
-        TapsQ tp;    // (R1 in its packed form: this kernel only runs inside whole calls)
-        float fxv, fyv;
-        int y;
-        bool active;
-    };
-    auto first_prepare = [&](int r) {
-        Px p;
-        p.y = clampi(y0 - 1 + r, 0, h - 1);
-        p.active = true;
-        const int qc = p.y - (y0 - 2), qx = x - (x0 - 2);
-        box_solve_rows([&](int c, int k) { return (const float *)(s0 + c * n0 + (qc - 1 + k) * kFtS0 + (qx - 1)); }, scale, p.fxv, p.fyv);
-        p.tp = gather_taps_q(bR1, x, p.y, w, h, pitch, pb, p.fxv, p.fyv);
-        return p;
-    };
-    auto first_finish = [&](int r, const Px &p, const float r0v[5]) {
-        M5 mm = update_matrices_finish(r0v, p.tp, x, p.y, w, h, p.fxv, p.fyv);
-#pragma unroll
-        for (int c = 0; c < 5; c++) s1row(c, r)[lane] = mm.v[c];
-    };
-    auto second_prepare = [&](int r, bool wave_has_row) {  // ring row r = tile row r - 1
-        Px p;
-        p.y = y0 - 1 + r;
-        p.active = wave_has_row && lane >= 1 && lane <= kFtW && xr < w && p.y < h;  // not the ring itself, inside the image
-        p.fxv = p.fyv = 0.f;
-        if (p.active) {
-            const int ra = clampi(r - 1, rlo, rhi), rc = clampi(r + 1, rlo, rhi);
-            box_solve_rows([&](int c, int k) { return (const float *)(s1row(c, k == 0 ? ra : (k == 1 ? r : rc)) + (lane - 1)); }, scale, p.fxv, p.fyv);
-            p.tp = gather_taps_q(bR1, xr, p.y, w, h, pitch, pb, p.fxv, p.fyv);
-        }
-        return p;
-    };
-    auto second_finish = [&](const Px &p, const float r0v[5]) {
-        if (!p.active) return;
-        M5 mm = update_matrices_finish(r0v, p.tp, xr, p.y, w, h, p.fxv, p.fyv);
-        const unsigned off = ((unsigned)p.y * (unsigned)pitch + (unsigned)xr) * 4u;
-#pragma unroll
-        for (int c = 0; c < 5; c++) buf_st(bMo, mm.v[c], off, c * pb);
-    };
-
-    // R0 of both owned rows is requested first: it does not depend on M
-    float r0keep[2][5];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const unsigned off = ((unsigned)clampi(y0 - 1 + 8 * q + wave, 0, h - 1) * (unsigned)pitch + (unsigned)x) * 4u;
-#pragma unroll
-        for (int c = 0; c < 5; c++) r0keep[q][c] = buf_ld(bR0, off, c * pb);
-    }
-    // stage M-in: position (ry, rx) of the region holds M(clamp(y0 - 2 + ry), clamp(x0 - 2 + rx))
-    for (int e = threadIdx.x; e < n0; e += kFtThreads) {
-        const int ry = e / kFtS0, rx = e - ry * kFtS0;
-        const unsigned off = ((unsigned)clampi(y0 - 2 + ry, 0, h - 1) * (unsigned)pitch + (unsigned)clampi(x0 - 2 + rx, 0, w - 1)) * 4u;
-#pragma unroll
-        for (int c = 0; c < 5; c++) s0[c * n0 + e] = buf_ld(bM, off, c * pb);
-    }
-    __syncthreads();
-
-    {   // first iteration, ring rows 0..7
-        Px a = first_prepare(wave);
-        first_finish(wave, a, r0keep[0]);
-    }
-    __syncthreads();
-    {   // second iteration on tile rows 0..5 (ring rows 1..6 need rows 0..7) and first iteration on ring rows 8..15,
-        // which nobody reads yet
-        Px c0 = second_prepare(wave, wave >= 1 && wave <= 6);
-        second_finish(c0, r0keep[0]);
-        Px b1 = first_prepare(8 + wave);
-        first_finish(8 + wave, b1, r0keep[1]);
-    }
-    __syncthreads();
-    {   // remaining second-iteration rows: tile row 6 (ring row 7, wave 7) and tile rows 7..13 (ring rows 8..14)
-        Px c1 = second_prepare(wave == 7 ? 7 : 8 + wave, true);
-        second_finish(c1, wave == 7 ? r0keep[0] : r0keep[1]);
-    }
-}
-
 // ------------------------------------------------------------------ OPTFLOW_FARNEBACK_GAUSSIAN window
 //
 // FarnebackUpdateFlow_GaussianBlur: separable Gaussian window (sigma = (winsize/2) * 0.3), both passes accumulate in
@@ -2145,9 +1898,8 @@ struct ColArgs {
 
 template <int NW>
 struct ColLds {
-    // the boundary rows of the two steps: a buffer each -- or, where twelve wavefronts must fit beside the R1 ring, ONE that the steps take turns in
-    // (a wavefront's slot then carries its writes in sequence: step 1 and step 2 of round 0, of round 1, ...; put_boundary / get_boundary)
-    static constexpr int NB = NW > 8 ? 1 : 2;
+    // the boundary rows of the two steps: a buffer each
+    static constexpr int NB = 2;
     float b[NB][NW][3][5][64];
     // the token of step s: the running column sums of five channels per lane as {P0, P1} {P2, P3} {P4} and, written LAST and read FIRST, the ticket
     // they are for.  LDS executes a wavefront's accesses in issue order, so a reader that finds the tag finds the sums behind it: no fence, no
@@ -2238,13 +1990,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     static_assert(RW >= 3, "the three boundary rows");
     constexpr int DEPTH = 1;  // rows whose samples are in flight before the first is consumed (2 and 4 measured the same: r05_experiments.md)
     __shared__ ColLds<NW> lds;
-    static_assert(!RING || (K1 == kHaloIter && ((RW == 4 && NW == 8) || (RW == 3 && NW == 12))),
-                  "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows or twelve of three");
-    // Fill groups are four image rows whatever the wavefronts' rows.  Eight wavefronts of four rows: ticket t fills group t + 6.  Twelve of three: three of
-    // every four tickets fill a group (tickets 4m + j, j < 3, fill group 3m + j + 4): twelve rows per four tickets either way.  Lead 4 is what a 64-row
-    // ring allows there -- group g overwrites group g - 16, whose last reader (ticket floor((4g - 56) / 3) for step 2's rows one above) must be a
-    // whole round (twelve tickets) behind the filler; brute-forced over 400 groups in r05_experiments.md.
-    constexpr int kLead = RW == 3 ? 4 : kRingLead;  // (twelve of three: three leads the same launch time, two 44 % more: r05_experiments.md 14)
+    static_assert(!RING || (K1 == kHaloIter && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
+    // Fill groups are four image rows: ticket t fills group t + 6.  (A second geometry, twelve wavefronts of three rows with the boundary rows of both
+    // steps in one LDS buffer, ran 2.5 % faster in round 5 and was never the default; removed in round 6 -- profiles/r05_experiments.md 14 has it.)
+    constexpr int kLead = kRingLead;
     __shared__ typename std::conditional<RING, ColRing, int>::type ring;
     int tbx, tby, tbz;
     xcd_tile(tbx, tby, tbz);
@@ -2410,8 +2159,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     auto ring_wait = [&](int ticket) __attribute__((always_inline)) {
         if constexpr (RING) {
             // the last group this ticket's rows can reach, and the ticket that fills it
-            const int gk = (RW * ticket + RW - 1 + kRingD) / 4 - kLead;
-            const int T = RW == 4 ? gk : (gk < 0 ? -1 : 4 * (gk / 3) + gk % 3);
+            const int T = (RW * ticket + RW - 1 + kRingD) / 4 - kLead;
             const int l = fresh_lane();
             const int need = (l < NW && T >= l) ? (T - l) / NW + 1 : 0;
             unsigned n = 0;
@@ -2506,14 +2254,8 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
     };
     // the last three rows of this wavefront's step-s field for the wavefront below
-    // shared buffer: write number NSEQ * r + s of the slot (NSEQ = the steps of a round that hand rows on: the last step of a level does not)
-    constexpr bool SHB = ColLds<NW>::NB == 1;
-    constexpr int NSEQ = (!LAST1 && TWO && !LAST2) ? 2 : 1;
     auto put_boundary = [&](int s, int r, const float (&m)[RW][5]) __attribute__((always_inline)) {
-        const int sb = SHB ? 0 : s, seq = SHB ? NSEQ * r + s : r;
-        // (shared buffer: the last wavefront's rows of the last round have no reader -- wavefront 0 would take them a round later -- and its second
-        // write would wait for the read of its first for ever)
-        if (SHB && wave == NW - 1 && r == ca.rounds - 1) return;
+        const int sb = s, seq = r;
         lds_wait(&lds.rd[sb][wave], seq, ca);  // the reader is done with what was here before
         const int l = fresh_lane();
 #pragma unroll
@@ -2524,7 +2266,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     };
     auto get_boundary = [&](int s, int r, float (&pv)[3][5]) __attribute__((always_inline)) {
         const int rr = wave == 0 ? r - 1 : r;  // wavefront 0 takes what the last wavefront left in the round before
-        const int sb = SHB ? 0 : s, seq = SHB ? NSEQ * rr + s : rr;
+        const int sb = s, seq = rr;
         lds_wait(&lds.wr[sb][pw], seq + 1, ca);
         const int l = fresh_lane();
 #pragma unroll
@@ -2617,8 +2359,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             chain(0, ticket, sum, P);
             stamp(r, 2);   // chain of step 1 passed
             // (holding the token: every reader of the rows this overwrites is done)
-            if (RW == 4) ring_fill(ticket + kLead);
-            else if ((ticket & 3) != 3) ring_fill(3 * (ticket >> 2) + (ticket & 3) + kLead);
+            ring_fill(ticket + kLead);
             ring_wait(ticket);
             stamp(r, 3);   // fill issued, the rows this ticket reads have landed
         }
@@ -2866,11 +2607,11 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
     const int fcb = ctx->fb_filter_contraction << 4;  // the same flag for the kernels that take the two taps as scalars (bit 4 of `area`)
     int ntap = (lw == W && lh == H) ? 1 : 2;
     const int area = (W == 2 * lw && H == 2 * lh) ? ctx->fb_resize_generation : 0;  // cv::resize's exact-2x rewrite (resize_combine)
-    const bool no_fused = ctx->fb_unfused_pyr;
+    const bool no_fused = ctx->fb_pyr_mode == 0, pyr_rows = ctx->fb_pyr_mode != 3, pyr_bytewise = ctx->fb_pyr_mode == 2;
     bool aligned = true;
     for (int i = 0; i < nimg; i++) aligned = aligned && ((uintptr_t)imgs.p[i] & 3) == 0 && (imgs.step[i] & 3) == 0;
     const bool dword_ok = !no_fused && ksize == 3 && W >= 16 && H >= 2 && aligned && (I_stride & 3) == 0;
-    if (dword_ok && ctx->fb_pyr_rows && (W & 3) == 0 && H >= 4 && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
+    if (dword_ok && pyr_rows && (W & 3) == 0 && H >= 4 && (ntap == 1 || (W == 2 * lw && H == 2 * lh))) {
         // eight (k = 0) / four (k = 1) output rows per wavefront, four wavefronts per workgroup
         if (ntap == 1)
             hipLaunchKernelGGL((pyr_direct3w_kernel<1, 8>), dim3(ofxcv_div_up(W, 248), ofxcv_div_up(lh, 32), nimg), dim3(256), 0, s, imgs, W, H, lw, lh, gk.k[1], gk.k[2], d_I,
@@ -2895,7 +2636,7 @@ int launch_pyr_image(ofxcv_ctx *ctx, hipStream_t s, const ImgTab &imgs, int nimg
         return OFXCV_OK;
     }
     // the default pyramid's coarse levels: exactly a quarter / an eighth of the frame, 9 / 19 taps
-    if (!no_fused && !ctx->fb_pyr_bytewise && aligned && ntap == 2 && W >= 64 && H >= 64) {
+    if (!no_fused && !pyr_bytewise && aligned && ntap == 2 && W >= 64 && H >= 64) {
         const dim3 g(ofxcv_div_up(lw, 32), ofxcv_div_up(lh, 8), nimg);
         if (W == 4 * lw && H == 4 * lh && ksize == 9) {
             hipLaunchKernelGGL((pyr_fused_al_kernel<4, 9>), g, dim3(256), 0, s, imgs, W, H, lw, lh, gk, d_I, I_stride);
@@ -2956,28 +2697,22 @@ int launch_polyexp(ofxcv_ctx *ctx, hipStream_t s, const float *d_I, int w, int h
     int cw = kPeTW + 2 * poly_n, ldw = cw | 1, ih = kPeTH + 2 * poly_n;
     size_t lds = sizeof(float) * ((size_t)ih * ldw + 3 * kPeTH * ldw);
     dim3 grid(ofxcv_div_up(w, kPeTW), ofxcv_div_up(h, kPeTH), nimg);
-    if (ctx->fb_polyexp_variant >= 1 && (poly_n == 5 || poly_n == 7)) {
-        const int v = ctx->fb_polyexp_variant;
-        const int th = (v & 1) ? 16 : 8, wgs_per_cu = v <= 2 ? 4 : (v <= 4 ? 5 : 6);
+    if (poly_n == 5 || poly_n == 7) {
+        // persistent workgroups, 64 x 16 tiles, six workgroups per CU (the measured best of the round-2/3 variants: tiles of 8 rows and four / five
+        // workgroups per CU lost, the one-tile-per-workgroup kernel too: profiles/r03_experiments.md)
+        const int th = 16, wgs_per_cu = 6;
         const int tiles_x = (int)grid.x, tiles_y = ofxcv_div_up(h, th), ntiles = tiles_x * tiles_y;
         const int nwg = std::min((ntiles * nimg + 7) & ~7, ctx->num_cus * wgs_per_cu & ~7);  // a multiple of the 8 XCDs
 #define OFXCV_LAUNCH_PE(N, TH)                                                                                                          \
     hipLaunchKernelGGL((polyexp_persistent_kernel<N, TH>), dim3(nwg), dim3(256), 0, s, d_I, w, h, d_R, plane_pitch(w), pc, tiles_x, ntiles, \
                        nimg, I_stride, pair_stride, field, po)
-        if (poly_n == 5) {
-            if (th == 16) OFXCV_LAUNCH_PE(5, 16);
-            else OFXCV_LAUNCH_PE(5, 8);
-        } else {
-            if (th == 16) OFXCV_LAUNCH_PE(7, 16);
-            else OFXCV_LAUNCH_PE(7, 8);
-        }
+        if (poly_n == 5) OFXCV_LAUNCH_PE(5, 16);
+        else OFXCV_LAUNCH_PE(7, 16);
 #undef OFXCV_LAUNCH_PE
         OFXCV_LAUNCH_CHECK(ctx, "polyexp_persistent_kernel");
         return OFXCV_OK;
     }
-    if (poly_n == 5) hipLaunchKernelGGL(polyexp_kernel<5>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
-    else if (poly_n == 7) hipLaunchKernelGGL(polyexp_kernel<7>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
-    else hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
+    hipLaunchKernelGGL(polyexp_kernel<0>, grid, dim3(256), lds, s, d_I, w, h, d_R, plane_pitch(w), pc, I_stride, pair_stride, field, po);
     OFXCV_LAUNCH_CHECK(ctx, "polyexp_kernel");
     return OFXCV_OK;
 }
@@ -3005,25 +2740,6 @@ int launch_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
             else
                 hipLaunchKernelGGL(strict_solve_kernel<false>, grid, block, 0, s, r0, r1, (const double *)V, mo, flow, flow_step, w, h, pitch, scale, r1q);
             OFXCV_LAUNCH_CHECK(ctx, "strict_solve_kernel");
-        } else if (winsize == 3) {
-            // rows per wave: 2 keeps >= 3 rounds of waves per CU at 1080p (measured best); 1 for small levels
-            const int cols = ofxcv_div_up(w, 64);
-            int rows = 4;
-            while (rows > 1 && (long)cols * ofxcv_div_up(h, rows) < 8192) rows >>= 1;
-            dim3 grid(ofxcv_div_up(w, 256), ofxcv_div_up(h, rows)), block(256);
-#define OFXCV_LAUNCH_IT(UPD, RW) \
-    hipLaunchKernelGGL((iterate3_kernel<UPD, RW>), grid, block, 0, s, r0, r1, mi, mo, flow, flow_step, w, h, pitch, scale, r1q)
-            if (update) {
-                if (rows == 4) OFXCV_LAUNCH_IT(true, 4);
-                else if (rows == 2) OFXCV_LAUNCH_IT(true, 2);
-                else OFXCV_LAUNCH_IT(true, 1);
-            } else {
-                if (rows == 4) OFXCV_LAUNCH_IT(false, 4);
-                else if (rows == 2) OFXCV_LAUNCH_IT(false, 2);
-                else OFXCV_LAUNCH_IT(false, 1);
-            }
-#undef OFXCV_LAUNCH_IT
-            OFXCV_LAUNCH_CHECK(ctx, "iterate3_kernel");
         } else {
             dim3 grid(ofxcv_div_up(w, 64), ofxcv_div_up(h, 4)), block(64, 4);
             if (update)
@@ -3072,19 +2788,24 @@ int launch_gauss_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const
 struct HaloGeom {
     int rw, nw, tiles_x, nstrips, so;  // so = output rows per strip (computed rows - 3)
 };
+// Thresholds (workgroups over the whole batch) measured in rounds 3 - 5: eight tall wavefronts from 300 workgroups of 69 rows (a launch of exactly 256
+// tall workgroups is one round at half occupancy), eight wavefronts of 5 rows from 200 workgroups of 37 stored rows (960x540 of a single pair).
+// Test hook, option "farneback.halo_geom" (never changes a result): 0 by size; low nibble 1 small form, 2 four tall wavefronts, 3 eight tall;
+// bits 4..6 the small form's wavefronts (0 / 3: eight of 3 rows, 2: eight of 2, 4: four of 3, 5: four of 5, 6: eight of 5); bits 8.. the computed rows
+// of a tall strip (33..36 / 65..72) instead of the choice by launch rounds.
+constexpr int kHaloMin8 = 300, kHaloMin5 = 200, kHaloDeep = 2;
 HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
     HaloGeom g;
     g.tiles_x = ofxcv_div_up(w, kSsW);
     const long t = (long)g.tiles_x * n;
-    int form = ctx->fb_halo_geom;  // 0 = by size, 1 small, 2 four tall wavefronts, 3 eight
-    if (form < 1 || form > 3) form = t * ofxcv_div_up(h, 69) >= ctx->fb_halo_min8 ? 3 : (t * ofxcv_div_up(h, 33) >= ctx->fb_halo_min4 ? 2 : 1);
+    const int hook = ctx->fb_halo_geom, hook_small = (hook >> 4) & 7, hook_strip = hook >> 8;
+    int form = hook & 15;  // 0 = by size, 1 small, 2 four tall wavefronts, 3 eight
+    if (form < 1 || form > 3) form = t * ofxcv_div_up(h, 69) >= kHaloMin8 ? 3 : 1;
     if (form == 1) {
-        // small levels: by default eight wavefronts of 3 rows (21 stored rows per strip); option farneback.halo_small 5 = four of 5
-        // rows, 2 = eight of 2, 4 = four of 3
-        // ... and eight of 5 rows (difference field, no rows through LDS) on a level in between: 960x540 of a single pair, 240 such
-        // workgroups (16.2 against 17.3 us; on the levels below it the longer wavefronts lose: 12.9 / 14.0 against 10.4 / 12.0 us)
-        int f = ctx->fb_halo_small;  // 6 forces that form
-        if (f == 3 && t * ofxcv_div_up(h, 37) >= ctx->fb_halo_min5) f = 6;
+        // small levels: eight wavefronts of 3 rows (21 stored rows per strip), and eight of 5 rows (difference field, no rows through LDS) on a level
+        // in between: 960x540 of a single pair, 240 such workgroups (16.2 against 17.3 us; on the levels below it the longer wavefronts lose)
+        int f = hook_small ? hook_small : 3;
+        if (f == 3 && !hook_small && t * ofxcv_div_up(h, 37) >= kHaloMin5) f = 6;
         g.nw = (f == 5 || f == 4) ? 4 : 8;
         g.rw = (f == 5 || f == 6) ? 5 : (f == 2 ? 2 : 3);
         g.so = g.nw * g.rw - 3;
@@ -3097,7 +2818,7 @@ HaloGeom halo_geom(const ofxcv_ctx *ctx, int w, int h, int n) {
         double best_cost = 0;
         int best = g.nw * 9;
         for (int sc = g.nw * 8 + 1; sc <= g.nw * 9; sc++) {
-            if (ctx->fb_halo_strip > 0 && sc != ctx->fb_halo_strip && ctx->fb_halo_strip > g.nw * 8 && ctx->fb_halo_strip <= g.nw * 9) continue;
+            if (hook_strip > 0 && sc != hook_strip && hook_strip > g.nw * 8 && hook_strip <= g.nw * 9) continue;
             const double r = (double)t * ofxcv_div_up(h, sc - 3) / slots, full = std::floor(r), frac = r - full;
             const double cost = sc * (full + (frac > 0.02 ? 0.3 + 0.7 * frac : 0.0));
             if (best_cost == 0 || cost <= best_cost) {
@@ -3158,7 +2879,7 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
         else OFXCV_LAUNCH_HALO_K(kHaloGiven, RW, NW, VAR, DEEP);                   \
     } while (0)
     // small form: every gather of a wavefront in flight at once while the launch has at most two wavefronts per SIMD
-    const bool deep = g.rw == 5 && ctx->fb_halo_deep && (long)g.tiles_x * g.nstrips * L.n * 4 <= (long)ctx->fb_halo_deep * 4 * ctx->num_cus;
+    const bool deep = g.rw == 5 && (long)g.tiles_x * g.nstrips * L.n * 4 <= (long)kHaloDeep * 4 * ctx->num_cus;
     if (g.rw == 5 && g.nw == 8) OFXCV_LAUNCH_HALO(5, 8, false, false);
     else if (g.rw == 3 && g.nw == 8) OFXCV_LAUNCH_HALO(3, 8, false, true);
     else if (g.rw == 2) OFXCV_LAUNCH_HALO(2, 8, false, true);
@@ -3178,12 +2899,10 @@ int launch_halo_iteration(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const 
 struct ColGeom {
     int nw, rw, S, rounds, tiles_x;
 };
-ColGeom col_geom(const ofxcv_ctx *ctx, int w, int h, bool iter_pair) {
+ColGeom col_geom(int w, int h) {
     ColGeom g;
-    // experimental geometries exist for the (iterate, iterate) launch only; the field between launches does not depend on it
-    const bool wide = iter_pair && !ctx->fb_col_trace && ctx->fb_col_geom == 1;  // A/B: twelve wavefronts of three rows (36-row rounds)
-    g.nw = wide ? 12 : 8;
-    g.rw = wide ? 3 : 4;
+    g.nw = 8;  // eight wavefronts of four rows: 32-row rounds
+    g.rw = 4;
     g.tiles_x = ofxcv_div_up(w, kColW);
     g.S = g.nw * g.rw;
     g.rounds = ofxcv_div_up(h + 2, g.S);  // step 2 runs one row behind step 1, the differences it stores another row behind, and d_{h-1} needs the row below the image
@@ -3217,7 +2936,6 @@ int col_pairs(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
             ncol = g;
         }
     }
-    if (ctx->fb_col_split == 0 && ncol) ncol = n;  // option: the whole call or nothing (round 4's first half)
     return ncol;
 }
 int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Din, float *Dout, const FlowTab &fin, const FlowTab &fout,
@@ -3225,7 +2943,7 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     RgbaTab rg = {};
     if (rgba) rg = *rgba;
     const bool iter_pair = k1 == kHaloIter && k2 == kHaloIter;
-    const ColGeom g = col_geom(ctx, w, h, iter_pair);
+    const ColGeom g = col_geom(w, h);
     ColArgs ca = {hs.E[slot], hs.E[slot ^ 1], L.vsum, g.S, g.rounds, ctx->fb_col_abort, (unsigned)ctx->fb_col_spin,
                   ctx->fb_col_trace ? (unsigned long long *)((char *)ctx->fb_col_flag.ptr + 256) : nullptr};
     dim3 grid(g.tiles_x, 1, L.n);
@@ -3237,12 +2955,8 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     // step-1 token -- in the eight-by-four geometry; everything else gathers from memory
     // (the ring needs ColLds + ColRing = 159 KB of LDS and 16-byte LDS-DMA -- gfx950; anywhere else the launches gather from memory)
     const bool ring_ok = ctx->is_gfx950 && (size_t)ctx->max_lds >= sizeof(ColLds<8>) + sizeof(ColRing);
-    const bool ring = ring_ok && ctx->fb_col_ring && g.nw == 8 && g.rw == 4;  // (the other geometries' ring variants are launched by name below)
-    if (iter_pair && ctx->fb_col_trace) {
-        if (ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
-        else OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, true);
-    } else if (iter_pair && g.nw == 12 && ctx->fb_col_ring && ring_ok) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, true, false);
-    else if (iter_pair && g.nw == 12) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 3, 12, false, false);
+    const bool ring = ring_ok && ctx->fb_col_ring;
+    if (iter_pair && ctx->fb_col_trace && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, true);
     else if (k1 == kHaloIter && k2 == kHaloIter && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, true, false);
     else if (k1 == kHaloIter && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloIter, 4, 8, false, false);
     else if (k1 == kHaloIter && k2 == kHaloLast && ring) OFXCV_LAUNCH_COL_K(kHaloIter, kHaloLast, 4, 8, true, false);
@@ -3257,21 +2971,6 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     else return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "iterate_col_kernel: no such pair of steps (%d, %d)", k1, k2);
 #undef OFXCV_LAUNCH_COL_K
     OFXCV_LAUNCH_CHECK(ctx, "iterate_col_kernel");
-    return OFXCV_OK;
-}
-
-// two fused iterations M -> M'' (winsize 3, direct-window mode), pair by pair
-int launch_iteration_pair(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float *R1, const float *Min, float *Mout, int w, int h,
-                          bool level0, const Layout &L) {
-    dim3 grid(ofxcv_div_up(w, kFtW), ofxcv_div_up(h, kFtH));
-    for (int z = 0; z < L.n; z++) {
-        const size_t o = (size_t)z * L.planes;
-        if (level0)
-            hipLaunchKernelGGL(iterate3x2_kernel<true>, grid, dim3(kFtThreads), 0, s, R0 + o, R1 + o, Min + o, Mout + o, w, h, plane_pitch(w), 1. / 9.);
-        else
-            hipLaunchKernelGGL(iterate3x2_kernel<false>, grid, dim3(kFtThreads), 0, s, R0 + o, R1 + o, Min + o, Mout + o, w, h, plane_pitch(w), 1. / 9.);
-        OFXCV_LAUNCH_CHECK(ctx, "iterate3x2_kernel");
-    }
     return OFXCV_OK;
 }
 
@@ -3472,7 +3171,6 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             for (int z = ncol; z < n; z += per_group) plan[ngroups++] = {z, std::min(per_group, n - z), false};
         }
         const FlowTab out_all = k == 0 ? out : coarse_tab(cflow[k & 1], (size_t)w * 8);
-        const bool fuse = !ctx->fb_no_fuse && winsize == 3 && !ctx->fb_opencv_rounding && !gaussian;
         for (int gi = 0; gi < ngroups; gi++) {
             const int z0 = plan[gi].z0, gn = plan[gi].gn;
             const bool col = plan[gi].col;
@@ -3571,15 +3269,11 @@ static int enqueue_farneback(ofxcv_ctx *ctx, hipStream_t s, hipStream_t sp, cons
             OFXCV_LAUNCH_CHECK(ctx, "update_matrices_kernel");
             int cur = 0;
             for (int i = 0; i < iterations;) {
-                const bool pair = fuse && i + 2 <= iterations - 1;
-                const bool prof = profile && k == 0 && (fuse ? pair : i < iterations - 1);  // the dominant kernel's launches
-                const bool inner = prof && halo && !pair;  // marks set around the kernel inside launch_halo_iteration
+                const bool prof = profile && k == 0 && i < iterations - 1;  // the dominant kernel's launches
+                const bool inner = prof && halo;  // marks set around the kernel inside launch_halo_iteration
                 ctx->prof_now = inner;
                 if (prof && !inner && (rc = ofxcv_prof_mark(ctx, s))) return rc;
-                if (pair) {  // two updating iterations in one launch
-                    rc = launch_iteration_pair(ctx, s, R0, R1, Mg[cur], Mg[cur ^ 1], w, h, k == 0, G);
-                    i += 2;
-                } else {
+                {
                     bool update = i < iterations - 1;
                     const FlowTab &ft = update ? no_flow : out_tab;
                     if (gaussian)

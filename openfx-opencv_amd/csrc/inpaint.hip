@@ -331,7 +331,6 @@ struct FillArgs {
     int spin_limit;                                      // polls a wavefront spends on one awaited colour before it gives up
     int k0;                                              // tile schedule: the order numbers of this launch's pixels are k0+1 .. k0+kFillSlots at most
     int ts;                                              // tile schedule: tile size (padded pixels); 0 = component schedule (all polls through the L2)
-    int dyn;                                             // tile schedule: wavefronts take the tile's next pixel from an LDS counter (1) instead of every 16th (0)
 };
 
 __device__ __forceinline__ void wave_lds_sync() {  // LDS hand-over between lanes of ONE wavefront
@@ -401,10 +400,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
         __syncthreads();
     }
     const int ts = LDSWIN ? a.ts : 0;
-    __shared__ int s_next;  // tile schedule, dynamic grab: the next pixel of the tile nobody has taken yet
     if (ts) {
         for (int e = threadIdx.x; e < kFillSlots; e += 64 * NWAVES) s_slot[e] = 0;
-        if (threadIdx.x == 0) s_next = 0;
         __syncthreads();
     }
     const int ec = a.w + 2, er = a.h + 2, range = a.range;
@@ -741,22 +738,8 @@ __global__ __launch_bounds__(64 * NWAVES) void telea_fill_kernel(FillArgs a) {
         // cmp_off holds one record per workgroup: {first pixel, end, this workgroup's first wavefront slot, slots in total}
         const int cbeg = a.cmp_off[4 * blockIdx.x], cend = a.cmp_off[4 * blockIdx.x + 1];
         const int first = a.cmp_off[4 * blockIdx.x + 2], stride = a.cmp_off[4 * blockIdx.x + 3];
-        if (ts && a.dyn) {
-            // A wavefront takes the tile's next pixel when it is free (fill order is kept: pixels are handed out in ascending order, so whatever a
-            // wavefront waits for has been taken by somebody before -- the smallest unfinished pixel always has an owner that waits for nobody).
-            // Against the static form (every 16th pixel) this takes the head-of-line blocking out of a tile: a wavefront whose pixel had to wait
-            // does not hold back the fifteen behind it.
-            for (;;) {
-                int k = 0;
-                if (lane == 0) k = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                k = __builtin_amdgcn_readfirstlane(k);
-                const int id = cbeg + k;
-                if (id >= cend) break;
-                fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
-            }
-        } else {
-            for (int id = cbeg + first + wave; id < cend; id += stride) fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
-        }
+        // (round 4/5 also had a dynamic form -- a wavefront takes the tile's next pixel from an LDS counter -- which bought nothing: removed in round 6)
+        for (int id = cbeg + first + wave; id < cend; id += stride) fill_pixel(a.cmp_pix[id], a.cmp_ord[id]);
     } else {
         const int seg_beg = a.comp_off[blockIdx.x], seg_end = a.comp_off[blockIdx.x + 1];
         int beg = seg_beg < seg_end ? a.lvl_off[seg_beg] : 0;
@@ -1058,7 +1041,6 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
     fa.spin_limit = 0;
     fa.k0 = 0;
     fa.ts = 0;
-    fa.dyn = 0;
     fa.lvl_pix = fa.cmp_pix = (const int *)(dp + off_pix);
     fa.lvl_ord = fa.cmp_ord = (const int *)(dp + off_po);
     fa.lvl_off = fa.cmp_off = (const int *)(dp + off_wg);
@@ -1129,12 +1111,11 @@ int ofxcv_inpaint(ofxcv_ctx *ctx, const uint8_t *d_src, ptrdiff_t src_step, int 
             if (nwg < 0) {
                 ts = 0;
                 m.cell.clear();  // the tile pass leaves the grid in another geometry
-                nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, ctx->ip_per_wg > 0 ? ctx->ip_per_wg : 256,
-                                             ctx->ip_max_wg > 0 ? ctx->ip_max_wg : 8, fill_waves);
+                nwg = build_dataflow_portion(m, k0, k1, sp, so, sw, m.cell, m.stack, 256,
+                                             8, fill_waves);
             }
             fa.k0 = k0;
             fa.ts = ts;
-            fa.dyn = ctx->ip_dynamic;
             // the portion's block: [pixel index | distance | schedule pixel | schedule order number] x got, [workgroup record] x nwg
             const size_t a16 = 16, q = align_up((size_t)got * 4, a16);
             const size_t b_idx = cursor, b_t = b_idx + q, b_pix = b_t + q, b_ord = b_pix + q, b_wg = b_ord + q, b_end = b_wg + align_up((size_t)nwg * 16, a16);

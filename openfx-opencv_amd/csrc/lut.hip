@@ -188,7 +188,7 @@ int ofxcv_to_byte_grayscale(ofxcv_ctx *ctx, const float *d_src, ptrdiff_t src_ro
     constexpr int kSeg = 1;
     const uint16_t *lut_arg = (const uint16_t *)((uintptr_t)ctx->d_srgb_lut | (ctx->lut_luma601 ? 1u : 0u));  // (bit 0: Rec.601 luma weights, lut_byte)
     dim3 block(256), grid(ofxcv_div_up(width, 256 * kSeg), height);
-    if (ncomp == 4 && ctx->lut4 && !(width & 3) && !(((uintptr_t)d_src) & 15) && !(src_row_bytes & 15) && !(((uintptr_t)d_dst) & 3) && !(dst_row_bytes & 3))
+    if (ncomp == 4 && !(width & 3) && !(((uintptr_t)d_src) & 15) && !(src_row_bytes & 15) && !(((uintptr_t)d_dst) & 3) && !(dst_row_bytes & 3))
         hipLaunchKernelGGL(gray_lut4_kernel, dim3(ofxcv_div_up(width / 4, 256), height), block, 0, s, d_src, src_row_bytes, width, height, d_dst, dst_row_bytes,
                            lut_arg);
     else if (ncomp == 4)
@@ -203,7 +203,7 @@ int ofxcv_to_byte_grayscale_batch(ofxcv_ctx *ctx, int n, const float *const *d_s
                                   int height, uint8_t *const *d_dst, const ptrdiff_t *dst_row_bytes, void *stream) {
     if (!ctx) return OFXCV_ERR_INVALID;
     if (n <= 0 || !d_src || !src_row_bytes || !d_dst || !dst_row_bytes) return ofxcv_fail(ctx, OFXCV_ERR_INVALID, "to_byte_grayscale_batch: bad argument");
-    bool fast = ncomp == 4 && ctx->lut4 && n <= kLutBatch && width > 0 && height > 0 && !(width & 3);
+    bool fast = ncomp == 4 && n <= kLutBatch && width > 0 && height > 0 && !(width & 3);
     for (int i = 0; fast && i < n; i++)
         fast = d_src[i] && d_dst[i] && !(((uintptr_t)d_src[i]) & 15) && !(src_row_bytes[i] & 15) && !(((uintptr_t)d_dst[i]) & 3) && !(dst_row_bytes[i] & 3);
     if (!fast) {  // whatever the four-pixel kernel cannot take (RGB, odd widths, unaligned rows), and every argument check: frame by frame

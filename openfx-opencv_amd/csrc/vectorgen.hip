@@ -909,7 +909,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         FlowReq rq;
         rq.sig = {width, height, levels, iterations, poly_n, ctx->fb_opencv_rounding, ctx->fb_gauss_generation, ctx->fb_filter_contraction, ctx->fb_resize_generation, poly_sigma};
         rq.n_other = n_other;
-        rq.no_graph = ctx->fb_no_graph || ctx->host_coalesce_eager;
+        rq.no_graph = true;  // (the queue's call is launched kernel by kernel: no runtime lock held, the first kernels run while the rest is enqueued)
         rq.ready = ctx->ev_done;
         rq.stream = ctx->compute;
         for (int f = 0; f < nf; f++) rq.gray[f] = d_gray[f];
@@ -926,7 +926,7 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         // one workgroup per CU: 8 pairs at 1920x1080, 4 at 3840x2160) -- measured: 12 queued pairs run faster as 8 + (4 + newcomers) than as 12
         int max_pairs = ctx->host_coalesce_max;
         if (max_pairs <= 0) max_pairs = std::max(2, std::min(OFXCV_FARNEBACK_MAX_BATCH, (ctx->num_cus / std::max(1, ofxcv_div_up(width, 60))) & ~1));
-        rc = FlowQueue::of(ctx->device).submit(ctx->device, rq, max_pairs, ctx->host_coalesce_depth);
+        rc = FlowQueue::of(ctx->device).submit(ctx->device, rq, max_pairs, 1);
         if (rc) return ofxcv_fail(ctx, rc, "%s", rq.err);
         OFXCV_HIP_CHECK(ctx, hipSetDevice(ctx->hip_device));
         ctx->host_coalesced_calls++;

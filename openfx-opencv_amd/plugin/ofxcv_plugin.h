@@ -184,14 +184,16 @@ struct ImageGuard {
 class ThreadContext {
   public:
     static constexpr int kMaxDevices = 64;
-    // (one hipGetDeviceCount + getenv per process, not per render; re-read after OfxActionUnload)
+    // (the runtime is asked once -- hipGetDeviceCount is the expensive part -- and again only when OFXCV_VIRTUAL_DEVICES has changed or after OfxActionUnload)
     static int device_count() {
-        int n = cached_count().load(std::memory_order_relaxed);
-        if (n < 0) {
-            n = ofxcv_device_count();
-            cached_count().store(n, std::memory_order_relaxed);
+        const char *e = std::getenv("OFXCV_VIRTUAL_DEVICES");
+        std::lock_guard<std::mutex> lock(count_mu());
+        CountCache &c = count_cache();
+        if (c.n < 0 || c.env != (e ? e : "")) {
+            c.n = ofxcv_device_count();
+            c.env = e ? e : "";
         }
-        return n;
+        return c.n;
     }
     // the device of a named frame time: blocks of OFXCV_FRAMES_PER_DEVICE (default 16) consecutive frames per device, round-robin
     static int device_for_time(double time) {
@@ -265,7 +267,10 @@ class ThreadContext {
             }
             p.idle.clear();
         }
-        cached_count().store(-1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lock(count_mu());
+            count_cache().n = -1;
+        }
     }
 
   private:
@@ -277,10 +282,12 @@ class ThreadContext {
         static Pool *pools = new Pool[kMaxDevices];  // intentionally leaked: no static destructor runs while a host unloads the plugin
         return pools[device];
     }
-    static std::atomic<int> &cached_count() {
-        static std::atomic<int> v{-1};
-        return v;
-    }
+    struct CountCache {
+        int n = -1;
+        std::string env;
+    };
+    static CountCache &count_cache() { static CountCache *c = new CountCache(); return *c; }
+    static std::mutex &count_mu() { static std::mutex *m = new std::mutex(); return *m; }
 };
 
 inline void check_hip(ofxcv_ctx *ctx, int rc) {

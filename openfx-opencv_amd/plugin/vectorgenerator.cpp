@@ -67,7 +67,6 @@ struct InstanceData {
     OfxImageClipHandle dstClip = nullptr, srcClip = nullptr;
     OfxParamHandle channel[4] = {nullptr, nullptr, nullptr, nullptr};
     OfxParamHandle method = nullptr, levels = nullptr, iterations = nullptr, neighborhood = nullptr, sigma = nullptr;
-    std::atomic<bool> warned_direct{false};  // the notice that OFXCV_FARNEBACK_WINDOW=direct leaves the reference's 1e-4 band has been logged
     OfxParamSetHandle params = nullptr;
 };
 
@@ -291,16 +290,6 @@ OfxStatus render(OfxImageEffectHandle effect, OfxPropertySetHandle inArgs, OfxPr
         fail_with_message(effect, "VectorGenerator: only the Farneback method is implemented by the MI355X back-end");
     const int levels = get_int(d->levels, time), iterations = get_int(d->iterations, time), poly_n = get_int(d->neighborhood, time);
     const double poly_sigma = get_double(d->sigma, time);
-    // OFXCV_FARNEBACK_WINDOW=direct (a user's opt-in through the environment: each 3x3 window summed on its own) is not the reference's arithmetic:
-    // said once per instance through the message suite, as the segment plugin does for its substitution
-    if ((forward || backward) && g.message && !d->warned_direct.load(std::memory_order_relaxed)) {
-        const char *e = std::getenv("OFXCV_FARNEBACK_WINDOW");
-        if (e && !std::strcmp(e, "direct") && !d->warned_direct.exchange(true))
-            g.message->message(effect, kOfxMessageLog, "ofxcv.vectorgenerator.direct_window",
-                               "VectorGenerator: OFXCV_FARNEBACK_WINDOW=direct sums each 3x3 window directly; a few ill-conditioned pixels (6e-5 of the samples at "
-                               "1920x1080, 6.5e-4 at 3840x2160, errors up to pixels) then differ from OpenCV's result by more than 1e-4. Unset it for the reference's arithmetic.");
-    }
-
     // both directions over the whole reference frame: one library call stages and converts the reference once and
     // overlaps the second frame pair with the first flow
     if (forward && backward) {

@@ -25,15 +25,19 @@ for case in range(ncases):
     if init:
         kw["flags"] = ofxcv.OPTFLOW_USE_INITIAL_FLOW
     halo = {"farneback.col": 0}
+    # farneback.halo_geom (test hook): low nibble the form, bits 4..6 the small form's wavefronts, bits 8.. the rows of a tall strip
+    hg = 0
     if rng.random() < 0.5:
-        halo["farneback.halo_geom"] = int(rng.integers(0, 4))
+        hg |= int(rng.integers(0, 4))
     if rng.random() < 0.3:
-        halo["farneback.halo_small"] = int(rng.choice([2, 3, 4, 5, 6]))
+        hg |= int(rng.choice([2, 3, 4, 5, 6])) << 4
     if rng.random() < 0.3:
-        halo["farneback.halo_strip"] = int(rng.choice([33, 35, 36, 65, 68, 71, 72]))
+        hg |= int(rng.choice([33, 35, 36, 65, 68, 71, 72])) << 8
+    if hg:
+        halo["farneback.halo_geom"] = hg
     if rng.random() < 0.2:
         halo["farneback.batch_mb"] = int(rng.choice([1, 8, 40]))
-    col = {"farneback.col_min": 1, "farneback.col_geom": int(rng.integers(0, 2)), "farneback.col_ring": int(rng.integers(0, 2))}
+    col = {"farneback.col_min": 1, "farneback.col_ring": int(rng.integers(0, 2))}
     base = rng.integers(0, 256, size=(h + 24, w + 24), dtype=np.uint8)
     blur = (base[:-2, :-2].astype(np.int32) + base[1:-1, 1:-1] + base[2:, 2:]) // 3
     pa = [torch.from_numpy(np.ascontiguousarray(blur[i:i + h, i:i + w]).astype(np.uint8)).cuda() for i in range(n)]

@@ -58,7 +58,7 @@ def test_pyr_image_bit_exact(oracle, ofxcv, direct_ctx, w, h):
 def test_pyr_image_quarter_and_eighth_levels(oracle, ofxcv, w, h):
     """The coarse levels of the default pyramid (exactly 1/4 and 1/8 of the frame, 9 / 19 taps) take pyr_fused_al_kernel (aligned
     dword staging, both filtered columns of an output column from one byte run): bit-identical to the oracle and to the
-    byte-wise tile kernel (option farneback.pyr_bytewise), with partial tiles, reflected edges on all four sides, and a source whose
+    byte-wise tile kernel (option farneback.fused_pyramid 2), with partial tiles, reflected edges on all four sides, and a source whose
     rows are not dword-aligned (which must fall back by itself)."""
     import torch
     ga, _ = _gray_pair(oracle, w, h)
@@ -68,11 +68,11 @@ def test_pyr_image_quarter_and_eighth_levels(oracle, ofxcv, w, h):
             lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
             assert (w, h) == (lw << k, lh << k) and ks == (9, 19)[k - 2]
             ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
-            ctx.set_option("farneback.pyr_bytewise", 0)
+            ctx.set_option("farneback.fused_pyramid", 1)
             got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
-            ctx.set_option("farneback.pyr_bytewise", 1)
+            ctx.set_option("farneback.fused_pyramid", 2)
             other = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
-            ctx.set_option("farneback.pyr_bytewise", 0)
+            ctx.set_option("farneback.fused_pyramid", 1)
             padded = torch.zeros((h, w + 3), dtype=torch.uint8, device="cuda")  # row step w + 3: not a multiple of 4
             padded[:, :w] = _dev(ga)
             odd = ctx.farneback_pyr_image(padded[:, :w], lw, lh, sigma, ks).cpu().numpy()
@@ -86,7 +86,7 @@ def test_pyr_image_quarter_and_eighth_levels(oracle, ofxcv, w, h):
 def test_pyr_image_three_tap_levels_wavefront_rows(oracle, ofxcv, w, h):
     """Levels 0 and 1 of the default pyramid (3 taps; same size / exactly half) on frames whose width is a multiple of four take
     pyr_direct3w_kernel (one dword per lane and source row, the neighbour bytes from the neighbour lanes, several output rows per wavefront):
-    bit-identical to the oracle and to the one-group-per-lane kernel (option farneback.pyr_rows 0) -- tile seams at 248 columns, both image
+    bit-identical to the oracle and to the one-group-per-lane kernel (option farneback.fused_pyramid 3) -- tile seams at 248 columns, both image
     edges inside one wavefront, heights that end inside a wavefront's rows -- with the filter contraction and resize generations on as well."""
     ga, _ = _gray_pair(oracle, w, h)
     ctx = ofxcv.Context(0)
@@ -101,9 +101,9 @@ def test_pyr_image_three_tap_levels_wavefront_rows(oracle, ofxcv, w, h):
                     continue
                 lw, lh, sigma, ks = ofxcv.farneback_level_geom(w, h, 0.5, k)
                 ref = oracle.farneback_pyr_image(ga, lw, lh, sigma, ks)
-                ctx.set_option("farneback.pyr_rows", 1)
+                ctx.set_option("farneback.fused_pyramid", 1)
                 got = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
-                ctx.set_option("farneback.pyr_rows", 0)
+                ctx.set_option("farneback.fused_pyramid", 3)
                 other = ctx.farneback_pyr_image(_dev(ga), lw, lh, sigma, ks).cpu().numpy()
                 assert np.array_equal(ref, got), "level %d (fc %d, resize %d) max diff %g" % (k, fc, rz, np.abs(ref - got).max())
                 assert np.array_equal(ref, other)
@@ -361,11 +361,10 @@ def test_gray_lut_and_scatter(oracle, ofxcv, direct_ctx):
     # widths that are a multiple of four take the four-pixels-per-lane kernel (53 above does not): both against the oracle
     wide = rng.uniform(-0.2, 1.3, size=(37, 256 + 52, 4)).astype(np.float32)
     wide[3, 5] = (np.nan, np.inf, -np.inf, 0)
-    one = ofxcv.Context(0)
-    one.set_option("lut.four", 0)
-    for c in (direct_ctx, one):
-        assert np.array_equal(c.to_byte_grayscale(_dev(wide)).cpu().numpy(), oracle.to_byte_grayscale(wide))
-    one.close()
+    assert np.array_equal(direct_ctx.to_byte_grayscale(_dev(wide)).cpu().numpy(), oracle.to_byte_grayscale(wide))
+    # ... and the same pixels through the one-pixel-per-lane kernel (a view whose rows are not 16-byte aligned) give the same bytes
+    shifted = _dev(np.concatenate([np.zeros((37, 1, 4), np.float32), wide], axis=1))[:, 1:]
+    assert shifted.data_ptr() % 16 == 0 and np.array_equal(direct_ctx.to_byte_grayscale(shifted[:, :-1].contiguous()).cpu().numpy(), oracle.to_byte_grayscale(wide[:, :-1]))
     flow = rng.normal(0, 3, size=(37, 53, 2)).astype(np.float32)
     for mu, mv, rs in [(0b0011, 0b1100, (1.0, 1.0)), (0b0001, 0b0010, (0.5, 0.25)), (0b0101, 0b0100, (1.0, 2.0)), (0, 0, (1.0, 1.0))]:
         base = rng.normal(size=(37, 53, 4)).astype(np.float32)
@@ -418,11 +417,12 @@ def test_opencv_order_mode_matches_faithful_oracle_everywhere(oracle, strict_ctx
 
 # the three evaluations of OpenCV's running sums the library has: mode 2 (serial column scan, the independent cross-check), the
 # overlapped-strip form and the column-owning form (farneback.col_min 1 forces it on every level of any frame)
-_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0), dict(col_min=1, col_geom=1), dict(col_min=1, col_geom=1, col_ring=0))
+_FORMS = (dict(opencv_rounding=2), dict(col=0), dict(col_min=1), dict(col_min=1, col_ring=0))
 # strip / wavefront geometries of the overlapped-strip form the library otherwise picks by level size
-_HALO_GEOMS = (dict(halo_geom=1), dict(halo_geom=2), dict(halo_geom=3), dict(halo_geom=2, halo_strip=33), dict(halo_geom=2, halo_strip=35),
-               dict(halo_geom=3, halo_strip=65), dict(halo_geom=3, halo_strip=67), dict(halo_geom=3, halo_strip=70), dict(halo_geom=3, halo_strip=72),
-               dict(halo_small=2), dict(halo_small=4), dict(halo_small=5), dict(halo_small=6), dict(halo_min5=1))
+# farneback.halo_geom (test hook): low nibble 1 small / 2 four tall / 3 eight tall wavefronts, bits 4..6 the small form's wavefronts, bits 8.. rows per tall strip
+_HG = lambda form=0, small=0, strip=0: dict(halo_geom=form | (small << 4) | (strip << 8))
+_HALO_GEOMS = (_HG(1), _HG(2), _HG(3), _HG(2, strip=33), _HG(2, strip=35), _HG(3, strip=65), _HG(3, strip=67), _HG(3, strip=70), _HG(3, strip=72),
+               _HG(1, small=2), _HG(1, small=4), _HG(1, small=5), _HG(1, small=6))
 
 
 def _flow_with(ofxcv, opts, ga, gb, *args, twice=False, **kw):
@@ -464,7 +464,7 @@ def test_opencv_order_mode_step_pairs_and_first_matrix_forms(oracle, ofxcv, w, h
                dict(iterations=5), dict(iterations=2, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW),
                dict(iterations=1, flags=ofxcv.OPTFLOW_USE_INITIAL_FLOW)):   # at level 0 the given flow and the result share a buffer (fuzz_halo.py, round 4)
         args = (init,) if "flags" in kw else ()
-        outs = [_flow_with(ofxcv, opts, ga, gb, *args, levels=levels, **kw) for opts in _FORMS + (dict(col=0, halo_geom=2), dict(col=0, halo_small=5))]
+        outs = [_flow_with(ofxcv, opts, ga, gb, *args, levels=levels, **kw) for opts in _FORMS + (dict(col=0, halo_geom=2), dict(col=0, **_HG(1, small=5)))]
         assert all(np.array_equal(outs[0], o) for o in outs[1:]), kw
     ref = oracle.calc_optical_flow_farneback(ga, gb, blur_mode=oracle.BLUR_FAITHFUL, levels=levels, iterations=3)
     got = _flow_with(ofxcv, dict(col_min=1), ga, gb, levels=levels, iterations=3)
@@ -784,10 +784,10 @@ def test_batch_shared_first_frame_and_every_window_mode(oracle, ofxcv):
     w, h = 333, 257
     (a, b), (_, c) = _pairs(oracle, w, h, (5, 6))
     da, db, dc = _dev(a), _dev(b), _dev(c)
-    cases = [dict(opts=dict(opencv_rounding=1)), dict(opts=dict(opencv_rounding=1, col_min=1)), dict(opts=dict(opencv_rounding=1, col_min=1, col_ring=0)), dict(opts=dict(opencv_rounding=1, col_min=1, col_geom=1)),
+    cases = [dict(opts=dict(opencv_rounding=1)), dict(opts=dict(opencv_rounding=1, col_min=1)), dict(opts=dict(opencv_rounding=1, col_min=1, col_ring=0)),
              dict(opts=dict(opencv_rounding=2)), dict(opts=dict(opencv_rounding=0)), dict(opts=dict(opencv_rounding=0), kw=dict(iterations=4)),
              dict(opts=dict(opencv_rounding=1), kw=dict(winsize=5)), dict(opts=dict(opencv_rounding=1), kw=dict(flags=ofxcv.OPTFLOW_FARNEBACK_GAUSSIAN, winsize=5)),
-             dict(opts=dict(opencv_rounding=1, halo_geom=2)), dict(opts=dict(opencv_rounding=1, halo_small=5))]
+             dict(opts=dict(opencv_rounding=1, halo_geom=2)), dict(opts=dict(opencv_rounding=1, **_HG(1, small=5)))]
     for case in cases:
         ctx = ofxcv.Context(0)
         for k, v in case["opts"].items():
@@ -817,7 +817,7 @@ def test_batch_launch_groups(oracle, ofxcv, mb):
     ctx.close()
 
 
-@pytest.mark.parametrize("opts", [dict(), dict(col_min=1), dict(col_min=1, col_ring=0), dict(opencv_rounding=0), dict(col_min=1, col_geom=1), dict(opencv_rounding=2)])
+@pytest.mark.parametrize("opts", [dict(), dict(col_min=1), dict(col_min=1, col_ring=0), dict(opencv_rounding=0), dict(opencv_rounding=2)])
 def test_flow_to_rgba_fused_into_the_call(oracle, ofxcv, opts):
     """ofxcv_calc_optical_flow_farneback_batch_rgba: F7 rides on the launch that produces the final flow (overlapped strips: the default for these
     small batches; column-owning form: col_min 1) or is appended by the library (other window modes) -- the RGBA images equal ofxcv_flow_to_rgba applied to the returned flows bit for bit: all
@@ -909,7 +909,7 @@ def test_deep_pyramid_and_two_pass_images_in_batches(oracle, ofxcv):
 
 def test_column_owning_form_for_part_of_a_batch(oracle, ofxcv):
     """One workgroup per tile column and pair, one workgroup per CU: the pairs of a call that would start another round of the
-    chip keep the overlapped strips (farneback.col_split; a 1921-pixel-wide frame has 33 tile columns: 7 pairs fill the 256 CUs,
+    chip keep the overlapped strips (a 1921-pixel-wide frame has 33 tile columns: 7 pairs fill the 256 CUs,
     the eighth does not).  With the column-owning form forced from 3 workgroups on a small frame (6 tile columns) the split is
     driven through the same plan: whatever mix of forms a batch is walked in, every pair equals its single call bit for bit."""
     w, h, n = 333, 257, 7
@@ -918,7 +918,7 @@ def test_column_owning_form_for_part_of_a_batch(oracle, ofxcv):
     single = ofxcv.Context(0)
     singles = [single.calc_optical_flow_farneback(x, y, iterations=4).cpu().numpy() for x, y in zip(da, db)]
     single.close()
-    for opts in (dict(col_min=1), dict(col_min=1, col_split=0), dict(col_min=12), dict(col_min=30), dict(col_min=36), dict(col=0)):
+    for opts in (dict(col_min=1), dict(col_min=12), dict(col_min=30), dict(col_min=36), dict(col=0)):
         c = ofxcv.Context(0)
         for k, v in opts.items():
             c.set_option("farneback." + k, v)

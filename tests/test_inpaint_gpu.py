@@ -334,32 +334,3 @@ def test_parallel_front_march_option_gives_the_same_maps_and_colours(oracle, ofx
         assert np.array_equal(a, b)
     ref = oracle.inpaint_render(fr, 3.0, 1.0)
     assert np.array_equal(outs[1][0][..., :3], ref[..., :3])
-
-
-def test_dynamic_grab_option_gives_the_same_colours(oracle, ofxcv):
-    """option inpaint.dynamic_grab: the wavefronts of a tile take its next pixel from an LDS counter instead of every 16th in
-    fill order.  The grab loop that never returned in rounds 2 and 4 terminates (pixels are handed out in ascending order; the counter's result is
-    broadcast from lane 0 with the other lanes' value defined) and the colours are the static schedule's and the oracle's -- at three sizes, both
-    methods; it is off by default because it buys nothing (profiles/r05_experiments.md)."""
-    import torch
-    from openfx_opencv_amd import synth
-    for (w, h) in ((64, 48), (333, 257), (640, 480)):
-        fr = synth.inpaint_frame(w, h)
-        d = torch.from_numpy(fr).cuda()
-        outs = []
-        for dyn in (0, 1):
-            c = ofxcv.Context(0)
-            c.set_option("inpaint.dynamic_grab", dyn)
-            m = c.inpaint_mask(d, 1)
-            res = []
-            for method in (ofxcv.INPAINT_TELEA, ofxcv.INPAINT_NS):
-                for _ in range(2):
-                    dst = c.inpaint(d, m, 3.0, method)
-                torch.cuda.synchronize()
-                res.append(dst.cpu().numpy())
-            assert c.inpaint_fallback_count() == 0
-            outs.append(res)
-            c.close()
-        for a, b in zip(outs[0], outs[1]):
-            assert np.array_equal(a, b), (w, h)
-        assert np.array_equal(outs[1][0][..., :3], oracle.inpaint_render(fr, 3.0, 1.0)[..., :3])

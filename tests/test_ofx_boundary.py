@@ -354,28 +354,6 @@ def test_vectorgenerator_render_through_ofx(host, oracle):
 
 
 @pytest.mark.gpu
-def test_vectorgenerator_direct_window_opt_in_is_announced(host, monkeypatch):
-    """OFXCV_FARNEBACK_WINDOW=direct lets a plugin user leave the reference's arithmetic (direct window sums): the plugin says so once per
-    instance through the message suite -- and says nothing without the variable."""
-    from openfx_opencv_amd import synth
-    w, h = 160, 96
-    seq = [synth.flow_pair(w, h, seed=60 + i)[0].copy() for i in range(3)]
-    pl = Plugin(host, "VectorGenerator")
-    for env, expect in ((None, False), ("direct", True)):
-        if env:
-            monkeypatch.setenv("OFXCV_FARNEBACK_WINDOW", env)
-        inst = pl.instance()
-        out = np.zeros((h, w, 4), np.float32)
-        for u in range(3):
-            pl.set_image(inst, "Source", float(u), seq[u], "OfxBitDepthFloat")
-        pl.set_image(inst, "Output", 1.0, out, "OfxBitDepthFloat")
-        assert pl.render(inst, 1.0, w, h) == STAT_OK
-        assert (b"OFXCV_FARNEBACK_WINDOW=direct" in host.mh_last_message(inst)) == expect
-        pl.destroy(inst)
-    monkeypatch.delenv("OFXCV_FARNEBACK_WINDOW")
-
-
-@pytest.mark.gpu
 def test_vectorgenerator_named_frames_follow_their_block_across_devices(host, monkeypatch):
     """with several devices the plugin sends BLOCKS of 16 consecutive frame times to one device when the host names its
     images (a named frame stays on the device it was uploaded to), instead of whatever device the calling thread happens to own.  Two logical
