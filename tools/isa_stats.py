@@ -6,8 +6,8 @@ The assembly is produced with the library's own flags (openfx-opencv_amd/Makefil
 import argparse, collections, os, re, subprocess, sys
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--src", default="csrc/farneback.hip")
-ap.add_argument("--asm", default="/tmp/isa/farneback.s")
+ap.add_argument("--src", default="csrc/fb_column.hip")
+ap.add_argument("--asm", default="/tmp/isa/fb_column.s")
 ap.add_argument("--rebuild", action="store_true")
 ap.add_argument("--dump")
 ap.add_argument("--top", type=int, default=40)
