@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Column-owning form (iterate_col_kernel) against the overlapped-strip form: bit-identity of the flows on a few sizes, batches and
-iteration counts, and the abort word.  usage: python tools/col_check.py [geom ...]"""
+iteration counts, and the abort word.  usage: python tools/col_check.py [ring ...]     (ring: 1 = R1 from the LDS ring, 0 = every gather from memory)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -14,7 +14,7 @@ if "--opts" in argv:  # further options of the tested context: --opts k=v,k=v
     i = argv.index("--opts")
     extra = [kv.split("=") for kv in argv[i + 1].split(",") if kv]
     del argv[i:i + 2]
-geoms = [int(v) for v in argv] or [0, 1]
+geoms = [int(v) for v in argv] or [1, 0]
 cases = [(333, 257, 2, dict()), (640, 480, 1, dict()), (125, 70, 3, dict(levels=1)), (640, 480, 2, dict(iterations=4)), (640, 480, 1, dict(iterations=1)),
          (200, 150, 1, dict(iterations=2, levels=0)), (1920, 1080, 2, dict()), (61, 131, 1, dict(levels=0)), (60, 64, 1, dict(levels=0)), (59, 300, 1, dict(levels=1))]
 bad = 0
@@ -30,7 +30,7 @@ for w, h, n, kw in cases:
         c = ofxcv.Context(0)
         c.set_option("farneback.col", 1)
         c.set_option("farneback.col_min", 1)
-        c.set_option("farneback.col_geom", g)
+        c.set_option("farneback.col_ring", g)
         for k_, v_ in extra:
             c.set_option(k_, int(v_))
         got = [f.cpu().numpy() for f in c.calc_optical_flow_farneback_batch(ga, gb, **kw)]
