@@ -40,7 +40,7 @@ VALU_CLK_PER_WAVE_INSTR = 4.0
 VALU_ISSUE_PER_S = 1024 * 2.4e9 / VALU_CLK_PER_WAVE_INSTR
 # one iteration = M-in 20 + R0 20 + R1 gather 20 + M-out 20 bytes per pixel
 ITER_BYTES_PER_PX = 80.0
-PMC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc_traffic.json")
 COL_W = 60  # columns a workgroup of iterate_col_kernel stores (csrc/farneback.hip: kColW)
 
 
@@ -496,7 +496,7 @@ def main():
                                                             "(`frac` of rounds 1-4; 0.81 in round 4).  Not what the fused launch moves: side key only"},
                      "avg_launch_us": main_s * 1e6, "launches_timed": main_n,
                      "timing": "HIP event pairs on the launch stream, one batched call in flight; the pairs include the dependent-launch gap -- the rocprofv3 "
-                               "durations of the same launches are in profiles/r05_bench_default_by_grid.txt",
+                               "durations of the same launches are in profiles/r06_bench_default_by_grid.txt",
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_note": "L2 <-> fabric bytes per launch (TCC_EA0 read requests x their size + write requests); Infinity-Cache hits are counted",

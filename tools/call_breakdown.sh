@@ -13,7 +13,7 @@ for f in glob.glob("/tmp/call_bd/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def nm(r):
-    return re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))[:52]
+    return re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))[:52]
 # a step begins with its first gray LUT after a non-LUT kernel
 steps, cur, prev_lut = [], [], False
 for r in rows:

@@ -6,7 +6,7 @@ d = sys.argv[1]; skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.3
 ev = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), n[:40], r.get("Grid_Size_Z", "")))
 ev.sort()
 t_lo = ev[0][0] + (ev[-1][1] - ev[0][0]) * skip

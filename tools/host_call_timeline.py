@@ -7,7 +7,7 @@ d = sys.argv[1]; ncalls = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ev = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+        n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K " + n[:40]))
 for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):

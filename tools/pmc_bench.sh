@@ -14,7 +14,7 @@ python - $CALLS $BATCH <<'PY'
 import csv, glob, collections, os, re, sys
 out = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_bench"
 def name_of(r):
-    return re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))[:44]
+    return re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))[:44]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob("/tmp/pmc_bench_raw/p*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):

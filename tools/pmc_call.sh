@@ -17,7 +17,7 @@ import csv, glob, collections, re, sys
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob(sys.argv[1] + "/p*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+        name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))
         key = (name[:40], r["Grid_Size"], r["Counter_Name"])
         agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
 with open(sys.argv[2], "w") as fo:

@@ -11,7 +11,7 @@ ap.add_argument("--pairs", type=int, default=8)
 args = ap.parse_args()
 rows = []
 for r in csv.DictReader(open(args.csv)):
-    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))
     gx, gy, gz, wx = (int(r.get(k, 1) or 1) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z", "Workgroup_Size_X"))
     wy, wz = (int(r.get(k, 1) or 1) for k in ("Workgroup_Size_Y", "Workgroup_Size_Z"))
     wgs = (gx // max(1, wx)) * (gy // max(1, wy)) * (gz // max(1, wz))

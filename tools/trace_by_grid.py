@@ -3,7 +3,7 @@
 import csv, sys, re, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
-    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", ""))
+    n = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").replace("void ofxcv_fb::", "").replace("ofxcv_fb::", ""))
     # threads in x, workgroups in y, pairs of the batched call (grid z), threads per workgroup
     g = "%sx%sx%s/%s" % (r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""), r.get("Workgroup_Size_X", ""))
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
