@@ -54,84 +54,77 @@ void *ofxcv_ctx_stream(const ofxcv_ctx *ctx);
  * column-owning Farneback kernel ever ran out on this context (its flows are then not valid; never observed) */
 int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
 
-/* context options:
+/* context options (25; unknown names and values outside an option's range are rejected with OFXCV_ERR_INVALID):
+ * -- what the results are --
  *   "farneback.opencv_rounding" 1|0|2 how the 3x3 box window of FarnebackUpdateFlow_Blur is evaluated.
- *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical
- *                                      row difference is added after being rounded to f32 -- evaluated strip-parallel: per level
- *                                      the pairs of the call that fill whole rounds of the chip (one workgroup per tile column
- *                                      and pair; ofxcv_farneback_col_pairs) by column-owning workgroups that run TWO iterations
- *                                      per launch (iterate_col_kernel), the others by overlapped strips, one launch per iteration
- *                                      (iterate3h_kernel).
- *                                      Reproduces the reference's rounding noise: every sample within 1e-4 (relative) of
- *                                      the CPU result.
- *                                    0: direct sums (each window summed on its own in f64, two iterations fused per launch):
- *                                      faster for single calls, but at ill-conditioned pixels (6e-5 of the samples at 1920x1080,
- *                                      6e-4 at 3840x2160) the result leaves the 1e-4 band around the reference's.
- *                                      Also selected by the environment variable OFXCV_FARNEBACK_WINDOW=direct.
+ *                                    1 (default): OpenCV's own order -- a running column sum in f64 to which every vertical row difference is
+ *                                      added after being rounded to f32 -- evaluated strip-parallel: per level the pairs of the call that fill
+ *                                      whole rounds of the chip (one workgroup per tile column and pair; ofxcv_farneback_col_pairs) by
+ *                                      column-owning workgroups that run TWO iterations per launch (iterate_col_kernel), the others by
+ *                                      overlapped strips, one launch per iteration (iterate3h_kernel).  Every sample within 1e-4 (relative)
+ *                                      of the CPU result.
+ *                                    0: direct sums (each window summed on its own in f64): at ill-conditioned pixels (6e-5 of the samples at
+ *                                      1920x1080, 6e-4 at 3840x2160) the result leaves the 1e-4 band around the reference's.
  *                                    2: OpenCV's order as a serial one-thread-per-column scan (cross-check only, slow).
  *                                    Window sizes other than the reference's 3 always use direct sums.
+ *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x (taps cast
+ *                                    to float before they are normalised), 4 = 4.x (normalised in double, one cast);
+ *   "farneback.filter_contraction" 0|1   0 (default) product and sum of a filter tap rounded separately (2.4 / 3.x, scalar builds), 1 = fused
+ *                                    multiply-adds (the AVX2 / NEON paths of OpenCV 4.x): pyramid images and the flow prolongation;
+ *   "farneback.resize_generation" 0|1|2   association of the 2x2 mean cv::resize(INTER_LINEAR) takes at an exact 2x reduction: 0 (default)
+ *                                    ((a+b)+(c+d))/4 = bilinear = 4.x SIMD, 1 (((a+b)+c)+d)/4 scalar loop (2.4.x), 2 ((a+c)+(b+d))/4 3.x SSE2;
+ *   "lut.luma"                 709|601  luma weights of the gray conversion (supportext's source is not in the reference tree);
+ * -- how a Farneback call is planned and launched (never changes a result) --
+ *   "farneback.graph"           0|1  0 (default): the launches of a call are enqueued one by one (0.3 ms of host time for a call of 8 pairs at
+ *                                    1920x1080; no runtime lock held); 1: captured once into a hipGraph and replayed with one hipGraphLaunch under
+ *                                    the process-wide runtime lock (the default of rounds 1-5; same speed);
  *   "farneback.col"             0|1  the column-owning form on the levels that qualify (default 1);
  *   "farneback.col_min"         n    workgroups (tile columns of 60 pixels x pairs) below which no launch takes it (128; from there on a cost
  *                                    model in rounds of the chip decides how many pairs do; smaller values force the form: tests);
- *   "farneback.col_split"       0|1  the pairs that would start another round of the chip keep the overlapped strips (1) / all or none (0);
- *   "farneback.batch_mb"        MiB  the other levels are walked with as many pairs per launch as keep the level's working set
- *                                    under this (160: the Infinity Cache holds 256 MiB);
- *   "farneback.gaussian_kernel_generation" 3|4   which cv::getGaussianKernel the pyramid blur follows: 3 (default) OpenCV 2.4 / 3.x
- *                                    (taps cast to float before they are normalised), 4 = 4.x (normalised in double, one cast):
- *                                    two taps of the 9- and 19-tap kernels differ by one ulp;
- *   "farneback.filter_contraction" 0|1   OpenCV 4.x runs GaussianBlur's separable filters and resize's vertical lerp through universal-intrinsics
- *                      code (AVX2 / NEON) whose taps are fused multiply-adds; 2.4 / 3.x and builds without it round product and sum separately.
- *                      0 (default) = separate roundings, 1 = fused (pyramid images and the flow prolongation; optflowgf.cpp itself is plain C++).
- *   "farneback.resize_generation" 0|1|2   cv::resize(INTER_LINEAR) rewrites itself to INTER_AREA when the level is exactly half the
- *                                    frame in both directions; the 2x2 mean it then takes differs from the bilinear form only in the
- *                                    association of three float additions: 0 (default) ((a+b)+(c+d))/4 = bilinear = the 4.x SIMD path,
- *                                    1 (((a+b)+c)+d)/4 = the scalar loop (2.4.x, builds without SIMD), 2 ((a+c)+(b+d))/4 = the 3.x SSE2 path;
- *   "lut.four"                  0|1  gray LUT with four pixels per lane where the images are aligned for it (default 1);
- *   "farneback.graph"           0|1  0 (default): the launches of a call are enqueued one by one (0.3 ms of host time for a call of 8 pairs at 1920x1080; no
- *                                    runtime lock held); 1: captured once into a hipGraph and replayed with one hipGraphLaunch under the process-wide runtime
- *                                    lock (the default of rounds 1-5; same speed, but the lock bounds a host process that drives several GPUs);
- *   "farneback.fuse_iterations" 0|1  direct-window mode: two iterations per launch through LDS (default 1);
- *   "farneback.prep_stream"     0|1  pyramid + polynomial expansion of all levels on a second stream (default 1);
- *   "farneback.fused_pyramid"   0|1  LDS-fused / direct pyramid kernels (default 1; 0 = the two-pass kernels);
+ *   "farneback.col_ring"        0|1  that form gathers the second frame's expansion from a ring of rows in LDS (1, default) or from memory (0);
+ *   "farneback.col_spin"        n    polls of one of its LDS waits before the kernel raises the abort word (2^22);
+ *   "farneback.col_trace"       0|1  its (iterate, iterate) launches stamp the shader clock per phase (tools/col_trace.py);
+ *   "farneback.batch_mb"        MiB  the strip-form levels are walked with as many pairs per launch as keep the level's working set under this
+ *                                    (160: the Infinity Cache holds 256 MiB);
+ *   "farneback.halo_geom"       n    test hook: geometry of the overlapped-strip form instead of the choice by level size (encoding: fb_strips.hip);
+ *   "farneback.fused_pyramid"   0..3 1 (default) LDS-fused / direct pyramid kernels, 0 the two-pass kernels; test hooks: 2 the coarse levels by the
+ *                                    byte-wise tile kernel, 3 the 3-tap levels without the wavefront-row form;
+ * -- host images --
  *   "host.register"           0|1|2  how ofxcv_vectorgen_flow(s)_host moves host images: 1 (default) asynchronous copies straight from / into
  *                                    the host's pageable images; 2 the host's buffers registered (hipHostRegister) for the duration of the
  *                                    call when all four channels are mapped; 0 staged through a pinned ring (what bottom-up images always get);
- *   "host.split"              0|1|2  ofxcv_vectorgen_flows_host with two directions: 0 one batched Farneback call after the third upload; 1 two
- *                                    single-pair calls, the first while the third frame is still on the wire; 2 (default) 1 while this is the
- *                                    only host-image call in flight in the process, else 0 (several render threads keep the link busy anyway);
+ *   "host.split"              0|1|2  two directions: 0 one batched Farneback call after the third upload; 1 two single-pair calls, the first
+ *                                    while the third frame is still on the wire; 2 (default) 1 while this is the only host-image call in
+ *                                    flight on the device, else 0;
  *   "host.cache_mb"           n      budget of the device's cache of named frames (ofxcv_vectorgen_flows_host_keyed), default 512, 0 = off;
- *   "host.coalesce"           0|1|2  host-image calls of several render threads on one device (the reference is eRenderFullySafe, VectorGenerator.cpp:108):
- *                                    1 (default) a call that finds "host.coalesce_min" (3) host-image calls in flight on its device, itself included, hands
- *                                    its frame pairs to the device's submission queue; the first caller that finds no coalesced call running runs everything
- *                                    queued as ONE batched Farneback call (its own pairs at once when nothing else is queued), the callers download their own
- *                                    images.  0 every call runs its own; 2 every call goes through the queue (tests).  Same results bit for bit.
+ *   "host.coalesce"           0|1|2  host-image calls of several render threads on one device (the reference is eRenderFullySafe,
+ *                                    VectorGenerator.cpp:108): 1 (default) a call that finds "host.coalesce_min" (3) host-image calls in flight on
+ *                                    its device, itself included, hands its frame pairs to the device's submission queue; the first caller that
+ *                                    finds no coalesced call running runs everything queued as ONE batched Farneback call, the callers download
+ *                                    their own images.  0 every call runs its own; 2 every call goes through the queue (tests).  Same results.
  *   "host.coalesce_max"       n      frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip in the
  *                                    column-owning form of level 0: 8 pairs at 1920x1080, 4 at 3840x2160;
- *   "host.coalesce_depth"     1..4   coalesced calls in flight per device: 1 (default) the next one is formed when the running one has finished,
- *                                    n > 1: up to n beside each other (measured slower from 4 render threads on: the calls get smaller);
- *   "host.coalesce_eager"     0|1    the queue's batched call is launched kernel by kernel (1, default: no runtime lock held, the first kernels run while
- *                                    the rest is enqueued) or replayed from a captured hipGraph (0);
- *   "inpaint.portion" n, "inpaint.pixels_per_workgroup" n, "inpaint.max_workgroups" n   fill-order pixels per portion of the
- *                                    pipelined fill (8192), per workgroup of a component (256), workgroups per component and portion (8);
- *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share
- *                                    of the chip: 192 over the fills in flight, at least 48);
- *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back.
- * Unknown names and values outside an option's range are rejected with OFXCV_ERR_INVALID.  (Geometry hooks of the two strip-parallel
- * kernels used by the tests -- "farneback.halo_*", "farneback.col_geom", "farneback.col_trace" -- are listed in csrc/common.h; they select
- * forms the library otherwise picks by level size and never change a result.) */
+ *   "host.coalesce_min"       n      see host.coalesce (default 3);
+ * -- inpaint --
+ *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share of the
+ *                                    chip: 192 over the fills in flight, at least 48);
+ *   "inpaint.portion" n              fill-order pixels per portion of the pipelined fill (0 = 8192);
+ *   "inpaint.spin_limit" n           polls per awaited colour in the dataflow fill before the barrier-scheduled fall-back (-1 = 2^21);
+ *   "inpaint.parallel_march" n       0 (default) serial front march; n > 0 the hole's 4-connected components marched side by side on host threads
+ *                                    and merged into the exact fill order (1: from 8192 hole pixels; n > 1: from n).  Same maps; slower per call. */
 int ofxcv_ctx_set_option(ofxcv_ctx *ctx, const char *name, int value);
-/* current value of "farneback.opencv_rounding", "farneback.graph", "farneback.fuse_iterations", "host.register", "host.split",
- * "host.split_calls" (host-image calls that took the split form), "farneback.batch_mb",
- * "farneback.col", "farneback.col_min", "farneback.gaussian_kernel_generation", "farneback.resize_generation", and "farneback.col_aborts":
- * 1 if a bounded wait inside iterate_col_kernel ever ran out (waits for the context's streams: a test hook) */
+/* current value of "farneback.opencv_rounding", "farneback.gaussian_kernel_generation", "farneback.resize_generation", "farneback.filter_contraction",
+ * "lut.luma", "farneback.graph", "farneback.batch_mb", "farneback.col", "farneback.col_min", "host.register", "host.split", "host.cache_mb",
+ * "host.coalesce", and two counters: "host.split_calls" (host-image calls that took the split form), "farneback.col_aborts" (1 if a bounded wait
+ * inside iterate_col_kernel ever ran out; waits for the context's streams: a test hook) */
 int ofxcv_ctx_get_option(const ofxcv_ctx *ctx, const char *name, int *value);
 
 /* ---- measurement hook (bench.py's roofline leg) ---------------------------------------------
  * While enabled (enable = 1), the Farneback calls bracket every launch of the dominant kernel at pyramid level 0 with a hipEvent
- * pair on the stream it is launched on: OpenCV-order mode -- the (iterate, iterate) launches of iterate_col_kernel (two iterations of
- * every pair of the call) where level 0 takes the column-owning form, otherwise the iterating launches of iterate3h_kernel (one
- * iteration); direct-window mode -- the fused two-iteration kernel iterate3x2_kernel.  ofxcv_profile_read synchronises, adds up the
- * pairs and returns the total kernel time and the number of launches since the last reset. */
+ * pair on the stream it is launched on: the (iterate, iterate) launches of iterate_col_kernel (two iterations of every pair of the call) where
+ * level 0 takes the column-owning form, otherwise the iterating launches of iterate3h_kernel (one iteration); in the other window modes the
+ * iterating launches of the generic kernels.  ofxcv_profile_read synchronises, adds up the pairs and returns the total kernel time and the
+ * number of launches since the last reset. */
 int ofxcv_profile_enable(ofxcv_ctx *ctx, int enable);
 int ofxcv_profile_read(ofxcv_ctx *ctx, double *total_ms, long *launches, int reset);
 
