@@ -334,16 +334,17 @@ __global__ __launch_bounds__(256) void flows_to_rgba_kernel(const float2 *__rest
 // ---- concurrent host-image calls of one device, coalesced into ONE batched Farneback call ----
 // VectorGenerator is eRenderFullySafe with host frame threading off (VectorGenerator.cpp:108, GenericOpenCVPlugin.cpp:350-357): a host renders
 // several output frames at once, each render() on its own thread with its own context.  Left alone, every thread submits its own call of two
-// pairs, and the GPU runs 2-pair calls (<= 1 115 pairs/s at 1920x1080) where one call of 8 pairs reaches 1 660: the coarse levels are
-// latency-bound and level 0 only takes the column-owning form (two iterations per launch) from 6 pairs on.  So a call that finds another
-// host-image call in flight on its device does not start a Farneback call of its own: it uploads and converts its frames as ever, waits for
-// them, and hands its pairs to the device's SUBMISSION QUEUE.  The first caller that finds no coalesced call running becomes the leader: it
-// takes everything queued with its own geometry and parameters (its own pairs at once when it is alone: no added latency), gathers the gray
-// frames into the slots of the device's batch context (one launch; the slots keep the pointers of the captured launch sequence fixed), runs ONE
-// batched Farneback call there, composes every caller's RGBA image (or copies its flows back) on the same stream, waits, and wakes the callers,
-// who download their own images.  Callers that arrive while a call runs queue up and ride in the next one.  All ordering between contexts goes
-// through the host (the callers' frames are complete before they queue, the batch is complete before they are woken): no cross-context events.
-// Results are those of the callers' own calls bit for bit (a batch is bit-identical to its single calls).
+// pairs, and from five threads on the GPU runs many 2-pair calls beside each other (1 000 - 1 120 pairs/s at 1920x1080) where calls of 8 pairs
+// reach 1 700: level 0 only takes the column-owning form (two iterations per launch) from 6 pairs on.  So a call that finds host.coalesce_min (3)
+// host-image calls in flight on its device, itself included, does not start a Farneback call of its own: it uploads and converts its frames as
+// ever, records an event behind the last conversion and hands its pairs to the device's SUBMISSION QUEUE.  The first caller that finds no
+// coalesced call running becomes the leader: it takes everything queued with its geometry and parameters, up to one round of the chip (its own
+// pairs at once when nothing else is queued), makes the batch context's stream wait for the riders' events and runs ONE batched Farneback call
+// there -- launched kernel by kernel, reading the riders' gray frames and writing their flow fields and RGBA images (F7 inside the call) in
+// place -- then makes every rider's stream wait for the call's event and releases the riders, who enqueue their own downloads behind it.  The
+// leader keeps the slot until the call has completed: what arrives meanwhile rides in the next one.  All ordering is on the device; a host
+// thread only ever waits for its own stream (and the leader for its call).  Results are those of the callers' own calls bit for bit (a batch is
+// bit-identical to its single calls).
 namespace {
 // measurement aid (environment OFXCV_HOST_TRACE=1; tools/host_queue_trace.py): per host-image call the times of its phases in microseconds since the
 // first traced call -- entry, frames enqueued, frames complete (= queued), its batched call started / finished, the caller woke up, image downloaded --
@@ -362,10 +363,10 @@ struct HostTrace {
 };
 struct FlowSig {  // what two requests must share to ride in one call
     int w, h, levels, iterations, poly_n, rounding, gauss_gen, contraction, resize_gen;
-    double poly_sigma;
+    double poly_sigma, rsx, rsy;  // (the render scale: one per batched call -- the F7 pixels are written inside it)
     bool operator==(const FlowSig &o) const {
         return w == o.w && h == o.h && levels == o.levels && iterations == o.iterations && poly_n == o.poly_n && rounding == o.rounding &&
-               gauss_gen == o.gauss_gen && contraction == o.contraction && resize_gen == o.resize_gen && poly_sigma == o.poly_sigma;
+               gauss_gen == o.gauss_gen && contraction == o.contraction && resize_gen == o.resize_gen && poly_sigma == o.poly_sigma && rsx == o.rsx && rsy == o.rsy;
     }
 };
 struct BatchStatus {  // shared by the requests of one batched call: set by the leader once the call has completed
@@ -377,10 +378,9 @@ struct FlowReq {
     const uint8_t *gray[3] = {nullptr, nullptr, nullptr};  // device, rows gray_pitch apart; complete once `ready` has fired
     hipEvent_t ready = nullptr;   // recorded on the caller's compute stream behind its last conversion
     hipStream_t stream = nullptr; // the caller's compute stream: the leader makes it wait for the batched call
-    float *d_rgba = nullptr;  // all four channels mapped: the leader composes the image here (rows width * 16 bytes) ...
+    float *d_flow[2] = {nullptr, nullptr};  // where the call writes the flows (the caller's own buffers)
+    float *d_rgba = nullptr;  // all four channels mapped: the call also writes the image here (rows width * 16 bytes), channel -> (direction, coordinate) in cm
     ChanMap cm;
-    double rsx = 1, rsy = 1;
-    float *d_flow[2] = {nullptr, nullptr};  // ... otherwise it copies the flows here
     bool no_graph = true;  // (the oldest request of a call decides; never changes a result)
     int state = 0;  // 0 queued, 1 riding in a call that is being enqueued, 2 enqueued: the caller's stream waits for it
     int rc = OFXCV_OK, batch_pairs = 0;
@@ -390,15 +390,6 @@ struct FlowReq {
     bool led = false;
     char err[256] = {0};
 };
-struct FrameTab {
-    const uint4 *src[2 * OFXCV_FARNEBACK_MAX_BATCH];
-};
-__global__ __launch_bounds__(256) void gather_frames_kernel(FrameTab t, uint4 *__restrict__ dst, size_t vec_per_frame) {
-    const uint4 *__restrict__ s = t.src[blockIdx.y];
-    uint4 *__restrict__ d = dst + (size_t)blockIdx.y * vec_per_frame;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vec_per_frame; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
-}
-
 class FlowQueue {
     std::mutex mu_;
     std::condition_variable cv_;
@@ -442,53 +433,39 @@ class FlowQueue {
                     if (rc) return rc;
                 }
             b->fb_no_graph = batch[0]->no_graph;
-            b->fb_reserve_pairs = std::max(b->fb_reserve_pairs, reserve_pairs);
+            b->fb_reserve_pairs = std::max(b->fb_reserve_pairs, reserve_pairs);  // (the scratch is sized once for the largest call)
             int np = 0;
             for (const FlowReq *r : batch) np += r->n_other;
-            const size_t gray_pitch = align_up((size_t)sg.w, 256), gray = gray_pitch * sg.h, flow_bytes = align_up((size_t)sg.w * sg.h * 8, 256);
-            const int cap = std::max(np, b->fb_reserve_pairs);
-            int rc = ofxcv_reserve(b, b->d_stage, (size_t)cap * (2 * gray + flow_bytes));
-            if (rc) return rc;
-            // slots by pair: pair p reads the frames 2p, 2p + 1 and writes flow p -- the same pointers whoever rides in the call
-            char *dp = (char *)b->d_stage.ptr;
-            FrameTab ft = {};
+            // The call reads the riders' gray frames and writes their flow fields -- and, where all four channels are mapped, their RGBA images (F7 inside
+            // the last level-0 launch) -- IN PLACE: launched kernel by kernel, it has no captured pointers to keep fixed, so nothing is gathered or copied.
+            const size_t gray_pitch = align_up((size_t)sg.w, 256);
             const uint8_t *prevs[OFXCV_FARNEBACK_MAX_BATCH], *nexts[OFXCV_FARNEBACK_MAX_BATCH];
-            float *flows[OFXCV_FARNEBACK_MAX_BATCH];
+            float *flows[OFXCV_FARNEBACK_MAX_BATCH], *rgbas[OFXCV_FARNEBACK_MAX_BATCH];
             size_t gsteps[OFXCV_FARNEBACK_MAX_BATCH], fsteps[OFXCV_FARNEBACK_MAX_BATCH];
+            ptrdiff_t rsteps[OFXCV_FARNEBACK_MAX_BATCH];
+            unsigned mus[OFXCV_FARNEBACK_MAX_BATCH], mvs[OFXCV_FARNEBACK_MAX_BATCH];
             int p = 0;
             for (const FlowReq *r : batch)
                 for (int k = 0; k < r->n_other; k++, p++) {
-                    ft.src[2 * p] = (const uint4 *)r->gray[0];
-                    ft.src[2 * p + 1] = (const uint4 *)r->gray[k + 1];
-                    prevs[p] = (const uint8_t *)(dp + (size_t)(2 * p) * gray);
-                    nexts[p] = (const uint8_t *)(dp + (size_t)(2 * p + 1) * gray);
-                    flows[p] = (float *)(dp + (size_t)cap * 2 * gray + (size_t)p * flow_bytes);
+                    prevs[p] = r->gray[0];
+                    nexts[p] = r->gray[k + 1];
+                    flows[p] = r->d_flow[k];
                     gsteps[p] = gray_pitch;
                     fsteps[p] = (size_t)sg.w * 8;
+                    rgbas[p] = r->d_rgba;
+                    rsteps[p] = (ptrdiff_t)sg.w * 16;
+                    mus[p] = mvs[p] = 0;
+                    for (int c = 0; c < 4 && r->d_rgba; c++)  // the channels this direction owns (resolved by the caller: v over u, the later direction over the earlier)
+                        if (r->cm.k[c] == k) (r->cm.comp[c] ? mvs[p] : mus[p]) |= 1u << c;
                 }
             {
                 std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(b)));
                 for (const FlowReq *r : batch) OFXCV_HIP_CHECK(b, hipStreamWaitEvent(b->compute, r->ready, 0));
             }
-            const size_t vec = gray / 16;
-            hipLaunchKernelGGL(gather_frames_kernel, dim3((unsigned)std::min<size_t>(512, (vec + 255) / 256), 2 * np), dim3(256), 0, b->compute, ft, (uint4 *)dp, vec);
-            OFXCV_LAUNCH_CHECK(b, "gather_frames_kernel");
-            // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0
-            rc = ofxcv_calc_optical_flow_farneback_batch(b, np, prevs, gsteps, nexts, gsteps, flows, fsteps, sg.w, sg.h, 0.5, sg.levels, 3, sg.iterations, sg.poly_n,
-                                                         sg.poly_sigma, 0, b->compute);
+            // VectorGenerator.cpp:391,395,403: pyr_scale 0.5, winsize 3, flags 0; :494-519 the write-back
+            int rc = ofxcv_calc_optical_flow_farneback_batch_rgba(b, np, prevs, gsteps, nexts, gsteps, flows, fsteps, sg.w, sg.h, 0.5, sg.levels, 3, sg.iterations, sg.poly_n,
+                                                                  sg.poly_sigma, 0, rgbas, rsteps, mus, mvs, sg.rsx, sg.rsy, b->compute);
             if (rc) return rc;
-            p = 0;
-            for (const FlowReq *r : batch) {
-                if (r->d_rgba) {
-                    hipLaunchKernelGGL(flows_to_rgba_kernel, dim3(ofxcv_div_up(sg.w, 256), sg.h), dim3(256), 0, b->compute, (const float2 *)flows[p],
-                                       (const float2 *)(r->n_other > 1 ? flows[p + 1] : nullptr), sg.w, sg.h, r->d_rgba, (ptrdiff_t)sg.w * 16, r->cm, r->rsx, r->rsy);
-                    OFXCV_LAUNCH_CHECK(b, "flows_to_rgba_kernel");
-                } else {
-                    for (int k = 0; k < r->n_other; k++)
-                        OFXCV_HIP_CHECK(b, hipMemcpyAsync(r->d_flow[k], flows[p + k], (size_t)sg.w * sg.h * 8, hipMemcpyDeviceToDevice, b->compute));
-                }
-                p += r->n_other;
-            }
             {
                 std::unique_lock<std::shared_mutex> lock(ofxcv_capture_mutex(ofxcv_lock_index(b)));
                 OFXCV_HIP_CHECK(b, hipEventRecord(b->ev_done, b->compute));
@@ -907,20 +884,17 @@ static int flows_host(ofxcv_ctx *ctx, const float *h_ref, ptrdiff_t ref_row_byte
         }
         tr[2] = HostTrace::on() ? HostTrace::now() : 0;
         FlowReq rq;
-        rq.sig = {width, height, levels, iterations, poly_n, ctx->fb_opencv_rounding, ctx->fb_gauss_generation, ctx->fb_filter_contraction, ctx->fb_resize_generation, poly_sigma};
+        rq.sig = {width, height, levels, iterations, poly_n, ctx->fb_opencv_rounding, ctx->fb_gauss_generation, ctx->fb_filter_contraction, ctx->fb_resize_generation, poly_sigma, render_scale_x, render_scale_y};
         rq.n_other = n_other;
         rq.no_graph = true;  // (the queue's call is launched kernel by kernel: no runtime lock held, the first kernels run while the rest is enqueued)
         rq.ready = ctx->ev_done;
         rq.stream = ctx->compute;
         for (int f = 0; f < nf; f++) rq.gray[f] = d_gray[f];
+        rq.d_flow[0] = d_flow[0];
+        rq.d_flow[1] = d_flow[1];
         if (direct_down) {
             rq.d_rgba = d_rgba;
             rq.cm = cm;
-            rq.rsx = render_scale_x;
-            rq.rsy = render_scale_y;
-        } else {
-            rq.d_flow[0] = d_flow[0];
-            rq.d_flow[1] = d_flow[1];
         }
         // pairs per coalesced call: what fills ONE round of the chip in the column-owning form of level 0 (a workgroup per 60-pixel tile column and pair,
         // one workgroup per CU: 8 pairs at 1920x1080, 4 at 3840x2160) -- measured: 12 queued pairs run faster as 8 + (4 + newcomers) than as 12
