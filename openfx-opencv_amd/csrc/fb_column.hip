@@ -2,6 +2,26 @@
 // (one translation unit of the Farneback path; shared declarations: fb.h)
 #include "fb.h"
 
+// Wavefront priorities inside iterate_col_kernel (s_setprio; profiles/r06_experiments.md 5).  A workgroup's eight wavefronts sit two per SIMD
+// (u and u + 4) and hand a token down the line; who issues when both wavefronts of a SIMD are ready decides how long the line waits.  A wavefront
+// working on its step-2 rows goes first (P2), then one on its step-1 rows -- the later wavefront of the SIMD (u + 4: the earlier one's results
+// are already on their way down the line) before the earlier one (P1HI > P1LO) -- and everything else (the next round's loads, the token of
+// step 1) at 0.  Measured on 8 x 1080p: 325 - 330 us without priorities, 298 - 302 us with (1, 2, 3).  Define OFXCV_COL_NOPRIO to compile them out.
+#ifndef OFXCV_COL_P1LO
+#define OFXCV_COL_P1LO 1
+#endif
+#ifndef OFXCV_COL_P1HI
+#define OFXCV_COL_P1HI 2
+#endif
+#ifndef OFXCV_COL_P2
+#define OFXCV_COL_P2 3
+#endif
+#ifdef OFXCV_COL_NOPRIO
+#define OFXCV_SETPRIO(p) do { } while (0)
+#else
+#define OFXCV_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 namespace ofxcv_fb {
 
 // ------------------------------------------------------------------ OpenCV-order window: column-owning workgroups, TWO steps per launch
@@ -507,6 +527,8 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             }
             stamp(r, 1);   // rows of the difference field requested
             chain(0, ticket, sum, P);
+            if (wave < NW / 2) OFXCV_SETPRIO(OFXCV_COL_P1LO);
+            else OFXCV_SETPRIO(OFXCV_COL_P1HI);
             stamp(r, 2);   // chain of step 1 passed
             // (holding the token: every reader of the rows this overwrites is done)
             ring_fill(ticket + kLead);
@@ -573,7 +595,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
         }
         if (SOLVE1 && r + 1 < ca.rounds) load_d(r + 1);  // this round's rows are used up: the next round's arrive during step 2
         if (!LAST1 && r + 1 < ca.rounds) load_r0(r + 1);
-        if (LAST1) continue;
+        if (LAST1) {
+            OFXCV_SETPRIO(0);
+            continue;
+        }
         stamp(r, 4);   // M' complete
         put_boundary(0, r, m1);  // rows RW-3 .. RW-1 for the wavefront below
         {
@@ -608,6 +633,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             chain(1, ticket, sum, P);
             stamp(r, 6);   // chain of step 2 passed
         }
+        OFXCV_SETPRIO(OFXCV_COL_P2);
         float m2[RW][5];
         auto st_d3 = [&](float dv, int i, int c) __attribute__((always_inline)) {  // d''_t, t = a - 2 + i: rows a-1+i and a-4+i of M''
             const int t = a - 2 + i;
@@ -646,7 +672,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             }
         }
         stamp(r, 7);
-        if (LAST2) continue;
+        if (LAST2) {
+            OFXCV_SETPRIO(0);
+            continue;
+        }
         stamp(r, 8);   // M'' complete
         put_boundary(1, r, m2);
         if (topw && own) {  // row 0 of M'' for the next launch's vsum(-1)
@@ -661,6 +690,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #pragma unroll
                 for (int i = 0; i < 3; i++) st_d3(m2[i][c] - (topw ? m2[0][c] : pv[i][c]), i, c);
         }
+        OFXCV_SETPRIO(0);
         stamp(r, 9);   // end of the round
     }
 }
