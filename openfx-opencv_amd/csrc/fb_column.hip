@@ -138,7 +138,10 @@ __device__ __forceinline__ void f7_store(const RgbaTab &rg, int z, int xr, int y
 //     wavefront -- started, and it is itself the next round of ticket g - 14: every reader of the old rows is done;
 //   * a gather whose 64 lanes all sample within +- D of their own pixel (wave-uniform test, one ballot) reads the ring (four ds_read_b128 + two
 //     ds_read2_b32 per pixel); otherwise the whole wavefront-row takes the global gather as before -- same values either way.
-constexpr int kRingD = 4, kRingRows = 64, kRingCols = 64 + 2 * kRingD, kRingLead = 6;
+#ifndef OFXCV_COL_LEAD
+#define OFXCV_COL_LEAD 6
+#endif
+constexpr int kRingD = 4, kRingRows = 64, kRingCols = 64 + 2 * kRingD, kRingLead = OFXCV_COL_LEAD;
 struct ColRing {
     ofxcv_f4 q[kRingRows * kRingCols];
     float c[kRingRows * kRingCols];
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
     static_assert(K2 == kColNone || K2 == kHaloIter || K2 == kHaloLast, "step 2 iterates or ends the level");
     static_assert(LAST1 != TWO, "nothing follows the last step; every other step has a partner");
     static_assert(RW >= 3, "the three boundary rows");
-    constexpr int DEPTH = 1;  // rows whose samples are in flight before the first is consumed (2 and 4 measured the same: r05_experiments.md)
+#ifndef OFXCV_COL_DEPTH
+#define OFXCV_COL_DEPTH 4
+#endif
+    constexpr int DEPTH = OFXCV_COL_DEPTH;  // rows whose samples are in flight before the first is consumed (round 6, with the priorities: 4 is 2 % faster than 1, 207 VGPRs, no spill)
     __shared__ ColLds<NW> lds;
     static_assert(!RING || (K1 == kHaloIter && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
     // Fill groups are four image rows: ticket t fills group t + 6.  (A second geometry, twelve wavefronts of three rows with the boundary rows of both
@@ -717,15 +723,15 @@ bool col_level(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
 // overlapped strips -- the forms are per pair, their fields never meet).  One workgroup per tile column and pair, one workgroup per
 // CU: a launch lasts ceil(workgroups / CUs) rounds, so 33 tile columns x 8 pairs = 264 workgroups on 256 CUs would be TWO rounds
 // (a 1921-pixel-wide frame: 0.94 against 0.65 ms per pair at 1920), and 4 x 32 = 128 workgroups leave half the chip idle for a
-// whole round.  Cost model in rounds of the column-owning launch: a pair in strips costs 0.196 x w / 1920 of a round (2 x 39.7 us
-// against 405 us at 1920x1080; both scale with the level's height) -- it reproduces where the form was measured to pay
+// whole round.  Cost model in rounds of the column-owning launch: a pair in strips costs 0.237 x w / 1920 of a round (2 x 35.8 us
+// against 302 us at 1920x1080; both scale with the level's height) -- it reproduces where the form was measured to pay
 // (profiles/r04_experiments.md: 1080p from 6 pairs, 3840x2160 from 3, not 1080p x 4 or 5).  A farneback.col_min below the default
 // (tests) forces the form wherever it reaches that many workgroups.
 constexpr int kColMinDefault = 128;
 int col_pairs(const ofxcv_ctx *ctx, int w, int h, int n, bool halo) {
     if (!col_level(ctx, w, h, n, halo)) return 0;
     const long T = ofxcv_div_up(w, kColW), cus = std::max(1, ctx->num_cus);
-    const double strip_cost = 0.196 * w / 1920.0;
+    const double strip_cost = 0.237 * w / 1920.0;  // (round 6: 2 x 35.8 us against the 302 us round; rounds 4 - 5: 0.196 = 2 x 39.7 / 405)
     const bool forced = ctx->fb_col_min < kColMinDefault;
     int ncol = 0;
     double best = forced ? 1e30 : n * strip_cost;  // (all pairs in strips)
