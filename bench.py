@@ -500,10 +500,10 @@ def main():
                      "traffic_GBps": (traffic / main_s / 1e9) if traffic else None,
                      "traffic_frac_of_peak": (traffic / main_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                      "traffic_note": "L2 <-> fabric bytes per launch (TCC_EA0 read requests x their size + write requests); Infinity-Cache hits are counted",
-                     "bound_actual": ("the launch moves its minimal bytes (1.42 GB for 8 pairs: every field once per two iterations, traffic_over_min 1.02) at about 0.7 of the copy rate; "
-                                      "what holds it is the workgroup, not memory: a round of 32 rows is 19 k cycles for eight wavefronts that hand two f64 column sums and six boundary "
-                                      "rows to each other, two wavefronts per SIMD (155 KB of LDS: R1 ring + hand-off rows), the vector ALU 51 % busy; the same kernel on a quarter of the "
-                                      "pixels with half the chip idle runs its rounds 8 % faster (profiles/r05_experiments.md 1, 4, 10)" if col else
+                     "bound_actual": ("the launch moves its minimal bytes (every field once per two iterations) at about 0.75 of the copy rate; what holds it is the workgroup, not memory: "
+                                      "eight wavefronts hand two f64 column sums and six boundary rows to each other per round of 32 rows, two wavefronts per SIMD (159 KB of LDS: R1 ring + "
+                                      "hand-off rows); since round 6 s_setprio orders them by phase (step-2 rows first), which spreads the wavefronts evenly over a round and took the "
+                                      "launch from 329 to ~300 us (profiles/r06_experiments.md 5)" if col else
                                       "hbm-side: the kernel moves 1.12x its algorithmic bytes at 0.83 of the achievable copy rate"),
                      "valu_issue_frac": (valu / VALU_ISSUE_PER_S / main_s) if valu else None,
                      "valu_busy_frac": (valu_busy * 4 / (1024 * 2.4e9) / main_s) if valu_busy else None,
