@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
 #endif
     constexpr int DEPTH = OFXCV_COL_DEPTH;  // rows whose samples are in flight before the first is consumed (round 6, with the priorities: 4 is 2 % faster than 1, 207 VGPRs, no spill)
     __shared__ ColLds<NW> lds;
-    static_assert(!RING || (K1 == kHaloIter && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
+    static_assert(!RING || (TWO && RW == 4 && NW == 8), "the ring's fill schedule rides on the step-1 token of eight wavefronts of four rows");
     // Fill groups are four image rows: ticket t fills group t + 6.  (A second geometry, twelve wavefronts of three rows with the boundary rows of both
     // steps in one LDS buffer, ran 2.5 % faster in round 5 and was never the default; removed in round 6 -- profiles/r05_experiments.md 14 has it.)
     constexpr int kLead = kRingLead;
@@ -540,6 +540,21 @@ __global__ __launch_bounds__(64 * NW) void iterate_col_kernel(const float *__res
             ring_fill(ticket + kLead);
             ring_wait(ticket);
             stamp(r, 3);   // fill issued, the rows this ticket reads have landed
+        } else {
+            if constexpr (RING) {
+                // the first step of a level has no column sums to hand on, but the ring's fill schedule rides on the step-1 token (whoever holds
+                // it knows that every reader of the rows its fill overwrites is done): an empty token takes its place
+                double none[5] = {0., 0., 0., 0., 0.};
+#pragma unroll
+                for (int c = 0; c < 5; c++) P[c] = 0.;
+                chain(0, ticket, none, P);
+            }
+            if (wave < NW / 2) OFXCV_SETPRIO(OFXCV_COL_P1LO);
+            else OFXCV_SETPRIO(OFXCV_COL_P1HI);
+            if constexpr (RING) {
+                ring_fill(ticket + kLead);
+                ring_wait(ticket);
+            }
         }
         // Rows below the image repeat the last row (zero differences -> the same column sums -> the same flow -> the same M'):
         // exactly what d'_{h-1} = M'[h-1] - M'[h-3] wants of the row below the image.
@@ -770,6 +785,7 @@ int launch_col_steps(ofxcv_ctx *ctx, hipStream_t s, const float *R0, const float
     else if (k1 == kHaloLast && k2 == kColNone) OFXCV_LAUNCH_COL_K(kHaloLast, kColNone, 4, 8, false, false);
     else if (k1 == kHaloZero && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloIter, 4, 8, false, false);
     else if (k1 == kHaloZero && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloZero, kHaloLast, 4, 8, false, false);
+    else if (k1 == kHaloCoarse && k2 == kHaloIter && ring) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloIter, 4, 8, true, false);
     else if (k1 == kHaloCoarse && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloIter, 4, 8, false, false);
     else if (k1 == kHaloCoarse && k2 == kHaloLast) OFXCV_LAUNCH_COL_K(kHaloCoarse, kHaloLast, 4, 8, false, false);
     else if (k1 == kHaloGiven && k2 == kHaloIter) OFXCV_LAUNCH_COL_K(kHaloGiven, kHaloIter, 4, 8, false, false);

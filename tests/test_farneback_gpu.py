@@ -973,11 +973,11 @@ def test_column_owning_abort_word_is_reported_once(oracle, ofxcv):
 
 def test_column_owning_plan(gpu_ctx):
     """ofxcv_farneback_col_pairs: how many pairs of a call walk level 0 in the column-owning form (256 CUs, one workgroup per
-    tile column and pair, launches charged in rounds of the chip against 0.196 x w / 1920 of a round per pair in strips)."""
+    tile column and pair, launches charged in rounds of the chip against 0.237 x w / 1920 of a round per pair in strips: from 5 pairs at 1920x1080 since round 6)."""
     if gpu_ctx.get_option("farneback.col") != 1:
         pytest.skip("column-owning form switched off on the shared context")
     plan = lambda w, h, n: gpu_ctx.farneback_col_pairs(w, h, n)
-    assert [plan(1920, 1080, n) for n in (1, 4, 5, 6, 7, 8, 9, 12, 16)] == [0, 0, 0, 6, 7, 8, 8, 8, 16]
+    assert [plan(1920, 1080, n) for n in (1, 4, 5, 6, 7, 8, 9, 12, 16)] == [0, 0, 5, 6, 7, 8, 8, 8, 16]
     assert [plan(1921, 1081, n) for n in (8, 16)] == [7, 15]          # 33 tile columns: 264 workgroups would be two rounds
     assert [plan(3840, 2160, n) for n in (1, 2, 3, 4, 5, 8)] == [0, 0, 3, 4, 4, 8]
     assert plan(1920, 40, 8) == 0                                     # too few rows for a column walk
