@@ -98,13 +98,13 @@ int ofxcv_ctx_synchronize(ofxcv_ctx *ctx, void *stream);
  *                                    flight on the device, else 0;
  *   "host.cache_mb"           n      budget of the device's cache of named frames (ofxcv_vectorgen_flows_host_keyed), default 512, 0 = off;
  *   "host.coalesce"           0|1|2  host-image calls of several render threads on one device (the reference is eRenderFullySafe,
- *                                    VectorGenerator.cpp:108): 1 (default) a call that finds "host.coalesce_min" (3) host-image calls in flight on
+ *                                    VectorGenerator.cpp:108): 1 (default) a call that finds "host.coalesce_min" (4) host-image calls in flight on
  *                                    its device, itself included, hands its frame pairs to the device's submission queue; the first caller that
  *                                    finds no coalesced call running runs everything queued as ONE batched Farneback call, the callers download
  *                                    their own images.  0 every call runs its own; 2 every call goes through the queue (tests).  Same results.
  *   "host.coalesce_max"       n      frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip in the
  *                                    column-owning form of level 0: 8 pairs at 1920x1080, 4 at 3840x2160;
- *   "host.coalesce_min"       n      see host.coalesce (default 3);
+ *   "host.coalesce_min"       n      see host.coalesce (default 4: measured at 1920x1080, three threads are faster with their own calls);
  * -- inpaint --
  *   "inpaint.tiles" 0|1, "inpaint.max_tiles" n   tile schedule of the pipelined fill (1), workgroups per fill launch (0 = this call's share of the
  *                                    chip: 192 over the fills in flight, at least 48);

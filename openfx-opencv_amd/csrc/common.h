@@ -143,7 +143,7 @@ struct ofxcv_ctx {
                                    // (also a lone call: tests)
     int host_coalesce_max = 0;     // option "host.coalesce_max": frame pairs per coalesced call (2 .. OFXCV_FARNEBACK_MAX_BATCH); 0 (default) = one round of the chip
                                    // in the column-owning form of level 0 (8 pairs at 1920x1080, 4 at 3840x2160)
-    int host_coalesce_min = 3;     // option "host.coalesce_min": host-image calls in flight on the device (this one included) from which a call goes to the queue
+    int host_coalesce_min = 4;     // option "host.coalesce_min": host-image calls in flight on the device (this one included) from which a call goes to the queue
     long host_coalesced_calls = 0, host_coalesced_pairs = 0, host_coalesced_batches = 0;  // calls of this context served by the queue, their pairs, the pairs of the batches they rode in
     int fb_reserve_pairs = 0;      // the Farneback scratch is sized for at least this many pairs (the batch context of the submission queue: no re-allocation as batches grow)
     int host_cache_mb = 512;       // option "host.cache_mb": budget of the device's cache of named frames' gray images (0 = off)

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void flows_to_rgba_kernel(const float2 *__rest
 // VectorGenerator is eRenderFullySafe with host frame threading off (VectorGenerator.cpp:108, GenericOpenCVPlugin.cpp:350-357): a host renders
 // several output frames at once, each render() on its own thread with its own context.  Left alone, every thread submits its own call of two
 // pairs, and from five threads on the GPU runs many 2-pair calls beside each other (1 000 - 1 120 pairs/s at 1920x1080) where calls of 8 pairs
-// reach 1 700: level 0 only takes the column-owning form (two iterations per launch) from 6 pairs on.  So a call that finds host.coalesce_min (3)
+// reach 1 700: level 0 only takes the column-owning form (two iterations per launch) from 5 pairs on.  So a call that finds host.coalesce_min (4)
 // host-image calls in flight on its device, itself included, does not start a Farneback call of its own: it uploads and converts its frames as
 // ever, records an event behind the last conversion and hands its pairs to the device's SUBMISSION QUEUE.  The first caller that finds no
 // coalesced call running becomes the leader: it takes everything queued with its geometry and parameters, up to one round of the chip (its own

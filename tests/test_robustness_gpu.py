@@ -506,6 +506,7 @@ def test_coalesced_host_calls_from_render_threads(ofxcv, nthreads):
     def work(k):
         try:
             c = ofxcv.Context(0)
+            c.set_option("host.coalesce_min", 2)             # (default 4: with four threads the queue would only engage when all four are in flight at once)
             si = k % 2 if k >= nthreads // 2 else 0           # most threads share a size, some render the other one
             w, h = sizes[si]
             start.wait()
