@@ -475,8 +475,8 @@ def main():
                     "held (0 holds); with farneback.graph 1 it is one hipGraphLaunch of 200-350 us" % B},
         "col_aborts": col_aborts,  # 1 if a bounded LDS wait of iterate_col_kernel ever ran out (never seen)
         "value_direct_window": statistics.median(drates) if drates else None,
-        "value_direct_window_stats": None if not drates else dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0: each 3x3 window summed directly, two iterations "
-                                          "fused per launch; does NOT meet 1e-4 at every sample (see parity)"),
+        "value_direct_window_stats": None if not drates else dict(stats(drates), note="opt-in mode farneback.opencv_rounding=0 (C ABI only): each 3x3 window summed directly by the generic window kernel, one iteration "
+                                          "per launch; does NOT meet 1e-4 at every sample (see parity)"),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
                      "traffic_source": "offline PMC (rocprofv3 --pmc, separate passes), %s" % PMC_FILE if traffic else None,
@@ -510,7 +510,7 @@ def main():
                      "valu_issue_note": "SQ_INSTS_VALU per launch (offline PMC) x %.1f clk per wave64 instruction (see VALU_CLK_PER_WAVE_INSTR in bench.py) "
                                         "/ (1024 SIMDs x 2.4 GHz) / launch time; valu_busy_frac = SQ_ACTIVE_INST_VALU (busy quad-cycles) x 4 / the same" % VALU_CLK_PER_WAVE_INSTR,
                      "direct_window_kernel": None if not fused_s else {
-                         "kernel": "iterate3x2_kernel<true> (two fused iterations per launch, direct sums)",
+                         "kernel": "blur_solve_update_kernel<true> (the generic box window: one iteration of one pair per launch, direct sums; the fused two-iteration kernel of rounds 1-5 was removed)",
                          "avg_launch_us": fused_s * 1e6, "launches_timed": fused_n, "bytes_per_launch": iter_bytes_pair,
                          "achieved": iter_bytes_pair / fused_s / 1e9, "frac": iter_bytes_pair / fused_s / 1e9 / HBM_PEAK_GBS,
                          "traffic": pf.get("traffic_bytes_per_launch"),

@@ -27,7 +27,7 @@ out = {"method": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh over a sh
                  "launches at level 0 one pair",
        "kernels": {}}
 want = {"iterate_col_kernel<1, 1,": "opencv_order_col_two_iterations_level0", "iterate3h_kernel<1, 9, 8": "opencv_order_halo_iteration_level0",
-        "iterate3x2_kernel<true>": "direct_window_fused_pair_level0"}
+        "blur_solve_update_kernel<true>": "direct_window_iteration_level0"}
 for (name, grid), c in rows.items():
     for k, tag in want.items():
         if name.startswith(k) and "TCC_EA0_RDREQ_sum" in c:
